@@ -1,0 +1,73 @@
+# -*- coding: utf-8 -*-
+import os
+import sys
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line(
+        "markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'))
+
+
+def two_chirps(N, seed=0, noise=0.1):
+    """Signal family of SURVEY.md section 8(d) (same formula as
+    oracle/gen_golden.py:two_chirps)."""
+    rng = np.random.default_rng(seed)
+    f0 = rng.uniform(0.01, 0.05)
+    f1 = rng.uniform(0.30, 0.45)
+    t = np.arange(N) / N
+    ph = f0 * N * t + 0.5 * (f1 - f0) * N * t**2
+    return (np.cos(2 * np.pi * ph) + np.cos(2 * np.pi * (ph + 0.04 * N * t))
+            + noise * rng.standard_normal(N))
+
+
+def kernel_inputs(dtype, na, n):
+    """Seeded inputs of the kernel-level fixtures (oracle/gen_golden.py:gen_kernels,
+    modelled on the reference's tests/fft_test.py:284-315)."""
+    np.random.seed(0)
+    Wx = np.random.randn(na, n).astype(dtype) * (1 + 2j)
+    dWx = np.random.randn(na, n).astype(dtype) * (2 - 1j)
+    w = np.abs(np.random.randn(na, n).astype(dtype))
+    w *= (2 * na / w.max())
+    Sfs = np.linspace(0, .5, na).astype(dtype)
+    Wx[3, 5] = 1e-4 * (1 + 1j)
+    Wx[7, 9] = 0
+    winf = w.copy()
+    winf[2, 3] = np.inf
+    x = np.random.randn(1000).astype(dtype)
+    return Wx, dWx, w, winf, Sfs, x
+
+
+def make_ssq_freqs(M, scaletype):
+    # grids of the reference's kernel tests (tests/fft_test.py:236-246)
+    if scaletype == 'log-piecewise':
+        sf = np.logspace(0, np.log10(M), 2 * M)
+        return np.hstack([sf[:M // 2], sf[M // 2 + 3 - 1::3]])
+    elif scaletype == 'log':
+        return np.logspace(0, np.log10(M), M)
+    return np.linspace(0, M, M)
+
+
+def const_of(kind, na, dtype):
+    if kind == 'scalar':
+        return np.log(2) / 32
+    v = np.log(2) / np.linspace(8, 32, na)
+    return v if kind == 'vec64' else v.astype(dtype)
+
+
+@pytest.fixture(scope='session')
+def orc():
+    from oracle import oracle
+    oracle.lib()
+    return oracle
