@@ -1,0 +1,209 @@
+/*
+ * ssq_hip.h -- C ABI of libssq_hip.so, the MI355X (gfx950) engine behind
+ * ssqueezepy_amd's cwt() / stft() / ssq_cwt() / ssq_stft().
+ *
+ * The reference (OverLordGoldDragon/ssqueezepy v0.6.6) has no FFI: its GPU seam is
+ * Python-level -- CuPy RawModule kernels launched with raw device pointers on
+ * torch's current stream (ssqueezepy/utils/gpu_utils.py:10-21, algos.py:100-105).
+ * This header is that seam restated as a C ABI: plain pointers and sizes, no torch
+ * or HIP types in the signatures (`stream` is a hipStream_t passed as void*, NULL =
+ * the default stream), every entry point asynchronous on its stream, int status
+ * returns (0 = ok, <0 = error, text via ssq_last_error()), no exceptions across the
+ * boundary. Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   dtype      SSQ_F32 / SSQ_F64: the *real* type; complex arrays are interleaved
+ *              (re, im) pairs of it (what torch.view_as_real gives, algos.py:61-64).
+ *   layouts    2-D arrays are row-major (rows = scales / frequency bins,
+ *              cols = time); batched arrays put the signal index first.
+ *   ownership  the caller owns every I/O buffer (device memory); plans own their
+ *              FFT plans, workspace and the device copy of the filter bank.
+ *   threading  one plan per host thread / stream at a time; plans are immutable
+ *              after creation except through the documented setters.
+ */
+#ifndef SSQ_HIP_H
+#define SSQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSQ_F32 0
+#define SSQ_F64 1
+
+#define SSQ_GRID_LOG 0            /* params: vlmin, dvl                         */
+#define SSQ_GRID_LOG_PIECEWISE 1  /* params: vlmin0, vlmin1, dvl0, dvl1, idx1   */
+#define SSQ_GRID_LIN 2            /* params: vmin, dv                           */
+
+#define SSQ_PAD_NONE (-1)
+#define SSQ_PAD_ZERO 0
+#define SSQ_PAD_REFLECT 1
+#define SSQ_PAD_SYMMETRIC 2
+#define SSQ_PAD_REPLICATE 3
+#define SSQ_PAD_WRAP 4
+
+/* ------------------------------------------------------------------ runtime */
+int         ssq_version(void);
+const char* ssq_last_error(void);
+int         ssq_device_count(int* count);
+int         ssq_set_device(int device);
+/* name[0..len) <- gcnArchName of `device`; *cus <- compute-unit count */
+int         ssq_device_info(int device, char* name, int len, int* cus,
+                            int64_t* hbm_bytes);
+
+/* Raw device-memory helpers for hosts that do not bring their own allocator
+ * (the Python layer normally passes torch-owned device pointers instead). */
+int ssq_malloc(void** ptr, int64_t bytes);
+int ssq_free(void* ptr);
+int ssq_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream);
+int ssq_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream);
+int ssq_memset(void* dst, int value, int64_t bytes, void* stream);
+int ssq_stream_synchronize(void* stream);
+
+/* ---------------------------------------------------- kernel-level seam
+ * These are the reference's L2 kernels. All arrays are
+ * (batch, na, n) device arrays; `batch` >= 1.
+ */
+
+/* w = |Wx| < gamma ? inf : |Im(dWx / Wx)| / 2pi
+ * replaces phase_cwt_cpu / phase_cwt_gpu (algos.py:706-781). */
+int ssq_phase_cwt(int dtype, const void* Wx, const void* dWx, void* w,
+                  int64_t batch, int64_t na, int64_t n, double gamma,
+                  void* stream);
+
+/* w = |Sx| < gamma ? inf : |Sfs[i] - Im(dSx / Sx) / 2pi|
+ * replaces phase_stft_cpu / phase_stft_gpu (algos.py:784-856). Sfs: (na,) real. */
+int ssq_phase_stft(int dtype, const void* Sx, const void* dSx, const void* Sfs,
+                   void* w, int64_t batch, int64_t na, int64_t n, double gamma,
+                   void* stream);
+
+/* Fused phase transform + bin search + accumulate:
+ *   for every (i, j) with |Wx[i,j]| > gamma:  Tx[k(i,j), j] += Wx[i,j] * cst[i]
+ * with k from `grid`/`params` (and mirrored, k -> na-1-k, if `flipud`).
+ * `Sfs` NULL selects the CWT form of w, non-NULL the STFT form.
+ * `cst` is a device vector of na weights: real `dtype`, or float64 when
+ * `cst_f64` != 0 (complex64 data weighted by a float64 vector accumulates in
+ * double, as the reference does for 'log-piecewise' scales).
+ * Tx is OVERWRITTEN (zero-filled and accumulated by the kernel).
+ * `kmap` (optional, int32 (batch, na, n)) receives the bin of every point, -1 where
+ * the point is below threshold.
+ * replaces ssqueeze_fast -> _ssq_cwt_{log,log_piecewise,lin}[_par], _ssq_stft[_par]
+ * and the CUDA strings ssq_cwt_* / ssq_stft (algos.py:126-150, 859-984, 1008-1167).
+ * Summation order per output cell is ascending i, as in the reference.
+ */
+int ssq_ssqueeze(int dtype, const void* Wx, const void* dWx, const void* Sfs,
+                 void* Tx, const void* cst, int cst_f64, int64_t batch,
+                 int64_t na, int64_t n, double gamma, int grid,
+                 const double* params, int flipud, int32_t* kmap, void* stream);
+
+/* Same accumulate, bins taken from a precomputed phase transform `w` (inf = skip).
+ * replaces indexed_sum_onfly -> _indexed_sum_{log,log_piecewise,lin}[_par] and the
+ * CUDA strings indexed_sum_* (algos.py:153-250, 1169-1268). */
+int ssq_indexed_sum(int dtype, const void* Wx, const void* w, void* Tx,
+                    const void* cst, int cst_f64, int64_t batch, int64_t na,
+                    int64_t n, int grid, const double* params, int flipud,
+                    void* stream);
+
+/* w[q] = replacement where |ref[q]| < value.
+ * replaces replace_under_abs (algos.py:498-579). */
+int ssq_replace_under_abs(int dtype, void* w, const void* ref, int64_t count,
+                          double value, double replacement, void* stream);
+
+/* STFT framing: out (batch, seg_len, n_segs) <- x (batch, n_x);
+ * n_segs = (n_x - seg_len) / (seg_len - n_overlap) + 1; `modulated` rotates every
+ * frame by ceil(seg_len/2). replaces buffer / _buffer_gpu
+ * (utils/stft_utils.py:20-138). */
+int ssq_buffer(int dtype, const void* x, void* out, int64_t batch, int64_t n_x,
+               int64_t seg_len, int64_t n_overlap, int modulated, void* stream);
+
+/* Signal extension: out (batch, n1 + n + n2) <- x (batch, n).
+ * replaces padsignal (utils/common.py:54-158). */
+int ssq_pad_signal(int dtype, const void* x, void* out, int64_t batch, int64_t n,
+                   int64_t n1, int64_t n2, int padtype, void* stream);
+
+/* ----------------------------------------------------------------- CWT plan
+ * Replaces the body of cwt() (_cwt.py:255-306: pad -> fft -> Psih*xh -> ifft
+ * [-> *1j*xi/dt -> ifft] -> unpad) and, when ssq parameters are set, the
+ * ssq_cwt() tail (_ssq_cwt.py:266-289 -> ssqueezing.py:122-146).
+ *
+ * The filter bank is passed in *banded* form: row i is non-negligible only on DFT
+ * bins [band_lo[i], band_lo[i] + band_len[i]) of the M-point grid (bins above M/2
+ * are negative frequencies); its values are bank[band_off[i] .. band_off[i+1]).
+ * The Nyquist bin must already be halved (wavelets.py:86-95).
+ */
+typedef struct ssq_cwt_plan ssq_cwt_plan;
+
+typedef struct {
+    int      dtype;        /* SSQ_F32 | SSQ_F64 (the wavelet's dtype)             */
+    int      padtype;      /* SSQ_PAD_*                                           */
+    int64_t  n;            /* signal length N                                     */
+    int64_t  m;            /* padded length M (== n when padtype NONE)            */
+    int64_t  n1;           /* left pad                                            */
+    int64_t  na;           /* number of scales                                    */
+    const void*    bank;       /* host, real dtype, concatenated band values     */
+    const int64_t* band_off;   /* host, na + 1                                    */
+    const int32_t* band_lo;    /* host, na                                        */
+    double   dt;           /* sampling period (derivative multiplier 1j*xi/dt)    */
+    const void*    row_scale;  /* host, na reals or NULL: per-row output scaling  */
+                               /* (sqrt(scale) when l1_norm=False, _cwt.py:307)   */
+    int64_t  max_batch;    /* largest batch the plan will be executed with        */
+    int      algo;         /* 0 = auto, 1 = force generic (rocFFT) path           */
+} ssq_cwt_desc;
+
+int  ssq_cwt_plan_create(ssq_cwt_plan** plan, const ssq_cwt_desc* desc);
+void ssq_cwt_plan_destroy(ssq_cwt_plan* plan);
+
+/* Synchrosqueezing parameters for subsequent executes (host pointers, copied). */
+int  ssq_cwt_plan_set_ssq(ssq_cwt_plan* plan, int grid, const double* params,
+                          const void* cst, int cst_f64, int flipud, double gamma);
+
+/* x: (batch, n) real `dtype` on the device. Outputs (any may be NULL):
+ *   Wx, dWx, Tx : (batch, na, n) complex;   w : (batch, na, n) real.
+ * `rpadded` != 0 returns Wx/dWx of padded width m instead (Tx/w must be NULL).
+ * Tx requires ssq_cwt_plan_set_ssq(); bins come from dWx (fused form) unless `w` is
+ * requested, in which case they come from the rounded `w` (two-step form,
+ * get_w=True in the reference). */
+int  ssq_cwt_execute(ssq_cwt_plan* plan, const void* x, int64_t batch, void* Wx,
+                     void* dWx, void* Tx, void* w, int rpadded, void* stream);
+
+/* bytes of device memory held by the plan (bank + workspace) */
+int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);
+/* name of the compute path the plan selected ("rocfft", "zoom+rocfft", ...) */
+const char* ssq_cwt_plan_algo(const ssq_cwt_plan* plan);
+
+/* ---------------------------------------------------------------- STFT plan
+ * Replaces the body of stft() (_stft.py:127-147,166-170: pad -> buffer -> *window
+ * -> rfft along the frame axis) and, with ssq parameters, the ssq_stft() tail
+ * (_ssq_stft.py:102-122).
+ */
+typedef struct ssq_stft_plan ssq_stft_plan;
+
+typedef struct {
+    int      dtype;
+    int      padtype;
+    int64_t  n;            /* signal length                                       */
+    int64_t  n_fft;        /* frame length                                        */
+    int64_t  hop_len;
+    int      modulated;
+    const void* window;       /* host, n_fft reals (already ifftshift-ed if        */
+    const void* diff_window;  /* modulated; diff_window already times fs), or NULL */
+    int64_t  max_batch;
+} ssq_stft_desc;
+
+int  ssq_stft_plan_create(ssq_stft_plan** plan, const ssq_stft_desc* desc);
+void ssq_stft_plan_destroy(ssq_stft_plan* plan);
+int  ssq_stft_plan_set_ssq(ssq_stft_plan* plan, const void* Sfs, int grid,
+                           const double* params, const void* cst, int cst_f64,
+                           int flipud, double gamma);
+/* rows = n_fft/2 + 1, n_hops = (n - 1) / hop_len + 1 -> query */
+int  ssq_stft_plan_shape(const ssq_stft_plan* plan, int64_t* rows, int64_t* n_hops);
+/* x: (batch, n). Sx, dSx, Tx: (batch, rows, n_hops) complex; w: real. */
+int  ssq_stft_execute(ssq_stft_plan* plan, const void* x, int64_t batch, void* Sx,
+                      void* dSx, void* Tx, void* w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSQ_HIP_H */

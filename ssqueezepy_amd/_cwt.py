@@ -1,0 +1,254 @@
+# -*- coding: utf-8 -*-
+"""Continuous Wavelet Transform on the MI355X.
+
+`cwt` keeps the signature, argument meaning, return values and error behaviour of
+the reference's ``ssqueezepy.cwt`` (ssqueezepy/_cwt.py:12-320). What differs is
+where the work happens: the reference broadcasts ``Psih * xh`` into dense
+``(na, M)`` temporaries and runs two batched iFFTs through torch; here a cached
+*plan* (libssq_hip.so, `ssq_cwt_*` in include/ssq_hip.h) owns the banded filter
+bank, the FFT plans and the workspace on the device, and `cwt` is a thin host
+wrapper: design step (cached) -> one `ssq_cwt_execute` call.
+"""
+import ctypes
+import logging
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, F32, F64, CwtDesc
+from . import algos
+from ._bank import banded_bank
+from .padding import pad_geometry, PADTYPES
+from .scales import process_scales, _process_fs_and_t
+from .wavelets import Wavelet
+
+WARN = lambda msg: logging.warning("WARNING: %s" % msg)
+
+__all__ = ['cwt', 'CwtPlan', 'get_cwt_plan', 'clear_plan_cache']
+
+_TDT = {'float32': torch.float32, 'float64': torch.float64}
+_CDT = {'float32': torch.complex64, 'float64': torch.complex128}
+
+
+class CwtPlan():
+    """Host handle of a device CWT plan for one
+    ``(wavelet, scales, N, padtype, dt, l1_norm)`` configuration."""
+
+    def __init__(self, wavelet, scales, N, padtype='reflect', dt=1., l1_norm=True,
+                 max_batch=1, band_tol=None, algo=0):
+        self.lib = _lib.load()
+        algos._require_gpu()
+        self.dtype = wavelet.dtype
+        self.N = int(N)
+        self.padtype = padtype
+        if padtype is not None:
+            self.M, self.n1, self.n2 = pad_geometry(self.N)
+        else:
+            self.M, self.n1, self.n2 = self.N, 0, 0
+        rdt = np.dtype(self.dtype)
+        self.scales = np.ascontiguousarray(np.asarray(scales, dtype=rdt).reshape(-1))
+        self.na = len(self.scales)
+        self.max_batch = int(max_batch)
+        vals, off, lo = banded_bank(wavelet, self.scales, self.M, tol=band_tol,
+                                    nohalf=False)
+        self.bank_nnz = int(off[-1])
+        row_scale = None
+        if not l1_norm:
+            row_scale = np.ascontiguousarray(np.sqrt(self.scales).astype(rdt))
+        desc = CwtDesc()
+        desc.dtype = F32 if self.dtype == 'float32' else F64
+        desc.padtype = _lib.PAD[padtype]
+        desc.n, desc.m, desc.n1, desc.na = self.N, self.M, self.n1, self.na
+        desc.bank = vals.ctypes.data
+        desc.band_off = off.ctypes.data
+        desc.band_lo = lo.ctypes.data
+        desc.dt = float(dt)
+        desc.row_scale = row_scale.ctypes.data if row_scale is not None else None
+        desc.max_batch = self.max_batch
+        desc.algo = int(algo)
+        self._h = ctypes.c_void_p()
+        check(self.lib.ssq_cwt_plan_create(ctypes.byref(self._h), ctypes.byref(desc)))
+        self._ssq_key = None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            try:
+                self.lib.ssq_cwt_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def algo(self):
+        return self.lib.ssq_cwt_plan_algo(self._h).decode()
+
+    @property
+    def device_bytes(self):
+        return int(self.lib.ssq_cwt_plan_bytes(self._h))
+
+    def set_ssq(self, grid, params, const, flipud, gamma):
+        """Synchrosqueezing parameters for subsequent `execute(..., Tx=...)`."""
+        const = np.asarray(const)
+        if const.size != self.na:
+            const = np.full(self.na, float(const))
+        const = const.reshape(-1)
+        c64 = int(self.dtype == 'float32' and const.dtype == np.float64)
+        if not c64:
+            const = const.astype(self.dtype)
+        const = np.ascontiguousarray(const)
+        key = (int(grid), tuple(float(v) for v in params), const.tobytes(),
+               bool(flipud), float(gamma))
+        if key == self._ssq_key:
+            return
+        check(self.lib.ssq_cwt_plan_set_ssq(self._h, int(grid), _lib.params5(params),
+                                            const.ctypes.data, c64,
+                                            int(bool(flipud)), float(gamma)))
+        self._ssq_key = key
+
+    def execute(self, x, want_dWx=False, want_Tx=False, want_w=False, rpadded=False):
+        """x: GPU tensor (N,) or (B, N) in the plan dtype. Returns a dict of GPU
+        tensors: 'Wx' always, 'dWx' / 'Tx' / 'w' as requested."""
+        batched = (x.ndim == 2)
+        B = x.shape[0] if batched else 1
+        if B > self.max_batch:
+            raise ValueError("batch %d exceeds the plan's max_batch %d"
+                             % (B, self.max_batch))
+        cols = self.M if rpadded else self.N
+        shape = (B, self.na, cols) if batched else (self.na, cols)
+        dev = x.device
+        cdt, rdt = _CDT[self.dtype], _TDT[self.dtype]
+        out = {'Wx': torch.empty(shape, dtype=cdt, device=dev)}
+        if want_dWx:
+            out['dWx'] = torch.empty(shape, dtype=cdt, device=dev)
+        if want_Tx:
+            out['Tx'] = torch.empty(shape, dtype=cdt, device=dev)
+        if want_w:
+            out['w'] = torch.empty(shape, dtype=rdt, device=dev)
+        p = lambda k: out[k].data_ptr() if k in out else None
+        check(self.lib.ssq_cwt_execute(self._h, x.data_ptr(), B, p('Wx'), p('dWx'),
+                                       p('Tx'), p('w'), int(bool(rpadded)),
+                                       algos.stream()))
+        return out
+
+
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 8
+
+
+def clear_plan_cache():
+    _PLAN_CACHE.clear()
+
+
+def get_cwt_plan(wavelet, scales, N, padtype, dt, l1_norm, batch, cache=True):
+    """Plan lookup/creation. Plans are cached per configuration and device (the
+    analogue of the reference's ``cache_wavelet`` / ``Wavelet.Psih`` cache, and of
+    CuPy's kernel memoisation, utils/gpu_utils.py:17)."""
+    scales = np.asarray(scales).reshape(-1)
+    key = (wavelet.key(), scales.tobytes(), int(N), padtype, float(dt),
+           bool(l1_norm), torch.cuda.current_device())
+    plan = _PLAN_CACHE.get(key) if cache else None
+    if plan is not None and plan.max_batch >= batch:
+        return plan
+    plan = CwtPlan(wavelet, scales, N, padtype=padtype, dt=dt, l1_norm=l1_norm,
+                   max_batch=batch)
+    if cache:
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
+def _process_gmw_wavelet(wavelet, l1_norm):
+    """Keep a GMW's `norm` consistent with `l1_norm` (_cwt.py:497-513)."""
+    norm = 'bandpass' if l1_norm else 'energy'
+    if isinstance(wavelet, str) and wavelet.lower()[:3] == 'gmw':
+        wavelet = ('gmw', {'norm': norm})
+    elif isinstance(wavelet, tuple) and wavelet[0].lower()[:3] == 'gmw':
+        name, opts = wavelet
+        opts = dict(opts)
+        opts['norm'] = opts.get('norm', norm)
+        wavelet = (name, opts)
+    elif isinstance(wavelet, Wavelet) and wavelet.family == 'gmw':
+        is_l2 = wavelet.config.get('norm') == 'energy'
+        if is_l2 and l1_norm:
+            raise ValueError("using GMW L2 wavelet with `l1_norm=True`")
+        elif not is_l2 and not l1_norm:
+            raise ValueError("using GMW L1 wavelet with `l1_norm=False`")
+    return wavelet
+
+
+def _zero_nonfinite_inplace(x):
+    bad = ~np.isfinite(x)
+    if bad.any():
+        WARN("found NaN or inf values in `x`; will zero")
+        x[bad] = 0.
+
+
+def cwt(x, wavelet='gmw', scales='log-piecewise', fs=None, t=None, nv=32,
+        l1_norm=True, derivative=False, padtype='reflect', rpadded=False,
+        vectorized=True, astensor=True, cache_wavelet=None, order=0, average=None,
+        nan_checks=None, patience=0):
+    """Continuous Wavelet Transform via FFT convolution with frequency-domain
+    wavelets matching the (padded) input's length; computed on the GPU in the
+    wavelet's dtype.
+
+    Arguments and returns follow ``ssqueezepy.cwt`` (ssqueezepy/_cwt.py:12-165):
+
+        x: np.ndarray / torch.Tensor, 1D or 2D (2D = batch of signals along dim 0)
+        wavelet: str / tuple[str, dict] / Wavelet
+        scales: 'log' | 'log-piecewise' | 'linear' | 'log:maximal' ... | np.ndarray
+        fs, t: sampling rate / time vector (for `dWx`)
+        nv: voices per octave;  l1_norm: L1 (True) or L2 normalisation
+        derivative: also return `dWx` (frequency-domain time derivative)
+        padtype: 'reflect' | 'symmetric' | 'replicate' | 'wrap' | 'zero' | None
+        rpadded: return the padded-width transform
+        astensor: True -> torch tensors on the GPU, False -> NumPy arrays
+
+    Returns ``(Wx, scales)`` or ``(Wx, scales, dWx)``; `Wx` is ``(na, N)``
+    (``(B, na, N)`` for batched input), `scales` a NumPy vector in the wavelet
+    dtype. `vectorized`, `patience` are accepted and ignored (the device path has
+    one execution strategy); `cache_wavelet=False` bypasses the plan cache.
+    Higher-order GMWs (`order > 0`) are outside the accelerated path.
+    """
+    if isinstance(order, (tuple, list, range)) or order > 0:
+        raise NotImplementedError("`order > 0` (higher-order GMWs) is not part of "
+                                  "the accelerated path")
+    if not hasattr(x, 'ndim'):
+        raise TypeError("`x` must be a numpy array or torch Tensor "
+                        "(got %s)" % type(x))
+    elif x.ndim not in (1, 2):
+        raise ValueError("`x` must be 1D or 2D (got x.ndim == %s)" % x.ndim)
+    if padtype is not None and padtype not in PADTYPES:
+        raise ValueError("`padtype` must be one of: %s (got %s)"
+                         % (', '.join(PADTYPES), padtype))
+    if nan_checks is None:
+        nan_checks = bool(isinstance(x, np.ndarray))
+    if nan_checks:
+        if not isinstance(x, np.ndarray):
+            raise ValueError("`nan_checks=True` requires NumPy input.")
+        _zero_nonfinite_inplace(x)
+    if not isinstance(scales, str):
+        nv = None
+    N = x.shape[-1]
+    dt, *_ = _process_fs_and_t(fs, t, N=N)
+
+    use_cache = True if cache_wavelet is None else bool(cache_wavelet)
+    wavelet = _process_gmw_wavelet(wavelet, l1_norm)
+    wavelet = Wavelet._init_if_not_isinstance(wavelet)
+    dtype = wavelet.dtype
+
+    scales = process_scales(scales, N, wavelet, nv=nv)
+    scales = np.asarray(scales, dtype=dtype)
+
+    xd = algos.to_device(x, _TDT[dtype])
+    B = xd.shape[0] if xd.ndim == 2 else 1
+    plan = get_cwt_plan(wavelet, scales, N, padtype, dt, l1_norm, B, cache=use_cache)
+    out = plan.execute(xd, want_dWx=derivative, rpadded=(rpadded and
+                                                         padtype is not None))
+    Wx, dWx = out['Wx'], out.get('dWx')
+    scales = scales.squeeze()
+    if not astensor:
+        Wx = Wx.cpu().numpy()
+        dWx = dWx.cpu().numpy() if dWx is not None else None
+    return (Wx, scales, dWx) if derivative else (Wx, scales)

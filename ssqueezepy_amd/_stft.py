@@ -1,0 +1,244 @@
+# -*- coding: utf-8 -*-
+"""Short-Time Fourier Transform on the MI355X.
+
+`stft` / `get_window` keep the signatures and semantics of the reference
+(ssqueezepy/_stft.py:13-181, 259-335). The window design (DPSS by default, its
+frequency-domain derivative, denormal flushing, NOLA warnings) is host NumPy /
+SciPy as in the reference; framing, windowing and the real FFT run on the device
+through a cached plan (`ssq_stft_*` in include/ssq_hip.h).
+"""
+import ctypes
+import logging
+import numpy as np
+import scipy.signal as sig
+import torch
+
+from . import _lib
+from ._lib import check, F32, F64, StftDesc
+from . import algos
+from .configs import defaults
+from .padding import PADTYPES
+from .scales import _process_fs_and_t
+from .wavelets import xi_grid
+
+WARN = lambda msg: logging.warning("WARNING: %s" % msg)
+
+__all__ = ['stft', 'get_window', 'StftPlan', 'get_stft_plan']
+
+_TDT = {'float32': torch.float32, 'float64': torch.float64}
+_CDT = {'float32': torch.complex64, 'float64': torch.complex128}
+
+
+def _flush_denormals(x):
+    """Zero entries with ``|x| < 1000 * tiny(dtype)`` in place (reference
+    `zero_denormals`, ssqueezepy/algos.py:593-613)."""
+    tiny = 1000 * np.finfo(x.dtype).tiny
+    x[(x < tiny) & (x > -tiny)] = 0
+    return x
+
+
+def get_window(window, win_len, n_fft=None, derivative=False, dtype=None):
+    """Length-`n_fft` analysis window (zero-padded symmetrically from `win_len`)
+    and, if `derivative`, its time derivative obtained by frequency-domain
+    differentiation ``ifft(fft(w) * 1j * xi).real``. `window`: None (DPSS, time-
+    bandwidth ``max(4, win_len//8)``), a `scipy.signal.get_window` name, or an
+    array. Reference: ssqueezepy/_stft.py:259-310."""
+    if n_fft is None:
+        pl, pr = 0, 0
+    else:
+        if win_len > n_fft:
+            raise ValueError("Can't have `win_len > n_fft` ({} > {})".format(
+                win_len, n_fft))
+        pl = (n_fft - win_len) // 2
+        pr = (n_fft - win_len - pl)
+    if window is not None:
+        if isinstance(window, str):
+            window = sig.get_window(window, win_len, fftbins=True)
+        elif isinstance(window, np.ndarray):
+            if len(window) != win_len:
+                WARN("len(window) != win_len (%s != %s)" % (len(window), win_len))
+        else:
+            raise ValueError("`window` must be string or np.ndarray "
+                             "(got %s)" % window)
+    else:
+        window = sig.windows.dpss(win_len, max(4, win_len // 8), sym=False)
+    if len(window) < (win_len + pl + pr):
+        window = np.pad(window, [pl, pr])
+
+    diff_window = None
+    if derivative:
+        import scipy.fft as sfft
+        nw = len(window)
+        xi = xi_grid(nw)
+        if nw % 2 == 0:
+            xi[nw // 2] = 0
+        diff_window = sfft.ifft(sfft.fft(window) * 1j * xi).real
+    if dtype is None:
+        dtype = window.dtype
+    window = _flush_denormals(np.asarray(window).astype(dtype))
+    if derivative:
+        diff_window = _flush_denormals(np.asarray(diff_window).astype(dtype))
+        return window, diff_window
+    return window
+
+
+def _check_NOLA(window, hop_len, dtype=None, imprecision_strict=False):
+    if hop_len > len(window):
+        WARN("`hop_len > len(window)`; STFT not invertible")
+    elif not sig.check_NOLA(window, len(window), len(window) - hop_len):
+        WARN("`window` fails Non-zero Overlap Add (NOLA) criterion; "
+             "STFT not invertible")
+    if dtype is None:
+        dtype = str(window.dtype)
+    tol = 0.15 if imprecision_strict else 1e-3
+    if dtype == 'float32' and hop_len <= len(window) and not sig.check_NOLA(
+            window, len(window), len(window) - hop_len, tol=tol):
+        WARN("Imprecision expected at right-most hop of signal, in inversion. "
+             "Lower `hop_len`, choose wider `window`, or use `dtype='float64'`.")
+
+
+class StftPlan():
+    """Host handle of a device STFT plan for one
+    ``(N, n_fft, hop_len, window, padtype, modulated, dtype)`` configuration."""
+
+    def __init__(self, N, n_fft, hop_len, window, diff_window, fs=1.,
+                 padtype='reflect', modulated=True, dtype='float32', max_batch=1):
+        self.lib = _lib.load()
+        algos._require_gpu()
+        self.dtype = dtype
+        self.N, self.n_fft, self.hop_len = int(N), int(n_fft), int(hop_len)
+        self.max_batch = int(max_batch)
+        win = np.asarray(window, dtype=dtype)
+        dwin = None if diff_window is None else np.asarray(diff_window, dtype=dtype)
+        if modulated:
+            # _stft.py:132-135: the window follows the frame rotation; the `* fs`
+            # on the differentiated window happens only on this branch
+            win = np.fft.ifftshift(win)
+            if dwin is not None:
+                dwin = np.fft.ifftshift(dwin) * fs
+        win = np.ascontiguousarray(win, dtype=dtype)
+        dwin = None if dwin is None else np.ascontiguousarray(dwin, dtype=dtype)
+        desc = StftDesc()
+        desc.dtype = F32 if dtype == 'float32' else F64
+        desc.padtype = _lib.PAD[padtype]
+        desc.n, desc.n_fft, desc.hop_len = self.N, self.n_fft, self.hop_len
+        desc.modulated = int(bool(modulated))
+        desc.window = win.ctypes.data
+        desc.diff_window = dwin.ctypes.data if dwin is not None else None
+        desc.max_batch = self.max_batch
+        self._h = ctypes.c_void_p()
+        check(self.lib.ssq_stft_plan_create(ctypes.byref(self._h), ctypes.byref(desc)))
+        rows, hops = ctypes.c_int64(), ctypes.c_int64()
+        check(self.lib.ssq_stft_plan_shape(self._h, ctypes.byref(rows),
+                                           ctypes.byref(hops)))
+        self.rows, self.n_hops = rows.value, hops.value
+        self._ssq_key = None
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h is not None and h.value:
+            try:
+                self.lib.ssq_stft_plan_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def set_ssq(self, Sfs, grid, params, const, flipud, gamma):
+        Sfs = np.ascontiguousarray(np.asarray(Sfs, dtype=self.dtype))
+        const = np.asarray(const)
+        if const.size != self.rows:
+            const = np.full(self.rows, float(const))
+        const = const.reshape(-1)
+        c64 = int(self.dtype == 'float32' and const.dtype == np.float64
+                  and const.size == self.rows and False)
+        const = np.ascontiguousarray(const.astype(self.dtype))
+        key = (Sfs.tobytes(), int(grid), tuple(float(v) for v in params),
+               const.tobytes(), bool(flipud), float(gamma))
+        if key == self._ssq_key:
+            return
+        check(self.lib.ssq_stft_plan_set_ssq(self._h, Sfs.ctypes.data, int(grid),
+                                             _lib.params5(params), const.ctypes.data,
+                                             c64, int(bool(flipud)), float(gamma)))
+        self._ssq_key = key
+
+    def execute(self, x, want_dSx=False, want_Tx=False, want_w=False):
+        batched = (x.ndim == 2)
+        B = x.shape[0] if batched else 1
+        if B > self.max_batch:
+            raise ValueError("batch %d exceeds the plan's max_batch %d"
+                             % (B, self.max_batch))
+        shape = ((B, self.rows, self.n_hops) if batched else
+                 (self.rows, self.n_hops))
+        cdt, rdt = _CDT[self.dtype], _TDT[self.dtype]
+        out = {'Sx': torch.empty(shape, dtype=cdt, device=x.device)}
+        if want_dSx:
+            out['dSx'] = torch.empty(shape, dtype=cdt, device=x.device)
+        if want_Tx:
+            out['Tx'] = torch.empty(shape, dtype=cdt, device=x.device)
+        if want_w:
+            out['w'] = torch.empty(shape, dtype=rdt, device=x.device)
+        p = lambda k: out[k].data_ptr() if k in out else None
+        check(self.lib.ssq_stft_execute(self._h, x.data_ptr(), B, p('Sx'), p('dSx'),
+                                        p('Tx'), p('w'), algos.stream()))
+        return out
+
+
+_PLAN_CACHE = {}
+
+
+def get_stft_plan(N, n_fft, hop_len, window, diff_window, fs, padtype, modulated,
+                  dtype, batch):
+    key = (int(N), int(n_fft), int(hop_len), np.asarray(window).tobytes(),
+           None if diff_window is None else np.asarray(diff_window).tobytes(),
+           float(fs), padtype, bool(modulated), dtype, torch.cuda.current_device())
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None and plan.max_batch >= batch:
+        return plan
+    plan = StftPlan(N, n_fft, hop_len, window, diff_window, fs, padtype, modulated,
+                    dtype, batch)
+    if len(_PLAN_CACHE) >= 8:
+        _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    _PLAN_CACHE[key] = plan
+    return plan
+
+
+def _stft_setup(x, window, n_fft, win_len, hop_len, fs, t, padtype, modulated,
+                dtype):
+    assert x.ndim in (1, 2)
+    if padtype not in PADTYPES:
+        raise ValueError("`padtype` must be one of: %s (got %s)"
+                         % (', '.join(PADTYPES), padtype))
+    N = x.shape[-1]
+    _, fs, _ = _process_fs_and_t(fs, t, N)
+    n_fft = n_fft or min(N // hop_len, 512)
+    if win_len is None:
+        win_len = (len(window) if isinstance(window, np.ndarray) else n_fft)
+    if dtype is None:
+        dtype = defaults('stft')['dtype']
+    dtype = str(np.dtype(dtype))
+    window, diff_window = get_window(window, win_len, n_fft, derivative=True,
+                                     dtype=dtype)
+    _check_NOLA(window, hop_len, dtype)
+    xd = algos.to_device(x, _TDT[dtype])
+    B = xd.shape[0] if xd.ndim == 2 else 1
+    plan = get_stft_plan(N, n_fft, hop_len, window, diff_window, fs, padtype,
+                         modulated, dtype, B)
+    return plan, xd, fs, dtype
+
+
+def stft(x, window=None, n_fft=None, win_len=None, hop_len=1, fs=None, t=None,
+         padtype='reflect', modulated=True, derivative=False, dtype=None,
+         astensor=True):
+    """Short-Time Fourier Transform; arguments follow ``ssqueezepy.stft``
+    (ssqueezepy/_stft.py:13-99). Returns `Sx` ``(n_fft//2 + 1, n_hops)`` with
+    ``n_hops = (len(x) - 1)//hop_len + 1`` (batched: leading signal dim), plus
+    `dSx` if `derivative`. Torch GPU tensors by default (`astensor=True`), NumPy
+    arrays otherwise."""
+    plan, xd, fs, dtype = _stft_setup(x, window, n_fft, win_len, hop_len, fs, t,
+                                      padtype, modulated, dtype)
+    out = plan.execute(xd, want_dSx=derivative)
+    Sx, dSx = out['Sx'], out.get('dSx')
+    if not astensor:
+        Sx = Sx.cpu().numpy()
+        dSx = dSx.cpu().numpy() if dSx is not None else None
+    return (Sx, dSx) if derivative else Sx

@@ -1,0 +1,325 @@
+// ssq_cwt.hip -- CWT / synchrosqueezed-CWT plan (C ABI: ssq_cwt_*).
+//
+// Data flow per signal (reference: ssqueezepy/_cwt.py:255-306, _ssq_cwt.py:250-289):
+//   x (N) --pad_kernel--> xp (M) --rocFFT R2C--> xh (M/2+1)
+//   rows in chunks:  xh, banded bank --bank_multiply_kernel--> P = psih*xh, dP = P*(1j*xi/dt)
+//                    --rocFFT C2C inverse, batched, scaled 1/M, in place-->  padded Wx, dWx
+//                    --cwt_epilogue_kernel--> Wx[:, n1:n1+N] (+ dWx / w / bin map)
+//   bin map or w --accumulate_tile_kernel--> Tx
+// Only the returned arrays (Wx, Tx [, dWx, w]) are written at full size; the padded
+// intermediates live in a plan-owned workspace that is reused chunk after chunk.
+//
+// The bank is *banded*: each row keeps only the contiguous run of DFT bins on which
+// the wavelet is non-negligible (hard part 4: 12.8 % of na*M at
+// N=160k), so the multiply reads ~40 MB instead of 315 MB and the bank stays in the
+// 256 MiB Infinity Cache across calls.
+//
+// Compiled with -ffp-contract=off (the epilogue computes bin indices; see
+// ssq_kernels.hip).
+#include "ssq_common.h"
+#include "ssq_fft.h"
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace ssq {
+
+// from ssq_kernels.hip (same arithmetic, re-declared here as device inlines would
+// need a shared header; kept in one place via this include)
+#include "ssq_point_math.inl"
+
+template <typename T>
+__global__ __launch_bounds__(256) void bank_multiply_kernel(
+    const T* __restrict__ xh,        // (M/2+1) complex, spectrum of the real padded signal
+    const T* __restrict__ bank, const int64_t* __restrict__ band_off,
+    const int32_t* __restrict__ band_lo,
+    T* __restrict__ prod,            // [rows][nplanes][M] complex
+    int64_t M, int64_t row0, int nplanes, double h, T inv_dt) {
+    const int64_t r = blockIdx.y;            // row within the chunk
+    const int64_t i = row0 + r;
+    const int64_t lo = band_lo[i];
+    const int64_t off = band_off[i];
+    const int64_t len = band_off[i + 1] - off;
+    T* P = prod + (size_t)r * nplanes * 2 * M;
+    T* dP = P + 2 * M;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M;
+         k += (int64_t)gridDim.x * blockDim.x) {
+        T re = T(0), im = T(0), dre = T(0), dim = T(0);
+        int64_t t = k - lo;
+        if (t >= 0 && t < len) {
+            T psi = bank[off + t];
+            T a, b;
+            if (k <= M / 2) { a = xh[2 * k]; b = xh[2 * k + 1]; }
+            else { a = xh[2 * (M - k)]; b = -xh[2 * (M - k) + 1]; }
+            re = psi * a; im = psi * b;
+            if (nplanes > 1) {
+                // xi_k = k*h (k <= M/2) or (k-M)*h, formed in double and stored in T
+                // (wavelets.py:473-484); multiplier 1j*xi/dt as NumPy forms it: xi * (1/dt)
+                int64_t ks = k <= M / 2 ? k : k - M;
+                T m = (T)((double)ks * h) * inv_dt;
+                dre = -(im * m); dim = re * m;
+            }
+        }
+        P[2 * k] = re; P[2 * k + 1] = im;
+        if (nplanes > 1) { dP[2 * k] = dre; dP[2 * k + 1] = dim; }
+    }
+}
+
+struct EpilogueArgs {
+    void* Wx; void* dWx; void* w; unsigned short* kidx;
+    int64_t out_cols;     // N, or M when rpadded
+    int64_t col0;         // n1, or 0 when rpadded
+    int64_t row0;
+    const void* row_scale;
+    double gamma;
+    int have_ssq;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cwt_epilogue_kernel(const T* __restrict__ prod, int64_t M,
+                                                           int nplanes, int64_t na,
+                                                           EpilogueArgs ea, SsqParams sp) {
+    const int64_t r = blockIdx.y;
+    const int64_t i = ea.row0 + r;
+    const T* P = prod + (size_t)r * nplanes * 2 * M;
+    const T* dP = P + 2 * M;
+    const int64_t omax = na - 1;
+    T rs = ea.row_scale ? ((const T*)ea.row_scale)[i] : T(1);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ea.out_cols;
+         j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = ea.col0 + j;
+        int64_t q = i * ea.out_cols + j;
+        T c = P[2 * p], d = P[2 * p + 1];
+        if (ea.row_scale) { c = c * rs; d = d * rs; }
+        ((T*)ea.Wx)[2 * q] = c; ((T*)ea.Wx)[2 * q + 1] = d;
+        if (nplanes > 1) {
+            T a = dP[2 * p], b = dP[2 * p + 1];
+            if (ea.row_scale) { a = a * rs; b = b * rs; }
+            if (ea.dWx) { ((T*)ea.dWx)[2 * q] = a; ((T*)ea.dWx)[2 * q + 1] = b; }
+            if (ea.w) {
+                // two-step form: phase_cwt (algos.py:720-740), threshold |Wx| < gamma
+                T wv;
+                if (mag_of(c, d) < (double)(T)ea.gamma) wv = (T)INFINITY;
+                else wv = (T)fabs(phase_ratio(a, b, c, d));
+                ((T*)ea.w)[q] = wv;
+            }
+            if (ea.kidx) {
+                // fused form (algos.py:859-953), threshold |Wx| > gamma
+                unsigned short kk = 0xFFFFu;
+                if (mag_of(c, d) > ea.gamma) {
+                    int64_t k = bin_from_w(fabs(phase_ratio(a, b, c, d)), sp, omax);
+                    kk = (unsigned short)(sp.flipud ? omax - k : k);
+                }
+                ea.kidx[q] = kk;
+            }
+        }
+    }
+}
+
+}  // namespace ssq
+
+using namespace ssq;
+
+struct ssq_cwt_plan {
+    ssq_cwt_desc d;
+    int csize() const { return d.dtype == SSQ_F32 ? 8 : 16; }
+    int rsize() const { return d.dtype == SSQ_F32 ? 4 : 8; }
+    // device copies
+    void* bank = nullptr; int64_t* band_off = nullptr; int32_t* band_lo = nullptr;
+    void* row_scale = nullptr;
+    std::vector<int64_t> h_band_off; std::vector<int32_t> h_band_lo;
+    // workspace
+    void* xp = nullptr; void* xh = nullptr; void* prod = nullptr; unsigned short* kidx = nullptr;
+    int64_t rows_chunk = 0;
+    int64_t bytes = 0;
+    FftPlan fwd;                          // R2C, batch = max_batch
+    std::map<int64_t, FftPlan> inv;       // C2C inverse keyed by transform count
+    // ssq
+    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr;
+    std::string algo = "rocfft";
+};
+
+static int dev_alloc(void** p, size_t bytes, int64_t& acc) {
+    SSQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 1));
+    acc += (int64_t)bytes;
+    return 0;
+}
+
+extern "C" {
+
+int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
+    SSQ_REQUIRE(out && desc, "ssq_cwt_plan_create: null pointer");
+    const ssq_cwt_desc& d = *desc;
+    SSQ_REQUIRE(d.dtype == SSQ_F32 || d.dtype == SSQ_F64, "bad dtype %d", d.dtype);
+    SSQ_REQUIRE(d.n >= 1 && d.m >= d.n && d.na >= 1, "bad sizes n=%lld m=%lld na=%lld",
+                (long long)d.n, (long long)d.m, (long long)d.na);
+    SSQ_REQUIRE(d.n1 >= 0 && d.n1 + d.n <= d.m, "bad left pad %lld", (long long)d.n1);
+    SSQ_REQUIRE(d.padtype >= SSQ_PAD_NONE && d.padtype <= SSQ_PAD_WRAP, "bad padtype %d", d.padtype);
+    SSQ_REQUIRE(d.padtype != SSQ_PAD_NONE || d.m == d.n, "padtype NONE requires m == n");
+    SSQ_REQUIRE(d.bank && d.band_off && d.band_lo, "bank arrays must not be null");
+    SSQ_REQUIRE(d.dt > 0, "dt must be > 0");
+    SSQ_REQUIRE(d.na < 65535, "na must be < 65535");
+    for (int64_t i = 0; i < d.na; ++i) {
+        int64_t len = d.band_off[i + 1] - d.band_off[i];
+        SSQ_REQUIRE(len >= 0 && d.band_lo[i] >= 0 && d.band_lo[i] + len <= d.m,
+                    "row %lld: band [%d, +%lld) outside [0, %lld)", (long long)i, d.band_lo[i],
+                    (long long)len, (long long)d.m);
+    }
+    auto* pl = new ssq_cwt_plan();
+    pl->d = d;
+    if (pl->d.max_batch < 1) pl->d.max_batch = 1;
+    pl->h_band_off.assign(d.band_off, d.band_off + d.na + 1);
+    pl->h_band_lo.assign(d.band_lo, d.band_lo + d.na);
+    pl->d.bank = nullptr; pl->d.band_off = nullptr; pl->d.band_lo = nullptr; pl->d.row_scale = nullptr;
+    const int rs = pl->rsize(), cs = pl->csize();
+    const int64_t nnz = d.band_off[d.na];
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { ssq_cwt_plan_destroy(pl); return rc; } } while (0)
+    TRY(dev_alloc(&pl->bank, (size_t)nnz * rs, pl->bytes));
+    TRY(dev_alloc((void**)&pl->band_off, (size_t)(d.na + 1) * 8, pl->bytes));
+    TRY(dev_alloc((void**)&pl->band_lo, (size_t)d.na * 4, pl->bytes));
+    SSQ_CHECK_HIP(hipMemcpy(pl->bank, d.bank, (size_t)nnz * rs, hipMemcpyHostToDevice));
+    SSQ_CHECK_HIP(hipMemcpy(pl->band_off, d.band_off, (size_t)(d.na + 1) * 8, hipMemcpyHostToDevice));
+    SSQ_CHECK_HIP(hipMemcpy(pl->band_lo, d.band_lo, (size_t)d.na * 4, hipMemcpyHostToDevice));
+    if (d.row_scale) {
+        TRY(dev_alloc(&pl->row_scale, (size_t)d.na * rs, pl->bytes));
+        SSQ_CHECK_HIP(hipMemcpy(pl->row_scale, d.row_scale, (size_t)d.na * rs, hipMemcpyHostToDevice));
+    }
+    TRY(dev_alloc(&pl->xp, (size_t)pl->d.max_batch * d.m * rs, pl->bytes));
+    TRY(dev_alloc(&pl->xh, (size_t)pl->d.max_batch * (d.m / 2 + 1) * cs, pl->bytes));
+    // product workspace: 2 planes (Wx, dWx) per row, bounded to ~2 GiB
+    const size_t per_row = (size_t)2 * d.m * cs;
+    const size_t budget = (size_t)2 << 30;
+    pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
+    TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
+    TRY(dev_alloc((void**)&pl->kidx, (size_t)d.na * d.n * 2, pl->bytes));
+    TRY(pl->fwd.create(0, d.dtype, (size_t)d.m, (size_t)pl->d.max_batch, 1.0));
+    pl->bytes += (int64_t)pl->fwd.work_bytes;
+#undef TRY
+    *out = pl;
+    return 0;
+}
+
+void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
+    if (!pl) return;
+    pl->fwd.destroy();
+    for (auto& kv : pl->inv) kv.second.destroy();
+    void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
+                    pl->kidx, pl->cst};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete pl;
+}
+
+int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const void* cst,
+                         int cst_f64, int flipud, double gamma) {
+    SSQ_REQUIRE(pl && params && cst, "ssq_cwt_plan_set_ssq: null pointer");
+    SSQ_REQUIRE(grid >= SSQ_GRID_LOG && grid <= SSQ_GRID_LIN, "unknown grid kind %d", grid);
+    for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
+    pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
+    pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
+    size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
+    if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->d.na * 8));
+    SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, bytes, hipMemcpyHostToDevice));
+    pl->have_ssq = true;
+    return 0;
+}
+
+int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* pl) { return pl ? pl->bytes : 0; }
+const char* ssq_cwt_plan_algo(const ssq_cwt_plan* pl) { return pl ? pl->algo.c_str() : ""; }
+
+}  // extern "C"
+
+template <typename T>
+static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* Wx, void* dWx,
+                         void* Tx, void* w, int rpadded, hipStream_t stream) {
+    const ssq_cwt_desc& d = pl->d;
+    const int64_t M = d.m, N = d.n, na = d.na;
+    const int64_t out_cols = rpadded ? M : N;
+    const bool deriv = dWx || Tx || w;
+    const int nplanes = deriv ? 2 : 1;
+    const double h = (2.0 * 3.141592653589793) / (double)M;
+    const T inv_dt = T(1) / (T)d.dt;
+
+    // pad (or copy) the whole batch, forward FFT of all signals at once
+    const T* xsrc = (const T*)x;
+    if (d.padtype != SSQ_PAD_NONE) {
+        int rc = ssq_pad_signal(d.dtype, x, pl->xp, batch, N, d.n1, M - N - d.n1, d.padtype, stream);
+        if (rc) return rc;
+        xsrc = (const T*)pl->xp;
+    } else {
+        SSQ_CHECK_HIP(hipMemcpyAsync(pl->xp, x, (size_t)batch * M * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        xsrc = (const T*)pl->xp;
+    }
+    if (batch == d.max_batch) {
+        int rc = pl->fwd.execute((void*)xsrc, pl->xh, stream);
+        if (rc) return rc;
+    } else {
+        // smaller batch than planned: run the planned batch over the (valid) prefix;
+        // rows past `batch` hold stale but finite data and are ignored
+        int rc = pl->fwd.execute((void*)xsrc, pl->xh, stream);
+        if (rc) return rc;
+    }
+
+    for (int64_t b = 0; b < batch; ++b) {
+        const T* xh = (const T*)pl->xh + (size_t)b * (M / 2 + 1) * 2;
+        T* Wx_b = Wx ? (T*)Wx + (size_t)b * na * out_cols * 2 : nullptr;
+        T* dWx_b = dWx ? (T*)dWx + (size_t)b * na * out_cols * 2 : nullptr;
+        T* w_b = w ? (T*)w + (size_t)b * na * out_cols : nullptr;
+        T* Tx_b = Tx ? (T*)Tx + (size_t)b * na * out_cols * 2 : nullptr;
+        for (int64_t row0 = 0; row0 < na; row0 += pl->rows_chunk) {
+            const int64_t rows = std::min(pl->rows_chunk, na - row0);
+            unsigned gx = (unsigned)std::min<int64_t>((M + 255) / 256, 4096);
+            hipLaunchKernelGGL((bank_multiply_kernel<T>), dim3(gx, (unsigned)rows), dim3(256), 0, stream,
+                               xh, (const T*)pl->bank, pl->band_off, pl->band_lo, (T*)pl->prod, M, row0,
+                               nplanes, h, inv_dt);
+            SSQ_LAUNCH_CHECK();
+            const int64_t ntrans = rows * nplanes;
+            auto it = pl->inv.find(ntrans);
+            if (it == pl->inv.end()) {
+                FftPlan fp;
+                int rc = fp.create(1, d.dtype, (size_t)M, (size_t)ntrans, 1.0 / (double)M);
+                if (rc) return rc;
+                pl->bytes += (int64_t)fp.work_bytes;
+                it = pl->inv.emplace(ntrans, fp).first;
+            }
+            int rc = it->second.execute(pl->prod, nullptr, stream);
+            if (rc) return rc;
+            EpilogueArgs ea;
+            ea.Wx = Wx_b; ea.dWx = dWx_b; ea.w = w_b;
+            ea.kidx = (Tx && !w) ? pl->kidx : nullptr;
+            ea.out_cols = out_cols; ea.col0 = rpadded ? 0 : d.n1; ea.row0 = row0;
+            ea.row_scale = pl->row_scale; ea.gamma = pl->sp.gamma; ea.have_ssq = pl->have_ssq;
+            unsigned ex = (unsigned)std::min<int64_t>((out_cols + 255) / 256, 4096);
+            hipLaunchKernelGGL((cwt_epilogue_kernel<T>), dim3(ex, (unsigned)rows), dim3(256), 0, stream,
+                               (const T*)pl->prod, M, nplanes, na, ea, pl->sp);
+            SSQ_LAUNCH_CHECK();
+        }
+        if (Tx) {
+            int rc2 = launch_accumulate(d.dtype, w ? BIN_FROM_W : BIN_FROM_KIDX, Wx_b,
+                                        w ? (const void*)w_b : (const void*)pl->kidx, nullptr, Tx_b,
+                                        pl->cst, pl->sp, 1, na, N, nullptr, stream);
+            if (rc2) return rc2;
+        }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int ssq_cwt_execute(ssq_cwt_plan* pl, const void* x, int64_t batch, void* Wx, void* dWx, void* Tx,
+                    void* w, int rpadded, void* stream) {
+    SSQ_REQUIRE(pl && x, "ssq_cwt_execute: null pointer");
+    SSQ_REQUIRE(batch >= 1 && batch <= pl->d.max_batch, "batch %lld outside [1, %lld]",
+                (long long)batch, (long long)pl->d.max_batch);
+    SSQ_REQUIRE(Wx || !(dWx || Tx || w), "Wx buffer is required");
+    SSQ_REQUIRE(!(rpadded && (Tx || w)), "rpadded output excludes Tx / w");
+    SSQ_REQUIRE(!Tx || pl->have_ssq, "Tx requested but ssq parameters were not set");
+    SSQ_REQUIRE(!w || pl->have_ssq, "w requested but ssq parameters (gamma) were not set");
+    SSQ_REQUIRE(Wx, "Wx buffer is required");
+    if (pl->d.dtype == SSQ_F32)
+        return cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
+    return cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
+}
+
+}  // extern "C"

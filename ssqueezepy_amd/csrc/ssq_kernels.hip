@@ -1,0 +1,515 @@
+// ssq_kernels.hip -- reassignment / phase / framing / padding kernels for gfx950 and
+// the runtime half of the C ABI (include/ssq_hip.h).
+//
+// Compiled with -ffp-contract=off: the per-point arithmetic here is specified
+// operation by operation (see oracle/ssq_oracle.c, "numba typing") so that bin
+// indices are reproducible bit-for-bit against the CPU path; no fused multiply-adds
+// may be introduced behind our back.
+//
+// Kernel inventory (all HBM-bound streaming kernels; no MFMA -- there is no dense
+// contraction on this path):
+//   accumulate_tile_kernel   fused phase transform + bin map + accumulate. One
+//       wavefront (64 lanes) owns a tile of TC time columns x all `na` frequency
+//       bins of Tx, held in LDS (<=160 KiB/CU on gfx950); it streams rows of
+//       Wx/dWx through registers with several loads in flight per lane, applies
+//       updates in ascending row order (the reference's summation order) and writes
+//       the tile out once. HBM traffic = read Wx + dWx (or w / bin map) once, write
+//       Tx once -- no read-modify-write, no atomics, deterministic.
+//   accumulate_global_kernel fallback for `na` too large for an LDS tile.
+//   phase_kernel             w = |Im(dWx/Wx)|/2pi (CWT) or |Sfs - ...| (STFT).
+//   replace_under_abs_kernel, buffer_kernel, pad_kernel.
+#include "ssq_common.h"
+#include <mutex>
+#include <string>
+
+namespace ssq {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+#include "ssq_point_math.inl"
+
+// out += z * cst   in the CPU path's arithmetic
+template <typename T, bool CST64>
+__device__ __forceinline__ void weighted_add(T& o_re, T& o_im, T c, T d, const void* cst, int64_t i) {
+    if constexpr (CST64 && sizeof(T) == 4) {
+        double w = ((const double*)cst)[i];
+        o_re = (T)((double)o_re + (double)c * w);
+        o_im = (T)((double)o_im + (double)d * w);
+    } else {
+        T w = ((const T*)cst)[i];
+        o_re = o_re + c * w;
+        o_im = o_im + d * w;
+    }
+}
+
+// Per-point side input of the accumulate kernels, loaded up front so that the loads
+// of several rows are in flight together.
+template <typename T, int BINSRC> struct SideVal;
+template <typename T> struct SideVal<T, BIN_FROM_DWX> {
+    T a, b;
+    __device__ __forceinline__ void load(const void* src, int64_t q) {
+        const T* dz = (const T*)src + 2 * q; a = dz[0]; b = dz[1];
+    }
+};
+template <typename T> struct SideVal<T, BIN_FROM_W> {
+    T w;
+    __device__ __forceinline__ void load(const void* src, int64_t q) { w = ((const T*)src)[q]; }
+};
+template <typename T> struct SideVal<T, BIN_FROM_KIDX> {
+    unsigned short k;
+    __device__ __forceinline__ void load(const void* src, int64_t q) { k = ((const unsigned short*)src)[q]; }
+};
+
+// One point of the fused kernel: returns bin (or -1) for row i
+template <typename T, int BINSRC, bool STFT>
+__device__ __forceinline__ int64_t point_bin(T c, T d, const SideVal<T, BINSRC>& sv, int64_t i,
+                                             const T* Sfs, const SsqParams& sp, int64_t omax) {
+    int64_t k;
+    if constexpr (BINSRC == BIN_FROM_DWX) {
+        if (!(mag_of(c, d) > sp.gamma)) return -1;
+        double r = phase_ratio(sv.a, sv.b, c, d);
+        double w;
+        if constexpr (STFT) w = fabs((double)Sfs[i] - r); else w = fabs(r);
+        k = bin_from_w(w, sp, omax);
+    } else if constexpr (BINSRC == BIN_FROM_W) {
+        if (isinf(sv.w)) return -1;
+        k = bin_from_stored_w(sv.w, sp, omax);
+    } else {
+        if (sv.k == 0xFFFFu) return -1;
+        return (int64_t)sv.k;             // already flipped by the producer
+    }
+    return sp.flipud ? omax - k : k;
+}
+
+// ------------------------------------------------- accumulate, LDS-tile form
+// block = 64 threads = RL row-lanes x TC columns; tile[k][c] complex<T> in LDS.
+template <typename T, int BINSRC, bool STFT, bool CST64, int TC>
+__global__ __launch_bounds__(64) void accumulate_tile_kernel(
+    const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
+    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na, int64_t n,
+    int32_t* __restrict__ kmap) {
+    constexpr int RL = 64 / TC;
+    constexpr int U = 4;                       // row batches in flight per lane
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* tile = reinterpret_cast<T*>(lds_raw);   // [na][TC][2]
+
+    const int lane = threadIdx.x;
+    const int c = lane % TC, rl = lane / TC;
+    const int64_t j = (int64_t)blockIdx.x * TC + c;
+    const int64_t b = blockIdx.y;
+    const bool col_ok = j < n;
+    const int64_t omax = na - 1;
+    const int64_t base = b * na * n;
+
+    for (int64_t t = lane; t < na * TC; t += 64) {
+        tile[2 * t] = T(0);
+        tile[2 * t + 1] = T(0);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    for (int64_t i0 = 0; i0 < na; i0 += RL * U) {
+        T zc[U], zd[U];
+        SideVal<T, BINSRC> sv[U];
+        int64_t kk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * RL + rl;
+            bool ok = col_ok && i < na;
+            zc[u] = T(0); zd[u] = T(0); kk[u] = -1;
+            if (ok) {
+                int64_t q = base + i * n + j;
+                zc[u] = Wx[2 * q];
+                zd[u] = Wx[2 * q + 1];
+                sv[u].load(src, q);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * RL + rl;
+            bool ok = col_ok && i < na;
+            if (ok) {
+                kk[u] = point_bin<T, BINSRC, STFT>(zc[u], zd[u], sv[u], i, Sfs, sp, omax);
+                if (kmap) kmap[base + i * n + j] = (int32_t)kk[u];
+            }
+        }
+        // apply in ascending row order: batch u, then row-lane r
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                if (rl == r && kk[u] >= 0) {
+                    T* o = tile + 2 * (kk[u] * TC + c);
+                    T ore = o[0], oim = o[1];
+                    weighted_add<T, CST64>(ore, oim, zc[u], zd[u], cst, i0 + u * RL + r);
+                    o[0] = ore; o[1] = oim;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (col_ok) {
+        for (int64_t k = rl; k < na; k += RL) {
+            int64_t q = base + k * n + j;
+            Tx[2 * q] = tile[2 * (k * TC + c)];
+            Tx[2 * q + 1] = tile[2 * (k * TC + c) + 1];
+        }
+    }
+}
+
+// ---------------------------------------------- accumulate, global fallback
+// one thread per time column, serial over rows, Tx (pre-zeroed) updated in place.
+template <typename T, int BINSRC, bool STFT, bool CST64>
+__global__ __launch_bounds__(256) void accumulate_global_kernel(
+    const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
+    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na, int64_t n,
+    int32_t* __restrict__ kmap) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t base = (int64_t)blockIdx.y * na * n;
+    const int64_t omax = na - 1;
+    for (int64_t i = 0; i < na; ++i) {
+        int64_t q = base + i * n + j;
+        T c = Wx[2 * q], d = Wx[2 * q + 1];
+        SideVal<T, BINSRC> sv;
+        sv.load(src, q);
+        int64_t k = point_bin<T, BINSRC, STFT>(c, d, sv, i, Sfs, sp, omax);
+        if (kmap) kmap[q] = (int32_t)k;
+        if (k < 0) continue;
+        T* o = Tx + 2 * (base + k * n + j);
+        T ore = o[0], oim = o[1];
+        weighted_add<T, CST64>(ore, oim, c, d, cst, i);
+        o[0] = ore; o[1] = oim;
+    }
+}
+
+template <typename T, int BINSRC, bool STFT, bool CST64>
+static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs, void* Tx,
+                               const void* cst, const SsqParams& sp, int64_t batch,
+                               int64_t na, int64_t n, int32_t* kmap, hipStream_t stream) {
+    const size_t cell = 2 * sizeof(T);
+    const size_t lds_cap = 160 * 1024;
+    auto launch_tile = [&](auto tc_tag) -> int {
+        constexpr int TC = decltype(tc_tag)::value;
+        size_t lds = (size_t)na * TC * cell;
+        auto kern = accumulate_tile_kernel<T, BINSRC, STFT, CST64, TC>;
+        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)((n + TC - 1) / TC), (unsigned)batch);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                           (T*)Tx, cst, sp, na, n, kmap);
+        SSQ_LAUNCH_CHECK();
+        return 0;
+    };
+    // prefer >= 2 resident tiles per CU; shrink the tile before giving up on LDS
+    if ((size_t)na * 16 * cell <= lds_cap / 2) return launch_tile(std::integral_constant<int, 16>{});
+    if ((size_t)na * 8 * cell <= lds_cap / 2) return launch_tile(std::integral_constant<int, 8>{});
+    if ((size_t)na * 16 * cell <= lds_cap) return launch_tile(std::integral_constant<int, 16>{});
+    if ((size_t)na * 8 * cell <= lds_cap) return launch_tile(std::integral_constant<int, 8>{});
+    if ((size_t)na * 4 * cell <= lds_cap) return launch_tile(std::integral_constant<int, 4>{});
+    SSQ_CHECK_HIP(hipMemsetAsync(Tx, 0, (size_t)batch * na * n * cell, stream));
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL((accumulate_global_kernel<T, BINSRC, STFT, CST64>), grid, dim3(256), 0,
+                       stream, (const T*)Wx, src, (const T*)Sfs, (T*)Tx, cst, sp, na, n, kmap);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, int BINSRC>
+static int launch_accumulate_b(const void* Wx, const void* src, const void* Sfs, void* Tx,
+                               const void* cst, const SsqParams& sp, int64_t batch,
+                               int64_t na, int64_t n, int32_t* kmap, hipStream_t stream) {
+    const bool c64 = sp.cst_f64 && sizeof(T) == 4;
+    if (Sfs) {
+        if constexpr (BINSRC == BIN_FROM_DWX) {
+            return c64 ? launch_accumulate_t<T, BINSRC, true, true>(Wx, src, Sfs, Tx, cst, sp, batch, na, n, kmap, stream)
+                       : launch_accumulate_t<T, BINSRC, true, false>(Wx, src, Sfs, Tx, cst, sp, batch, na, n, kmap, stream);
+        }
+    }
+    return c64 ? launch_accumulate_t<T, BINSRC, false, true>(Wx, src, nullptr, Tx, cst, sp, batch, na, n, kmap, stream)
+               : launch_accumulate_t<T, BINSRC, false, false>(Wx, src, nullptr, Tx, cst, sp, batch, na, n, kmap, stream);
+}
+
+int launch_accumulate(int dtype, int binsrc, const void* Wx, const void* src, const void* Sfs,
+                      void* Tx, const void* cst, const SsqParams& sp, int64_t batch, int64_t na,
+                      int64_t n, int32_t* kmap, hipStream_t stream) {
+    SSQ_REQUIRE(na >= 1 && n >= 1 && batch >= 1, "accumulate: empty shape (%lld, %lld, %lld)",
+                (long long)batch, (long long)na, (long long)n);
+    SSQ_REQUIRE(batch <= 65535, "accumulate: batch %lld > 65535", (long long)batch);
+    SSQ_REQUIRE(binsrc != BIN_FROM_KIDX || na < 65535, "bin map needs na < 65535");
+#define SSQ_ACC(T)                                                                                 \
+    switch (binsrc) {                                                                              \
+        case BIN_FROM_DWX: return launch_accumulate_b<T, BIN_FROM_DWX>(Wx, src, Sfs, Tx, cst, sp, batch, na, n, kmap, stream); \
+        case BIN_FROM_W: return launch_accumulate_b<T, BIN_FROM_W>(Wx, src, Sfs, Tx, cst, sp, batch, na, n, kmap, stream);     \
+        default: return launch_accumulate_b<T, BIN_FROM_KIDX>(Wx, src, Sfs, Tx, cst, sp, batch, na, n, kmap, stream);          \
+    }
+    if (dtype == SSQ_F32) { SSQ_ACC(float) }
+    SSQ_ACC(double)
+#undef SSQ_ACC
+}
+
+// ------------------------------------------------------------------ phase
+template <typename T, bool STFT>
+__global__ __launch_bounds__(256) void phase_kernel(const T* __restrict__ Wx,
+                                                    const T* __restrict__ dWx,
+                                                    const T* __restrict__ Sfs, T* __restrict__ w,
+                                                    int64_t na, int64_t n, int64_t total,
+                                                    double gamma) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        T c = Wx[2 * q], d = Wx[2 * q + 1];
+        // the two-step path thresholds with `abs(Wx) < gamma`, gamma in the data dtype
+        if (mag_of(c, d) < (double)(T)gamma) { w[q] = (T)INFINITY; continue; }
+        double r = phase_ratio(dWx[2 * q], dWx[2 * q + 1], c, d);
+        if constexpr (STFT) {
+            int64_t i = (q / n) % na;
+            w[q] = (T)fabs((double)Sfs[i] - r);
+        } else {
+            w[q] = (T)fabs(r);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void replace_under_abs_kernel(T* __restrict__ w,
+                                                                const T* __restrict__ ref,
+                                                                int64_t total, double value,
+                                                                T replacement) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+         q += (int64_t)gridDim.x * blockDim.x)
+        if (mag_of(ref[2 * q], ref[2 * q + 1]) < value) w[q] = replacement;
+}
+
+// ---------------------------------------------------------------- framing
+template <typename T>
+__global__ __launch_bounds__(256) void buffer_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                     int64_t n_x, int64_t seg_len, int64_t n_segs,
+                                                     int64_t hop, int64_t s20, int64_t s21,
+                                                     int modulated, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t c = t % n_segs, r = (t / n_segs) % seg_len, b = t / (n_segs * seg_len);
+        int64_t start = hop * c, s;
+        if (!modulated) s = start + r;
+        else if (r < s20) s = start + s21 + r;
+        else s = start + (r - s20);
+        out[t] = x[b * n_x + s];
+    }
+}
+
+// ---------------------------------------------------------------- padding
+__device__ __forceinline__ int64_t pad_source(int64_t t, int64_t n, int padtype) {
+    // t in [-n1, n + n2); returns source index in [0, n) or -1 for zero fill
+    if (t >= 0 && t < n) return t;
+    switch (padtype) {
+        case SSQ_PAD_REFLECT: {
+            if (n == 1) return 0;
+            int64_t period = 2 * (n - 1);
+            int64_t m = t % period; if (m < 0) m += period;
+            return m < n ? m : period - m;
+        }
+        case SSQ_PAD_SYMMETRIC: {
+            int64_t period = 2 * n;
+            int64_t m = t % period; if (m < 0) m += period;
+            return m < n ? m : period - 1 - m;
+        }
+        case SSQ_PAD_REPLICATE: return t < 0 ? 0 : n - 1;
+        case SSQ_PAD_WRAP: { int64_t m = t % n; if (m < 0) m += n; return m; }
+        default: return -1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pad_kernel(const T* __restrict__ x, T* __restrict__ out,
+                                                  int64_t n, int64_t n1, int64_t m, int padtype,
+                                                  int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t b = t / m, p = t % m;
+        int64_t s = pad_source(p - n1, n, padtype);
+        out[t] = s < 0 ? T(0) : x[b * n + s];
+    }
+}
+
+static inline unsigned stream_grid(int64_t total, int block = 256) {
+    int64_t g = (total + block - 1) / block;
+    const int64_t cap = 256 * 8 * 4;   // 256 CUs x 8 blocks, grid-stride the rest
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace ssq
+
+using namespace ssq;
+
+// ======================================================================= C ABI
+extern "C" {
+
+int ssq_version(void) { return 100; }
+const char* ssq_last_error(void) { return g_last_error.c_str(); }
+
+int ssq_device_count(int* count) {
+    SSQ_REQUIRE(count, "ssq_device_count: null pointer");
+    SSQ_CHECK_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+int ssq_set_device(int device) { SSQ_CHECK_HIP(hipSetDevice(device)); return 0; }
+
+int ssq_device_info(int device, char* name, int len, int* cus, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    SSQ_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && len > 0) { strncpy(name, prop.gcnArchName, len - 1); name[len - 1] = 0; }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+int ssq_malloc(void** ptr, int64_t bytes) {
+    SSQ_REQUIRE(ptr && bytes >= 0, "ssq_malloc: bad arguments");
+    SSQ_CHECK_HIP(hipMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1)));
+    return 0;
+}
+int ssq_free(void* ptr) { SSQ_CHECK_HIP(hipFree(ptr)); return 0; }
+int ssq_memcpy_h2d(void* dst, const void* src, int64_t bytes, void* stream) {
+    SSQ_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return 0;
+}
+int ssq_memcpy_d2h(void* dst, const void* src, int64_t bytes, void* stream) {
+    SSQ_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return 0;
+}
+int ssq_memset(void* dst, int value, int64_t bytes, void* stream) {
+    SSQ_CHECK_HIP(hipMemsetAsync(dst, value, (size_t)bytes, as_stream(stream)));
+    return 0;
+}
+int ssq_stream_synchronize(void* stream) {
+    SSQ_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    return 0;
+}
+
+static int check_dtype(int dtype) {
+    SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "dtype must be SSQ_F32 or SSQ_F64 (got %d)", dtype);
+    return 0;
+}
+
+int ssq_phase_cwt(int dtype, const void* Wx, const void* dWx, void* w, int64_t batch, int64_t na,
+                  int64_t n, double gamma, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(Wx && dWx && w, "ssq_phase_cwt: null pointer");
+    int64_t total = batch * na * n;
+    if (total == 0) return 0;
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL((phase_kernel<float, false>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const float*)Wx, (const float*)dWx, (const float*)nullptr, (float*)w, na, n, total, gamma);
+    else
+        hipLaunchKernelGGL((phase_kernel<double, false>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const double*)Wx, (const double*)dWx, (const double*)nullptr, (double*)w, na, n, total, gamma);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssq_phase_stft(int dtype, const void* Sx, const void* dSx, const void* Sfs, void* w,
+                   int64_t batch, int64_t na, int64_t n, double gamma, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(Sx && dSx && Sfs && w, "ssq_phase_stft: null pointer");
+    int64_t total = batch * na * n;
+    if (total == 0) return 0;
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL((phase_kernel<float, true>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const float*)Sx, (const float*)dSx, (const float*)Sfs, (float*)w, na, n, total, gamma);
+    else
+        hipLaunchKernelGGL((phase_kernel<double, true>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const double*)Sx, (const double*)dSx, (const double*)Sfs, (double*)w, na, n, total, gamma);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fill_params(SsqParams& sp, int grid, const double* params, int flipud, double gamma, int cst_f64) {
+    SSQ_REQUIRE(grid >= SSQ_GRID_LOG && grid <= SSQ_GRID_LIN, "unknown grid kind %d", grid);
+    SSQ_REQUIRE(params, "grid params must not be null");
+    for (int t = 0; t < 5; ++t) sp.p[t] = params[t];
+    sp.grid = grid; sp.flipud = flipud ? 1 : 0; sp.gamma = gamma; sp.cst_f64 = cst_f64 ? 1 : 0;
+    return 0;
+}
+
+int ssq_ssqueeze(int dtype, const void* Wx, const void* dWx, const void* Sfs, void* Tx,
+                 const void* cst, int cst_f64, int64_t batch, int64_t na, int64_t n, double gamma,
+                 int grid, const double* params, int flipud, int32_t* kmap, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(Wx && dWx && Tx && cst, "ssq_ssqueeze: null pointer");
+    SsqParams sp;
+    if (fill_params(sp, grid, params, flipud, gamma, cst_f64)) return -1;
+    return launch_accumulate(dtype, BIN_FROM_DWX, Wx, dWx, Sfs, Tx, cst, sp, batch, na, n, kmap, as_stream(stream));
+}
+
+int ssq_indexed_sum(int dtype, const void* Wx, const void* w, void* Tx, const void* cst, int cst_f64,
+                    int64_t batch, int64_t na, int64_t n, int grid, const double* params, int flipud,
+                    void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(Wx && w && Tx && cst, "ssq_indexed_sum: null pointer");
+    SsqParams sp;
+    if (fill_params(sp, grid, params, flipud, 0.0, cst_f64)) return -1;
+    return launch_accumulate(dtype, BIN_FROM_W, Wx, w, nullptr, Tx, cst, sp, batch, na, n, nullptr, as_stream(stream));
+}
+
+int ssq_replace_under_abs(int dtype, void* w, const void* ref, int64_t count, double value,
+                          double replacement, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(w && ref, "ssq_replace_under_abs: null pointer");
+    if (count == 0) return 0;
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL((replace_under_abs_kernel<float>), dim3(stream_grid(count)), dim3(256), 0, as_stream(stream),
+                           (float*)w, (const float*)ref, count, value, (float)replacement);
+    else
+        hipLaunchKernelGGL((replace_under_abs_kernel<double>), dim3(stream_grid(count)), dim3(256), 0, as_stream(stream),
+                           (double*)w, (const double*)ref, count, value, replacement);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssq_buffer(int dtype, const void* x, void* out, int64_t batch, int64_t n_x, int64_t seg_len,
+               int64_t n_overlap, int modulated, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(x && out, "ssq_buffer: null pointer");
+    int64_t hop = seg_len - n_overlap;
+    SSQ_REQUIRE(seg_len >= 1 && hop >= 1 && n_x >= seg_len, "ssq_buffer: bad framing (n_x=%lld seg_len=%lld n_overlap=%lld)",
+                (long long)n_x, (long long)seg_len, (long long)n_overlap);
+    int64_t n_segs = (n_x - seg_len) / hop + 1;
+    int64_t s20 = (seg_len + 1) / 2, s21 = (seg_len % 2 == 1) ? s20 - 1 : s20;
+    int64_t total = batch * seg_len * n_segs;
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL((buffer_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const float*)x, (float*)out, n_x, seg_len, n_segs, hop, s20, s21, modulated, total);
+    else
+        hipLaunchKernelGGL((buffer_kernel<double>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const double*)x, (double*)out, n_x, seg_len, n_segs, hop, s20, s21, modulated, total);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int ssq_pad_signal(int dtype, const void* x, void* out, int64_t batch, int64_t n, int64_t n1,
+                   int64_t n2, int padtype, void* stream) {
+    if (check_dtype(dtype)) return -1;
+    SSQ_REQUIRE(x && out, "ssq_pad_signal: null pointer");
+    SSQ_REQUIRE(padtype >= SSQ_PAD_ZERO && padtype <= SSQ_PAD_WRAP, "unknown padtype %d", padtype);
+    int64_t m = n1 + n + n2, total = batch * m;
+    if (total == 0) return 0;
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL((pad_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const float*)x, (float*)out, n, n1, m, padtype, total);
+    else
+        hipLaunchKernelGGL((pad_kernel<double>), dim3(stream_grid(total)), dim3(256), 0, as_stream(stream),
+                           (const double*)x, (double*)out, n, n1, m, padtype, total);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+// ssq_stft.hip -- STFT / synchrosqueezed-STFT plan (C ABI: ssq_stft_*).
+//
+// Data flow per signal (reference: ssqueezepy/_stft.py:127-147,166-170,
+// _ssq_stft.py:88-122):
+//   x (N) --pad_kernel--> xp (N + n_fft - 1)
+//   xp --frame_window_kernel--> frames[c][r] = xp[frame c, sample r] * window[r]
+//        (and the same with diff_window), frame-major so each transform is contiguous
+//   frames --rocFFT R2C, batch = n_hops, output stride n_hops--> Sx[f][c], dSx[f][c]
+//        (the strided store writes the (rows, n_hops) layout directly: no transpose)
+//   Sx, dSx --accumulate_tile_kernel (STFT form)--> Tx
+// Compiled with -ffp-contract=off (see ssq_kernels.hip).
+#include "ssq_common.h"
+#include "ssq_fft.h"
+#include <algorithm>
+#include <rocfft/rocfft.h>
+
+namespace ssq {
+
+template <typename T>
+__global__ __launch_bounds__(256) void frame_window_kernel(
+    const T* __restrict__ xp, const T* __restrict__ window, const T* __restrict__ diff_window,
+    T* __restrict__ frames, T* __restrict__ dframes, int64_t n_fft, int64_t n_hops, int64_t hop,
+    int64_t s20, int64_t s21, int modulated) {
+    const int64_t total = n_fft * n_hops;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = t % n_fft, c = t / n_fft;
+        int64_t start = hop * c, s;
+        if (!modulated) s = start + r;
+        else if (r < s20) s = start + s21 + r;
+        else s = start + (r - s20);
+        T v = xp[s];
+        frames[t] = v * window[r];
+        if (dframes) dframes[t] = v * diff_window[r];
+    }
+}
+
+// R2C with transposed (strided) output: transform c writes bin f at out[f*n_hops + c]
+struct StridedR2C {
+    rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr;
+    void* work = nullptr; size_t work_bytes = 0;
+    int create(int dtype, size_t n_fft, size_t n_hops) {
+        if (fft_global_setup()) return -4;
+        rocfft_plan_description desc = nullptr;
+        if (rocfft_plan_description_create(&desc) != rocfft_status_success) { set_error("rocfft desc"); return -4; }
+        size_t offs = 0, in_stride = 1, out_stride = n_hops;
+        if (rocfft_plan_description_set_data_layout(desc, rocfft_array_type_real,
+                rocfft_array_type_hermitian_interleaved, &offs, &offs, 1, &in_stride, n_fft, 1,
+                &out_stride, 1) != rocfft_status_success) { set_error("rocfft layout"); return -4; }
+        rocfft_status st = rocfft_plan_create(&plan, rocfft_placement_notinplace,
+                rocfft_transform_type_real_forward,
+                dtype == SSQ_F32 ? rocfft_precision_single : rocfft_precision_double, 1, &n_fft,
+                n_hops, desc);
+        rocfft_plan_description_destroy(desc);
+        if (st != rocfft_status_success) { set_error("rocfft_plan_create (stft) failed: %d", (int)st); return -4; }
+        rocfft_plan_get_work_buffer_size(plan, &work_bytes);
+        rocfft_execution_info_create(&info);
+        if (work_bytes) {
+            SSQ_CHECK_HIP(hipMalloc(&work, work_bytes));
+            rocfft_execution_info_set_work_buffer(info, work, work_bytes);
+        }
+        return 0;
+    }
+    int execute(void* in, void* out, hipStream_t stream) {
+        rocfft_execution_info_set_stream(info, stream);
+        void* ins[1] = {in}; void* outs[1] = {out};
+        rocfft_status st = rocfft_execute(plan, ins, outs, info);
+        if (st != rocfft_status_success) { set_error("rocfft_execute (stft) failed: %d", (int)st); return -4; }
+        return 0;
+    }
+    void destroy() {
+        if (info) rocfft_execution_info_destroy(info);
+        if (plan) rocfft_plan_destroy(plan);
+        if (work) (void)hipFree(work);
+        info = nullptr; plan = nullptr; work = nullptr;
+    }
+};
+
+}  // namespace ssq
+
+using namespace ssq;
+
+struct ssq_stft_plan {
+    ssq_stft_desc d;
+    int64_t padlen = 0, n1 = 0, n2 = 0, rows = 0, n_hops = 0;
+    int rsize() const { return d.dtype == SSQ_F32 ? 4 : 8; }
+    void* window = nullptr; void* diff_window = nullptr;
+    void* xp = nullptr; void* frames = nullptr; void* dframes = nullptr; void* dSx_ws = nullptr;
+    StridedR2C fft;
+    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;
+};
+
+extern "C" {
+
+int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
+    SSQ_REQUIRE(out && desc, "ssq_stft_plan_create: null pointer");
+    const ssq_stft_desc& d = *desc;
+    SSQ_REQUIRE(d.dtype == SSQ_F32 || d.dtype == SSQ_F64, "bad dtype %d", d.dtype);
+    SSQ_REQUIRE(d.n >= 1 && d.n_fft >= 1 && d.hop_len >= 1, "bad sizes n=%lld n_fft=%lld hop=%lld",
+                (long long)d.n, (long long)d.n_fft, (long long)d.hop_len);
+    SSQ_REQUIRE(d.window, "window must not be null");
+    SSQ_REQUIRE(d.padtype >= SSQ_PAD_ZERO && d.padtype <= SSQ_PAD_WRAP, "bad padtype %d", d.padtype);
+    auto* pl = new ssq_stft_plan();
+    pl->d = d;
+    if (pl->d.max_batch < 1) pl->d.max_batch = 1;
+    // padsignal(x, padlength = N + n_fft - 1): even total -> split evenly, odd -> left
+    // gets the extra sample (utils/common.py:116-124)
+    pl->padlen = d.n + d.n_fft - 1;
+    int64_t tot = pl->padlen - d.n;
+    pl->n2 = tot / 2;
+    pl->n1 = (tot % 2 == 0) ? pl->n2 : pl->n2 + 1;
+    pl->rows = d.n_fft / 2 + 1;
+    pl->n_hops = (pl->padlen - d.n_fft) / d.hop_len + 1;
+    const int rs = pl->rsize();
+    int rc = 0;
+#define TRYA(p, bytes) do { if (hipMalloc((void**)&(p), (bytes)) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; } } while (0)
+    TRYA(pl->window, (size_t)d.n_fft * rs);
+    SSQ_CHECK_HIP(hipMemcpy(pl->window, d.window, (size_t)d.n_fft * rs, hipMemcpyHostToDevice));
+    if (d.diff_window) {
+        TRYA(pl->diff_window, (size_t)d.n_fft * rs);
+        SSQ_CHECK_HIP(hipMemcpy(pl->diff_window, d.diff_window, (size_t)d.n_fft * rs, hipMemcpyHostToDevice));
+    }
+    TRYA(pl->xp, (size_t)pl->d.max_batch * pl->padlen * rs);
+    TRYA(pl->frames, (size_t)d.n_fft * pl->n_hops * rs);
+    TRYA(pl->dframes, (size_t)d.n_fft * pl->n_hops * rs);
+    TRYA(pl->dSx_ws, (size_t)pl->d.max_batch * pl->rows * pl->n_hops * rs * 2);
+#undef TRYA
+    rc = pl->fft.create(d.dtype, (size_t)d.n_fft, (size_t)pl->n_hops);
+    if (rc) { ssq_stft_plan_destroy(pl); return rc; }
+    pl->d.window = nullptr; pl->d.diff_window = nullptr;
+    *out = pl;
+    return 0;
+}
+
+void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
+    if (!pl) return;
+    pl->fft.destroy();
+    void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
+                    pl->cst, pl->Sfs};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete pl;
+}
+
+int ssq_stft_plan_set_ssq(ssq_stft_plan* pl, const void* Sfs, int grid, const double* params,
+                          const void* cst, int cst_f64, int flipud, double gamma) {
+    SSQ_REQUIRE(pl && Sfs && params && cst, "ssq_stft_plan_set_ssq: null pointer");
+    SSQ_REQUIRE(grid >= SSQ_GRID_LOG && grid <= SSQ_GRID_LIN, "unknown grid kind %d", grid);
+    for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
+    pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
+    pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
+    const int rs = pl->rsize();
+    if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->rows * 8));
+    if (!pl->Sfs) SSQ_CHECK_HIP(hipMalloc(&pl->Sfs, (size_t)pl->rows * 8));
+    SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, (size_t)pl->rows * ((cst_f64 || rs == 8) ? 8 : 4), hipMemcpyHostToDevice));
+    SSQ_CHECK_HIP(hipMemcpy(pl->Sfs, Sfs, (size_t)pl->rows * rs, hipMemcpyHostToDevice));
+    pl->have_ssq = true;
+    return 0;
+}
+
+int ssq_stft_plan_shape(const ssq_stft_plan* pl, int64_t* rows, int64_t* n_hops) {
+    SSQ_REQUIRE(pl, "ssq_stft_plan_shape: null plan");
+    if (rows) *rows = pl->rows;
+    if (n_hops) *n_hops = pl->n_hops;
+    return 0;
+}
+
+}  // extern "C"
+
+template <typename T>
+static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void* Sx, void* dSx,
+                          void* Tx, void* w, hipStream_t stream) {
+    const ssq_stft_desc& d = pl->d;
+    const int64_t rows = pl->rows, n_hops = pl->n_hops, n_fft = d.n_fft;
+    const bool deriv = dSx || Tx || w;
+    SSQ_REQUIRE(!deriv || pl->diff_window, "derivative outputs need a diff_window");
+    int rc = ssq_pad_signal(d.dtype, x, pl->xp, batch, d.n, pl->n1, pl->n2, d.padtype, stream);
+    if (rc) return rc;
+    const int64_t s20 = (n_fft + 1) / 2, s21 = (n_fft % 2 == 1) ? s20 - 1 : s20;
+    T* dS = dSx ? (T*)dSx : (T*)pl->dSx_ws;
+    for (int64_t b = 0; b < batch; ++b) {
+        const T* xp = (const T*)pl->xp + (size_t)b * pl->padlen;
+        int64_t total = n_fft * n_hops;
+        unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+        hipLaunchKernelGGL((frame_window_kernel<T>), dim3(g), dim3(256), 0, stream, xp,
+                           (const T*)pl->window, (const T*)pl->diff_window, (T*)pl->frames,
+                           deriv ? (T*)pl->dframes : (T*)nullptr, n_fft, n_hops, d.hop_len, s20, s21,
+                           d.modulated);
+        SSQ_LAUNCH_CHECK();
+        T* Sx_b = (T*)Sx + (size_t)b * rows * n_hops * 2;
+        rc = pl->fft.execute(pl->frames, Sx_b, stream);
+        if (rc) return rc;
+        if (deriv) {
+            rc = pl->fft.execute(pl->dframes, dS + (size_t)b * rows * n_hops * 2, stream);
+            if (rc) return rc;
+        }
+    }
+    if (w) {
+        rc = ssq_phase_stft(d.dtype, Sx, dS, pl->Sfs, w, batch, rows, n_hops, pl->sp.gamma, stream);
+        if (rc) return rc;
+    }
+    if (Tx) {
+        if (w)
+            rc = launch_accumulate(d.dtype, BIN_FROM_W, Sx, w, nullptr, Tx, pl->cst, pl->sp, batch,
+                                   rows, n_hops, nullptr, stream);
+        else
+            rc = launch_accumulate(d.dtype, BIN_FROM_DWX, Sx, dS, pl->Sfs, Tx, pl->cst, pl->sp, batch,
+                                   rows, n_hops, nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+extern "C" int ssq_stft_execute(ssq_stft_plan* pl, const void* x, int64_t batch, void* Sx, void* dSx,
+                                void* Tx, void* w, void* stream) {
+    SSQ_REQUIRE(pl && x && Sx, "ssq_stft_execute: null pointer");
+    SSQ_REQUIRE(batch >= 1 && batch <= pl->d.max_batch, "batch %lld outside [1, %lld]",
+                (long long)batch, (long long)pl->d.max_batch);
+    SSQ_REQUIRE(!(Tx || w) || pl->have_ssq, "Tx / w requested but ssq parameters were not set");
+    if (pl->d.dtype == SSQ_F32)
+        return stft_execute_t<float>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream));
+    return stft_execute_t<double>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream));
+}
