@@ -1,0 +1,200 @@
+# -*- coding: utf-8 -*-
+"""bench.py -- ssq_cwt throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: ssq_cwt('gmw'), N=160 000, 300 scales
+(`process_scales('log', N, wavelet, nv=32)[:300]`), float32,
+synthetic two-chirp + noise signals, already resident in HBM when the clock
+starts. One step = one batched `ssq_cwt` call over `--batch` independent signals
+per GPU (weak scaling: every rank transforms its own signals; there is no data-path
+collective -- signals are independent end to end -- and one tiny RCCL all_gather of
+per-signal checksums closes the timed region when N > 1).
+
+Prints ONE JSON line on rank 0: transforms/s (whole job), ms per step, plus
+  roofline     algorithmic HBM bytes (x in + Tx, Wx out = N*4 + 2*na*N*8 per
+               transform) / measured time, against the 8 TB/s
+               HBM3E peak. Measured with HIP events on the launch stream over the
+               timed region, for the whole transform (all of its kernels): the
+               pipeline has no single dominant kernel yet, so the whole-transform
+               figure is the honest one; per-kernel times are in profiles/.
+  cpu_baseline the CPU oracle pipeline (scipy.fft with all host cores + the OpenMP
+               C restatement of the reference's loop nests, oracle/) on ONE
+               transform of the same workload, same box, core count stated.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def two_chirps(N, seed, noise=0.1):
+    rng = np.random.default_rng(seed)
+    f0 = rng.uniform(0.01, 0.05)
+    f1 = rng.uniform(0.30, 0.45)
+    t = np.arange(N) / N
+    ph = f0 * N * t + 0.5 * (f1 - f0) * N * t**2
+    return (np.cos(2 * np.pi * ph) + np.cos(2 * np.pi * (ph + 0.04 * N * t))
+            + noise * rng.standard_normal(N))
+
+
+def cpu_baseline(N, na, seconds_budget=25.0):
+    """CPU oracle on the host cores: the same transform, one signal at a time."""
+    from oracle import oracle as orc
+    from pipeline import oracle_ssq_cwt
+    from ssqueezepy_amd.wavelets import Wavelet
+    from ssqueezepy_amd.scales import process_scales
+    import scipy.fft as sfft
+    cores = os.cpu_count() or 1
+    orc.lib()
+    wav = Wavelet()
+    scales = process_scales('log', N, wav, nv=32)[:na]
+    x = two_chirps(N, 0)
+
+    # the design step (bank, grids) is cached by the reference too
+    # (examples/benchmarks.py:30-37) -> build once, time only the transform
+    from ssqueezepy_amd.padding import pad_geometry
+    from ssqueezepy_amd.ssqueezing import (_compute_associated_frequencies,
+                                           ssq_grid_params, ssq_const)
+    sc = np.asarray(scales, dtype='float32')
+    M, n1, _ = pad_geometry(N)
+    Psih = wav(scale=sc, N=M, nohalf=False)
+    xi = wav.xifn(1., M).reshape(-1)
+    sc_ssq, st2, _, nv2 = process_scales(sc.squeeze(), N, get_params=True)
+    ssq_freqs = _compute_associated_frequencies(sc_ssq, N, wav, st2, 'peak', True,
+                                                1., 'cwt')
+    const = ssq_const('cwt', st2, nv2, sc_ssq, ssq_freqs)
+    grid, p = ssq_grid_params(ssq_freqs, True)
+    gamma = 10 * np.finfo(np.float32).eps
+
+    def one():
+        Wx, dWx = orc.cwt(x, Psih, xi, 1., n1, N, derivative=True, workers=cores)
+        return orc.ssqueeze(Wx, dWx, 'log', p, const, gamma, True, parallel=True)
+
+    one()
+    t0 = time.perf_counter()
+    runs = 0
+    while runs < 10 and time.perf_counter() - t0 < seconds_budget:
+        one()
+        runs += 1
+    dt = (time.perf_counter() - t0) / runs
+    return {"value": 1.0 / dt, "unit": "transforms/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d ssq_cwt transforms of the same workload (N=%d, %d scales, "
+                      "float32; scipy.fft workers=%d + OpenMP loop nests; wavelet "
+                      "bank cached as in examples/benchmarks.py)" % (runs, N, na, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=8, help='signals per GPU per step')
+    ap.add_argument('--n', type=int, default=160000)
+    ap.add_argument('--na', type=int, default=300)
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import ssqueezepy_amd as S
+    N, na, B = args.n, args.na, args.batch
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    # every rank owns its own signals (seeds disjoint across ranks)
+    x_host = np.stack([two_chirps(N, seed=rank * B + b) for b in range(B)])
+    x = torch.as_tensor(x_host, dtype=torch.float32, device=dev)
+
+    def step():
+        return S.ssq_cwt(x, wav, scales=scales)
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        out = step()
+    ev1.record()
+    if world > 1:
+        # the single collective of the job: per-signal checksums of Tx to every rank
+        chk = out[0].abs().sum(dim=(1, 2)).float()
+        gathered = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)
+    t = torch.tensor([wall, gpu_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, gpu_ms = t.tolist()
+
+    if rank == 0:
+        transforms = args.steps * B * world
+        value = transforms / wall
+        bytes_alg = N * 4 + 2 * na * N * 8          # per transform
+        t_transform = (gpu_ms / 1e3) / (args.steps * B)   # per GPU, event-timed
+        achieved = bytes_alg / t_transform / 1e9
+        from ssqueezepy_amd._cwt import _PLAN_CACHE
+        plan = next(iter(_PLAN_CACHE.values()))
+        line = {
+            "metric": "ssq_cwt transforms/sec (N=160k, 300 scales, f32)",
+            "value": value, "unit": "transforms/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "ssq_cwt('gmw'), N=%d, %d log scales (nv=32), "
+                                   "float32, two-chirp+noise" % (N, na),
+                       "signals_per_gpu_per_step": B,
+                       "sharding": "independent signals per rank, no data-path "
+                                   "collective; one all_gather of checksums",
+                       "algo": plan.algo},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "scope": "whole transform (all kernels), HIP-event timed",
+                         "bytes_alg_per_transform": bytes_alg,
+                         "us_per_transform": t_transform * 1e6},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                line["cpu_baseline"] = cpu_baseline(N, na)
+            except Exception as e:              # never lose the GPU number
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

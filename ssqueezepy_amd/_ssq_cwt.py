@@ -22,6 +22,61 @@ from .wavelets import Wavelet
 __all__ = ['ssq_cwt', 'phase_cwt']
 
 
+_DESIGN_CACHE = {}
+
+
+def _hashable(v):
+    if isinstance(v, np.ndarray):
+        return (v.dtype.str, v.shape, v.tobytes())
+    if hasattr(v, 'detach'):
+        return _hashable(v.detach().cpu().numpy())
+    return v
+
+
+def _ssq_design(wavelet, scales, nv, N, dt, ssq_freqs, maprange, was_padded):
+    """Host design step of `ssq_cwt`, memoised per configuration: scale vector,
+    frequency axis, reassignment weights and bin-map parameters. Sequenced exactly
+    as the reference does it: float64 scale design -> wavelet dtype for the
+    transform -> scale type / nv re-inferred from the rounded values for the
+    weights (_ssq_cwt.py:243-254, ssqueezing.py:168-188). The reference recomputes
+    all of this on every call (tens of ms of NumPy at N=160k); the values depend
+    only on the configuration, so they are cached next to the plan."""
+    key = (wavelet.key(), _hashable(scales), nv, int(N), float(dt),
+           _hashable(ssq_freqs), maprange if not isinstance(maprange, list)
+           else tuple(maprange), was_padded)
+    hit = _DESIGN_CACHE.get(key)
+    if hit is not None:
+        return hit
+    dtype = wavelet.dtype
+    scales64, cwt_scaletype, *_ = process_scales(scales, N, wavelet, nv=nv,
+                                                 get_params=True)
+    scales_dt = np.asarray(scales64, dtype=dtype)
+    scales_ssq, cwt_scaletype2, _, nv_ssq = process_scales(scales_dt.squeeze(), N,
+                                                           get_params=True)
+    if ssq_freqs is None:
+        ssq_freqs = cwt_scaletype
+    if not isinstance(ssq_freqs, np.ndarray) and not hasattr(ssq_freqs, 'detach'):
+        ssq_scaletype = ssq_freqs if isinstance(ssq_freqs, str) else cwt_scaletype2
+        if ((maprange == 'maximal' or isinstance(maprange, tuple)) and
+                ssq_scaletype == 'log-piecewise'):
+            raise ValueError("can't have `ssq_scaletype = log-piecewise` or "
+                             "tuple with `maprange = 'maximal'` "
+                             "(got %s)" % str(maprange))
+        ssq_freqs = _compute_associated_frequencies(
+            scales_ssq, N, wavelet, ssq_scaletype, maprange, was_padded, dt, 'cwt')
+    else:
+        ssq_freqs = np.asarray(ssq_freqs.detach().cpu().numpy()
+                               if hasattr(ssq_freqs, 'detach') else ssq_freqs)
+        ssq_scaletype, _ = infer_scaletype(ssq_freqs)
+    const = ssq_const('cwt', cwt_scaletype2, nv_ssq, scales_ssq, ssq_freqs)
+    grid, params = ssq_grid_params(ssq_freqs, ssq_scaletype.startswith('log'))
+    out = (scales_dt, ssq_freqs, const, grid, params)
+    if len(_DESIGN_CACHE) >= 16:
+        _DESIGN_CACHE.pop(next(iter(_DESIGN_CACHE)))
+    _DESIGN_CACHE[key] = out
+    return out
+
+
 def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
             ssq_freqs=None, padtype='reflect', squeezing='sum', maprange='peak',
             difftype='trig', difforder=None, gamma=None, vectorized=True,
@@ -77,40 +132,13 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
     wavelet = _process_gmw_wavelet(wavelet, True)
     wavelet = Wavelet._init_if_not_isinstance(wavelet, N=N)
     dtype = wavelet.dtype
-
-    # scale design, exactly as the reference sequences it: float64 design ->
-    # wavelet dtype for the transform -> scale type / nv re-inferred from the
-    # rounded values for the reassignment weights (_ssq_cwt.py:243-254,
-    # ssqueezing.py:168-169)
-    scales64, cwt_scaletype, *_ = process_scales(scales, N, wavelet, nv=nv,
-                                                 get_params=True)
-    scales_dt = np.asarray(scales64, dtype=dtype)
-    scales_ssq, cwt_scaletype2, _, nv_ssq = process_scales(scales_dt.squeeze(), N,
-                                                           get_params=True)
-
     if gamma is None:
         gamma = 10 * (EPS64 if dtype == 'float64' else EPS32)
-
-    # frequency axis of Tx
-    if ssq_freqs is None:
-        ssq_freqs = cwt_scaletype
     was_padded = bool(padtype is not None)
-    if not isinstance(ssq_freqs, np.ndarray) and not hasattr(ssq_freqs, 'detach'):
-        ssq_scaletype = ssq_freqs if isinstance(ssq_freqs, str) else cwt_scaletype2
-        if ((maprange == 'maximal' or isinstance(maprange, tuple)) and
-                ssq_scaletype == 'log-piecewise'):
-            raise ValueError("can't have `ssq_scaletype = log-piecewise` or "
-                             "tuple with `maprange = 'maximal'` "
-                             "(got %s)" % str(maprange))
-        ssq_freqs = _compute_associated_frequencies(
-            scales_ssq, N, wavelet, ssq_scaletype, maprange, was_padded, dt, 'cwt')
-    else:
-        ssq_freqs = np.asarray(ssq_freqs.detach().cpu().numpy()
-                               if hasattr(ssq_freqs, 'detach') else ssq_freqs)
-        ssq_scaletype, _ = infer_scaletype(ssq_freqs)
 
-    const = ssq_const('cwt', cwt_scaletype2, nv_ssq, scales_ssq, ssq_freqs)
-    grid, params = ssq_grid_params(ssq_freqs, ssq_scaletype.startswith('log'))
+    design = _ssq_design(wavelet, scales, nv, N, dt, ssq_freqs, maprange,
+                         was_padded)
+    scales_dt, ssq_freqs, const, grid, params = design
 
     use_cache = True if cache_wavelet is None else bool(cache_wavelet)
     xd = algos.to_device(x, _TDT[dtype])

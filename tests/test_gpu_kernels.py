@@ -1,0 +1,190 @@
+# -*- coding: utf-8 -*-
+"""Kernel-level parity on the MI355X: every C-ABI kernel entry point
+(include/ssq_hip.h, called through ssqueezepy_amd.algos) against the CPU oracle on
+identical inputs. Bin indices (integer work) must match exactly; float sums follow
+the reference's summation order and are compared exactly where the arithmetic is
+IEEE-reproducible, else within the tolerance stated at the assertion.
+Modelled on the reference's tests/fft_test.py:141-415.
+"""
+import numpy as np
+import pytest
+from conftest import (golden, kernel_inputs, make_ssq_freqs, const_of)
+
+pytestmark = pytest.mark.gpu
+NUMBA, NUMPY = 0, 1
+DTYPES = ('float32', 'float64')
+
+
+@pytest.fixture(scope='module')
+def A():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from ssqueezepy_amd import algos, _lib
+    _lib.load(build_if_missing=False)      # the in-tree HIP library must exist
+    return algos
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_phase_cwt_and_stft(A, orc, dtype):
+    na, n, gamma = 100, 1028, 1e-2
+    Wx, dWx, w, winf, Sfs, x = kernel_inputs(dtype, na, n)
+    out = _np(A.phase_cwt_gpu(Wx, dWx, gamma))
+    ref = orc.phase_cwt(Wx, dWx, gamma, typing=NUMBA)
+    assert np.array_equal(out, ref)
+    out = _np(A.phase_stft_gpu(Wx, dWx, Sfs, gamma))
+    ref = orc.phase_stft(Wx, dWx, Sfs, gamma, typing=NUMBA)
+    assert np.array_equal(out, ref)
+    # closed form, reference tolerance (tests/fft_test.py:159-174: np.allclose)
+    cf = np.abs((dWx / Wx).imag / (2 * np.pi))
+    cf[np.abs(Wx) < gamma] = np.inf
+    assert np.allclose(_np(A.phase_cwt_gpu(Wx, dWx, gamma)), cf)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('shape', [(100, 512), (300, 1000), (513, 77), (37, 16),
+                                   (1500, 40), (6000, 24)])
+def test_ssqueeze_fast_vs_oracle(A, orc, dtype, shape):
+    na, n = shape
+    gamma = 1e-2
+    Wx, dWx, *_ = kernel_inputs(dtype, max(na, 12), max(n, 12))
+    Wx, dWx = Wx[:na, :n].copy(), dWx[:na, :n].copy()
+    dWx[5, 3] = 0                      # exact-zero derivative -> bin 0 pre-flip
+    kinds = ('scalar', 'vec64', 'vecdt') if na <= 513 else ('scalar',)
+    for st in ('log-piecewise', 'log', 'linear'):
+        sf = make_ssq_freqs(na, st)
+        logscale = st.startswith('log')
+        from ssqueezepy_amd.ssqueezing import ssq_grid_params
+        _, p = ssq_grid_params(sf, logscale)
+        for flipud in (False, True):
+            for ck in kinds:
+                const = const_of(ck, na, dtype)
+                out, k = A.ssqueeze_fast(Wx, dWx, sf, const, logscale, flipud,
+                                         gamma, get_k=True)
+                ref, kref = orc.ssqueeze(Wx, dWx, st, p, const, gamma, flipud,
+                                         typing=NUMBA, get_k=True)
+                assert np.array_equal(_np(k), kref), (st, flipud, ck)   # index: exact
+                assert np.array_equal(_np(out), ref), (st, flipud, ck)  # sums: same order
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_ssqueeze_fast_vs_reference_golden(A, dtype):
+    """Against the reference's own outputs (NumPy-typed run, see oracle/): identical
+    except at float32 bin-edge ties; column sums are assignment-invariant."""
+    g = golden('kernels_' + dtype)
+    na, n, gamma = int(g['na']), int(g['n']), float(g['gamma'])
+    Wx, dWx, w, winf, Sfs, x = kernel_inputs(dtype, na, n)
+    for st in ('log-piecewise', 'log', 'linear'):
+        sf = make_ssq_freqs(na, st)
+        for flipud in (False, True):
+            out = _np(A.ssqueeze_fast(Wx, dWx, sf, const_of('scalar', na, dtype),
+                                      st.startswith('log'), flipud, gamma))
+            ref = g[f'ssq_cwt/{st}/{int(flipud)}/scalar']
+            differing = (np.abs(out - ref) > 1e-6 * np.abs(ref).max()).mean()
+            assert differing <= (5e-3 if dtype == 'float32' else 1e-3), differing
+            assert np.allclose(out.sum(0), ref.sum(0), rtol=0,
+                               atol=(2e-6 if dtype == 'float32' else 1e-13)
+                               * np.abs(ref.sum(0)).max())
+    for flipud in (False, True):
+        out = _np(A.ssqueeze_fast(Wx, dWx, Sfs, Sfs[1] - Sfs[0], False, flipud,
+                                  gamma, Sfs=Sfs))
+        ref = g[f'ssq_stft/{int(flipud)}']
+        assert (np.abs(out - ref) > 1e-6 * np.abs(ref).max()).mean() <= 5e-3
+        assert np.allclose(out.sum(0), ref.sum(0), rtol=0,
+                           atol=(2e-6 if dtype == 'float32' else 1e-13)
+                           * np.abs(ref.sum(0)).max())
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_ssqueeze_stft_form_and_batch(A, orc, dtype):
+    na, n, gamma = 129, 300, 1e-2
+    Wx, dWx, w, winf, Sfs, x = kernel_inputs(dtype, na, n)
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    _, p = ssq_grid_params(Sfs, False)
+    for flipud in (False, True):
+        out, k = A.ssqueeze_fast(Wx, dWx, Sfs, Sfs[1] - Sfs[0], False, flipud,
+                                 gamma, Sfs=Sfs, get_k=True)
+        ref, kref = orc.ssqueeze(Wx, dWx, 'linear', p, Sfs[1] - Sfs[0], gamma,
+                                 flipud, Sfs=Sfs, typing=NUMBA, get_k=True)
+        assert np.array_equal(_np(k), kref)
+        assert np.array_equal(_np(out), ref)
+    # batched == looped (reference: tests/fft_test.py:559-631)
+    Wb = np.stack([Wx, Wx[::-1].copy(), 2 * Wx])
+    dWb = np.stack([dWx, dWx[::-1].copy(), dWx])
+    sf = make_ssq_freqs(na, 'log')
+    outb = _np(A.ssqueeze_fast(Wb, dWb, sf, 0.5, True, True, gamma))
+    for b in range(3):
+        assert np.array_equal(outb[b], _np(A.ssqueeze_fast(Wb[b], dWb[b], sf, 0.5,
+                                                           True, True, gamma)))
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_indexed_sum_onfly(A, orc, dtype):
+    na, n = 100, 512
+    Wx, dWx, w, winf, Sfs, x = kernel_inputs(dtype, na, n)
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    for st in ('log-piecewise', 'log', 'linear'):
+        sf = make_ssq_freqs(na, st)
+        _, p = ssq_grid_params(sf, st.startswith('log'))
+        for flipud in (False, True):
+            for ck in ('scalar', 'vec64'):
+                const = const_of(ck, na, dtype)
+                out = _np(A.indexed_sum_onfly(Wx, winf, sf, const,
+                                              st.startswith('log'), flipud))
+                ref = orc.indexed_sum(Wx, winf, st, p, const, flipud, typing=NUMBA)
+                if dtype == 'float64' or st == 'linear':
+                    assert np.array_equal(out, ref), (st, flipud, ck)
+                else:
+                    # float32 log grids: log2f (device libm vs glibc) may differ by
+                    # an ulp, which moves a point only when it sits on a bin edge;
+                    # reference tolerance (tests/fft_test.py:277-281): mean abs
+                    # diff < 1e-8
+                    assert np.abs(out - ref).mean() < 1e-8, (st, flipud, ck)
+                    assert (out != ref).mean() < 1e-3
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_replace_buffer_pad(A, orc, dtype):
+    import torch
+    g = golden('kernels_' + dtype)
+    na, n = int(g['na']), int(g['n'])
+    Wx, dWx, w, winf, Sfs, x = kernel_inputs(dtype, na, n)
+    wt = A.to_device(w.copy())
+    A.replace_under_abs(wt, Wx, 1.5, np.inf)
+    assert np.array_equal(_np(wt), g['replace_under_abs'])
+    for seg, ov in ((128, 96), (127, 100), (64, 0), (33, 32)):
+        for mod in (False, True):
+            out = _np(A.buffer(x, seg, ov, mod))
+            assert np.array_equal(out, g[f'buffer/{seg}/{ov}/{int(mod)}'])
+    xb = np.stack([x, x[::-1].copy()])
+    outb = _np(A.buffer(xb, 100, 60, True))
+    assert np.array_equal(outb[1], orc.buffer(xb[1], 100, 60, True))
+    from ssqueezepy_amd.padding import padsignal
+    for pt in ('reflect', 'symmetric', 'replicate', 'wrap', 'zero'):
+        for n1, n2 in ((12, 12), (5, 4), (0, 7)):
+            ref = np.pad(x[:50], (n1, n2), mode={'zero': 'constant', 'reflect': 'reflect',
+                                                'symmetric': 'symmetric', 'replicate': 'edge',
+                                                'wrap': 'wrap'}[pt])
+            assert np.array_equal(_np(A.pad_signal_gpu(x[:50], n1, n2, pt)), ref)
+    # reflect pad longer than the signal (numpy repeats the reflection)
+    ref = np.pad(x[:10], (23, 17), mode='reflect')
+    assert np.array_equal(_np(A.pad_signal_gpu(x[:10], 23, 17, 'reflect')), ref)
+
+
+def test_error_paths(A):
+    import torch
+    from ssqueezepy_amd._lib import SsqError
+    Wx = np.ones((4, 8), np.complex64)
+    with pytest.raises(ValueError):
+        A.ssqueeze_fast(Wx, Wx, np.linspace(1, 2, 4), 1., False, False, None)
+    with pytest.raises(ValueError):
+        A.ssqueeze_fast(Wx, Wx[:, :4], np.linspace(1, 2, 4), 1., False, False, 1e-3)
+    with pytest.raises(TypeError):
+        A.ssqueeze_fast(Wx.real.copy(), Wx, np.linspace(1, 2, 4), 1., False, False, 1e-3)
+    from ssqueezepy_amd import _lib
+    lib = _lib.load()
+    rc = lib.ssq_pad_signal(7, None, None, 1, 4, 1, 1, 1, None)
+    assert rc != 0 and b'dtype' in lib.ssq_last_error()
