@@ -89,9 +89,12 @@ class CwtPlan():
 
     def set_ssq(self, grid, params, const, flipud, gamma):
         """Synchrosqueezing parameters for subsequent `execute(..., Tx=...)`."""
+        # as the reference materialises it (algos.py:66-79): a scalar becomes a
+        # vector in the data dtype; a float64 *vector* with float32 data stays
+        # float64 and the accumulate is then done in double
         const = np.asarray(const)
         if const.size != self.na:
-            const = np.full(self.na, float(const))
+            const = np.full(self.na, float(const)).astype(self.dtype)
         const = const.reshape(-1)
         c64 = int(self.dtype == 'float32' and const.dtype == np.float64)
         if not c64:

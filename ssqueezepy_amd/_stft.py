@@ -149,8 +149,7 @@ class StftPlan():
         if const.size != self.rows:
             const = np.full(self.rows, float(const))
         const = const.reshape(-1)
-        c64 = int(self.dtype == 'float32' and const.dtype == np.float64
-                  and const.size == self.rows and False)
+        c64 = 0      # the STFT weight is a scalar -> always the data dtype
         const = np.ascontiguousarray(const.astype(self.dtype))
         key = (Sfs.tobytes(), int(grid), tuple(float(v) for v in params),
                const.tobytes(), bool(flipud), float(gamma))

@@ -92,7 +92,12 @@ def test_ssq_cwt_options(S, orc, dtype):
     wref = g['w/256/log']
     fin = np.isfinite(wref)
     assert np.array_equal(np.isfinite(w), fin)
-    assert np.allclose(w[fin], wref[fin], rtol=2e-3 if dtype == 'float32' else 1e-8)
+    # w = Im(dWx/Wx)/2pi is ill-conditioned where |Wx| is tiny: compare where the
+    # transform has energy ("dWx/w where |Wx| >> gamma")
+    strong = fin & (np.abs(g['Wx/256/log']) > 1e-2 * np.abs(g['Wx/256/log']).max())
+    assert strong.mean() > 0.2
+    assert np.allclose(w[strong], wref[strong],
+                       rtol=1e-3 if dtype == 'float32' else 1e-9)
     r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=16)
     assert np.array_equal(w, orc.phase_cwt(Wx, dWx, r['gamma'], typing=NUMBA))
     ref = orc.indexed_sum(Wx, w, 'log', r['params'], r['const'], True, typing=NUMBA)
@@ -207,8 +212,13 @@ def test_ssq_stft_vs_reference(S, orc, dtype):
     wref = g['w/600/getw']
     fin = np.isfinite(wref)
     assert np.array_equal(np.isfinite(out[4]), fin)
-    assert np.allclose(out[4][fin], wref[fin], rtol=5e-3 if dtype == 'float32' else 1e-7,
-                       atol=1e-4 if dtype == 'float32' else 1e-10)
+    Sref = np.abs(oracle_ssq_stft(orc, x, dtype, n_fft=128, hop_len=16, fs=10.,
+                                  ssq=False)['Sx'])
+    strong = fin & (Sref > 1e-2 * Sref.max())
+    assert strong.mean() > 0.05
+    assert np.allclose(out[4][strong], wref[strong],
+                       rtol=1e-3 if dtype == 'float32' else 1e-9,
+                       atol=1e-4 if dtype == 'float32' else 1e-11)
     Sx = S.stft(x, 'hann', n_fft=128, win_len=100, hop_len=16, dtype=dtype,
                 astensor=False)
     assert relmax(Sx, g['Sx/600/hann100']) <= RTOL[dtype]
