@@ -168,6 +168,32 @@ int  ssq_cwt_plan_set_ssq(ssq_cwt_plan* plan, int grid, const double* params,
 int  ssq_cwt_execute(ssq_cwt_plan* plan, const void* x, int64_t batch, void* Wx,
                      void* dWx, void* Tx, void* w, int rpadded, void* stream);
 
+/* Optional fast path ("overlap-save zoom" iFFT, float32, power-of-two m, analytic
+ * bank): tables planned on the host (ssqueezepy_amd/_blocks.py documents the
+ * decomposition; all pointers are host arrays, copied). Rows with class -1 in `rows`
+ * -- listed in `generic_rows` -- keep using the exact full-length path.
+ * Must be called before the first execute. No reference counterpart: the reference
+ * evaluates every row as one length-m inverse FFT (_cwt.py:167-177); this is the
+ * same filter bank applied block-wise. */
+typedef struct {
+    int            n_classes;
+    const int64_t* classes;      /* n_classes x 4: P, margin, valid, blocks/signal  */
+    const int32_t* rows;         /* na x 6: class, kappa_lo, K_P, L', G, pbank_off  */
+    const float*   pbank;        /* P-grid band values of the block rows            */
+    int64_t        n_pbank;
+    const void*    ctw;          /* complex64 column twiddles exp(2i pi q/P)/P      */
+    const int64_t* ctw_off;      /* n_classes + 1                                   */
+    const void*    ftw;          /* complex64 FFT twiddles exp(2i pi q/L')          */
+    int64_t        n_ftw;
+    int64_t        ftw_off[5];   /* per L' = 128, 256, 512, 1024, 2048              */
+    const int32_t* items[5];     /* per L': n_items x 4: row, block, c0, class      */
+    int64_t        n_items[5];
+    const int32_t* generic_rows; /* rows left on the exact path                     */
+    int64_t        n_generic;
+} ssq_cwt_blocks_desc;
+
+int  ssq_cwt_plan_set_blocks(ssq_cwt_plan* plan, const ssq_cwt_blocks_desc* desc);
+
 /* bytes of device memory held by the plan (bank + workspace) */
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);
 /* name of the compute path the plan selected ("rocfft", "zoom+rocfft", ...) */

@@ -1,0 +1,184 @@
+# -*- coding: utf-8 -*-
+"""Block ("overlap-save zoom") decomposition of the CWT -- host-side planning.
+
+The reference computes every row as one length-M inverse FFT of
+``psih(scale*xi) * xh`` (ssqueezepy/_cwt.py:167-177). On the device that is ~14 GFLOP
+and several HBM round trips per transform at N=160k. Two properties of analytic
+wavelet filter banks make a far cheaper *equivalent* evaluation possible:
+
+  (1) each row is band-limited: non-negligible on K bins of the M-point grid;
+  (2) each row's impulse response is short: all but a 1e-9 fraction of its L1 mass
+      lies within +-m samples, m ~ 30 * scale for the default GMW (measured per
+      row, in double, from the bank itself -- nothing is assumed about the wavelet).
+
+By (2) the circular convolution over M samples can be evaluated block by block
+(overlap-save): a block of P >= 8m consecutive samples of the padded signal,
+filtered circularly with the P-periodised wavelet, equals the true output on its
+central V = 3P/4 samples up to the truncated tail mass. The P-periodised wavelet's
+spectrum is the M-point bank sampled every M/P-th bin -- the very same numbers. By
+(1) the block's P-point inverse FFT has only K*P/M non-zero inputs, so it splits
+into R' = P/L' independent L'-point FFTs (L' = 128...2048, a "zoom" FFT): output
+sample t = q*R' + c is entry q of the FFT of column c, whose inputs are the band
+entries times exp(2i*pi*kappa*c/P). L'-point FFTs fit in LDS, adjacent columns are
+adjacent output samples (coalesced stores), and nothing but the returned arrays
+touches HBM.
+
+Rows for which (2) fails -- the few smallest scales, whose pass-band is cut by the
+Nyquist frequency so that their impulse response decays like 1/t -- and rows of a
+non-analytic / non-power-of-two configuration stay on the exact full-length path.
+
+This module measures m per row, picks the block class of every row and builds the
+tables the kernel needs (`ssq_cwt_plan_set_blocks`, include/ssq_hip.h).
+"""
+import numpy as np
+import scipy.fft as sfft
+
+__all__ = ['plan_blocks']
+
+POINTS_PER_WG = 4096          # D = L' * G complex points per workgroup
+L_MIN, L_MAX = 128, 2048
+P_MIN = 4096
+
+
+def _is_pow2(v):
+    return v >= 1 and (v & (v - 1)) == 0
+
+
+def _margins(vals, off, lo, M, tol, chunk=32):
+    """Per row: smallest m such that the impulse response's L1 mass outside
+    [-m, m] (circularly, on the M-point grid) is <= tol * total. Double precision."""
+    na = len(lo)
+    lens = np.diff(off)
+    out = np.empty(na, np.int64)
+    half = M // 2
+    for i0 in range(0, na, chunk):
+        rows = range(i0, min(na, i0 + chunk))
+        D = np.zeros((len(rows), M), np.complex128)
+        for r, i in enumerate(rows):
+            D[r, lo[i]:lo[i] + lens[i]] = vals[off[i]:off[i + 1]]
+        h = np.abs(sfft.ifft(D, axis=-1, workers=-1))
+        f = h[:, :half + 1].copy()
+        f[:, 1:half] += h[:, :half:-1]
+        tot = f.sum(1)
+        cs = np.cumsum(f[:, ::-1], axis=1)[:, ::-1]      # cs[s] = sum_{s' >= s}
+        for r, i in enumerate(rows):
+            ok = np.nonzero(cs[r] <= tol * tot[r])[0]
+            out[i] = ok[0] if len(ok) else half
+    return out
+
+
+def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
+    """Plan the block decomposition.
+
+    vals/off/lo: banded bank on the M-grid (`_bank.banded_bank`). `vals64`: the
+    same band evaluated in float64 if available (margins are then measured on the
+    clean wavelet rather than on its float32 rounding noise).
+    Returns None when no row qualifies, else a dict of NumPy arrays:
+      classes  (nc, 4) int64: P, m (margin), V (valid), nb (blocks per signal)
+      rows     (na, 6) int32: class (-1 = exact path), kappa_lo, K_P, L', G, pbank_off
+      pbank    concatenated P-grid band values of the block rows (bank dtype)
+      ctw      per class: exp(2i*pi*q/P)/P, q in [0, P)   (complex, concatenated)
+      ctw_off  (nc + 1) int64 offsets into ctw
+      ftw      per L': exp(2i*pi*q/L'), concatenated for L' = 128..2048
+      items    dict L' -> (n_items, 4) int32: row, block, c0, class
+      generic_rows  int32 indices of rows left on the exact path
+    """
+    if not _is_pow2(M) or M < P_MIN or str(np.dtype(dtype)) != 'float32':
+        return None
+    na = len(lo)
+    lens = np.diff(off)
+    half = M // 2
+    if np.any(lo + lens > half + 1):
+        return None                                   # negative-frequency content
+    margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol)
+
+    # block classes: P = 4096, 8192, ..., M/2 (margin P/8, valid 3P/4) and the
+    # "global" class P = M (one block, no margin needed: the circular convolution
+    # over the padded signal *is* the reference's definition)
+    Ps = []
+    P = P_MIN
+    while P < M:
+        Ps.append(P)
+        P *= 2
+    Ps.append(M)
+    cls_of = np.full(na, -1, np.int64)
+    rows = np.zeros((na, 6), np.int32)
+    rows[:, 0] = -1
+    pb, pb_off = [], 0
+    for i in range(na):
+        if lens[i] == 0:
+            continue
+        for c, P in enumerate(Ps):
+            if P < M and 8 * margins[i] > P:
+                continue
+            S = M // P
+            k_lo = -(-int(lo[i]) // S)                       # ceil(lo / S)
+            k_hi = (int(lo[i]) + int(lens[i]) - 1) // S       # last P-grid bin in band
+            KP = k_hi - k_lo + 1
+            if KP <= 0:
+                k_lo, KP = int(lo[i]) // S, 0
+            Lp = L_MIN
+            while Lp < KP:
+                Lp *= 2
+            if Lp > L_MAX:
+                break                      # band too wide for an LDS FFT: exact path
+            G = POINTS_PER_WG // Lp
+            if P // Lp < G:
+                continue                   # fewer columns than a workgroup handles
+            cls_of[i] = c
+            sel = (np.arange(k_lo, k_lo + KP) * S - int(lo[i])) + int(off[i])
+            pb.append(vals[sel])
+            rows[i] = (c, k_lo, KP, Lp, G, pb_off)
+            pb_off += KP
+            break
+    used = sorted(set(int(c) for c in cls_of if c >= 0))
+    if not used:
+        return None
+    remap = {c: j for j, c in enumerate(used)}
+    classes = np.zeros((len(used), 4), np.int64)
+    ctw, ctw_off = [], [0]
+    for c in used:
+        P = Ps[c]
+        if P == M:
+            m, V, nb, t0 = 0, M, 1, 0
+        else:
+            m, V = P // 8, 3 * P // 4
+            nb = -(-N // V)
+        classes[remap[c]] = (P, m, V, nb)
+        q = np.arange(P)
+        w = np.exp(2j * np.pi * q / P) / P
+        ctw.append(w.astype(np.complex64))
+        ctw_off.append(ctw_off[-1] + P)
+    for i in range(na):
+        if rows[i, 0] >= 0:
+            rows[i, 0] = remap[int(rows[i, 0])]
+    # FFT twiddles per L'
+    ftw, ftw_off = [], {}
+    o = 0
+    Lp = L_MIN
+    while Lp <= L_MAX:
+        ftw.append(np.exp(2j * np.pi * np.arange(Lp) / Lp).astype(np.complex64))
+        ftw_off[Lp] = o
+        o += Lp
+        Lp *= 2
+    # work items per L': (row, block, c0, class)
+    items = {}
+    for i in range(na):
+        c = rows[i, 0]
+        if c < 0:
+            continue
+        P, m, V, nb = classes[c]
+        Lp, G = int(rows[i, 3]), int(rows[i, 4])
+        Rp = int(P) // Lp
+        b, c0 = np.meshgrid(np.arange(nb), np.arange(0, Rp, G), indexing='ij')
+        it = np.stack([np.full(b.size, i), b.ravel(), c0.ravel(),
+                       np.full(b.size, c)], axis=1).astype(np.int32)
+        items.setdefault(Lp, []).append(it)
+    items = {Lp: np.concatenate(v) for Lp, v in items.items()}
+    generic_rows = np.nonzero(rows[:, 0] < 0)[0].astype(np.int32)
+    return dict(classes=classes, rows=rows,
+                pbank=(np.concatenate(pb) if pb else np.zeros(1, vals.dtype)
+                       ).astype(vals.dtype),
+                ctw=np.concatenate(ctw), ctw_off=np.array(ctw_off, np.int64),
+                ftw=np.concatenate(ftw), ftw_off=ftw_off, items=items,
+                generic_rows=generic_rows, margins=margins)

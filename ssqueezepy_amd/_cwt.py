@@ -11,13 +11,15 @@ wrapper: design step (cached) -> one `ssq_cwt_execute` call.
 """
 import ctypes
 import logging
+import os
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, F32, F64, CwtDesc
+from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc
 from . import algos
 from ._bank import banded_bank
+from ._blocks import plan_blocks, L_MIN
 from .padding import pad_geometry, PADTYPES
 from .scales import process_scales, _process_fs_and_t
 from .wavelets import Wavelet
@@ -69,6 +71,62 @@ class CwtPlan():
         self._h = ctypes.c_void_p()
         check(self.lib.ssq_cwt_plan_create(ctypes.byref(self._h), ctypes.byref(desc)))
         self._ssq_key = None
+        self.block_rows = 0
+        if algo == 0 and os.environ.get('SSQ_CWT_ALGO', 'auto') != 'generic':
+            self._try_blocks(wavelet, vals, off, lo)
+
+    def _try_blocks(self, wavelet, vals, off, lo):
+        """Plan and install the block ("overlap-save zoom") fast path when the
+        configuration admits it (float32, padded power-of-two length, analytic
+        bank); see _blocks.py. Impulse-response margins are measured on the
+        wavelet evaluated in float64 when it is a built-in family."""
+        if self.dtype != 'float32' or self.padtype is None:
+            return
+        vals64 = None
+        if wavelet.family is not None:
+            cfg = {k: v for k, v in wavelet.config.items() if k != 'dtype'}
+            try:
+                twin = Wavelet((wavelet.family, dict(cfg, dtype='float64')))
+                v64, o64, l64 = banded_bank(twin, self.scales.astype('float64'),
+                                            self.M, tol=1e-3 * np.finfo('float32').eps)
+                if np.array_equal(o64, off) and np.array_equal(l64, lo):
+                    vals64 = v64
+            except Exception:
+                vals64 = None
+        bp = plan_blocks(vals, off, lo, self.M, self.N, self.n1, self.dtype,
+                         vals64=vals64)
+        if bp is None:
+            return
+        cls = np.ascontiguousarray(bp['classes'], dtype=np.int64)
+        # the single-block class spans the whole padded signal: its "margin" is the
+        # left pad, so that block sample t maps to output t - n1 (see kernel)
+        cls[cls[:, 0] == self.M, 1] = self.n1
+        rows = np.ascontiguousarray(bp['rows'], dtype=np.int32)
+        pbank = np.ascontiguousarray(bp['pbank'], dtype=np.float32)
+        ctw = np.ascontiguousarray(bp['ctw'], dtype=np.complex64)
+        ctw_off = np.ascontiguousarray(bp['ctw_off'], dtype=np.int64)
+        ftw = np.ascontiguousarray(bp['ftw'], dtype=np.complex64)
+        gen = np.ascontiguousarray(bp['generic_rows'], dtype=np.int32)
+        keep = [cls, rows, pbank, ctw, ctw_off, ftw, gen]
+        d = CwtBlocksDesc()
+        d.n_classes = len(cls)
+        d.classes, d.rows = cls.ctypes.data, rows.ctypes.data
+        d.pbank, d.n_pbank = pbank.ctypes.data, len(pbank)
+        d.ctw, d.ctw_off = ctw.ctypes.data, ctw_off.ctypes.data
+        d.ftw, d.n_ftw = ftw.ctypes.data, len(ftw)
+        for slot in range(5):
+            Lp = L_MIN << slot
+            it = np.ascontiguousarray(bp['items'].get(Lp, np.zeros((0, 4))),
+                                      dtype=np.int32)
+            keep.append(it)
+            d.items[slot] = it.ctypes.data if len(it) else None
+            d.n_items[slot] = len(it)
+            d.ftw_off[slot] = bp['ftw_off'][Lp]
+        d.generic_rows = gen.ctypes.data if len(gen) else None
+        d.n_generic = len(gen)
+        check(self.lib.ssq_cwt_plan_set_blocks(self._h, ctypes.byref(d)))
+        self.block_rows = int((rows[:, 0] >= 0).sum())
+        self.block_plan = {k: bp[k] for k in ('classes', 'margins')}
 
     def __del__(self):
         h = getattr(self, '_h', None)

@@ -31,6 +31,15 @@ class CwtDesc(Structure):
                 ('algo', c_int)]
 
 
+class CwtBlocksDesc(Structure):
+    _fields_ = [('n_classes', c_int), ('classes', c_void_p), ('rows', c_void_p),
+                ('pbank', c_void_p), ('n_pbank', c_int64), ('ctw', c_void_p),
+                ('ctw_off', c_void_p), ('ftw', c_void_p), ('n_ftw', c_int64),
+                ('ftw_off', c_int64 * 5), ('items', c_void_p * 5),
+                ('n_items', c_int64 * 5), ('generic_rows', c_void_p),
+                ('n_generic', c_int64)]
+
+
 class StftDesc(Structure):
     _fields_ = [('dtype', c_int), ('padtype', c_int), ('n', c_int64),
                 ('n_fft', c_int64), ('hop_len', c_int64), ('modulated', c_int),
@@ -74,6 +83,7 @@ _PROTOS = {
                                      c_int, c_int, c_double]),
     'ssq_cwt_execute': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int, c_void_p]),
+    'ssq_cwt_plan_set_blocks': (c_int, [c_void_p, POINTER(CwtBlocksDesc)]),
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),

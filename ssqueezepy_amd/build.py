@@ -23,6 +23,7 @@ HIPCC = os.path.join(ROCM, 'bin', 'hipcc')
 SOURCES = [
     ('ssq_kernels.hip', ['-ffp-contract=off']),
     ('ssq_cwt.hip', ['-ffp-contract=off']),
+    ('ssq_cwt_blocks.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
     ('ssq_fft.hip', []),
 ]

@@ -1,0 +1,53 @@
+// ssq_blocks.h -- device tables and plan object of the block ("overlap-save zoom")
+// CWT fast path (kernels in ssq_cwt_blocks.hip, host planning in _blocks.py).
+#pragma once
+#include "ssq_common.h"
+#include "ssq_fft.h"
+#include <algorithm>
+#include <vector>
+
+namespace ssq {
+
+struct BlockRowDev {        // one per scale row; mirrors _blocks.py `rows` (na, 6) int32
+    int32_t cls;            // block class, -1 = row stays on the exact path
+    int32_t klo;            // first P-grid bin of the band
+    int32_t KP;             // number of P-grid bins in the band
+    int32_t L;              // zoom FFT length L'
+    int32_t G;              // columns per workgroup (L' * G == 4096)
+    int32_t pb_off;         // offset of the row's P-grid band values in `pbank`
+};
+
+struct BlockClassDev {
+    int64_t P, m, V, nb;    // block length, margin, valid length, blocks per signal
+    int64_t ctw_off;        // offset of the class' column twiddles
+    int64_t xb_off;         // offset of the class' block spectra
+};
+
+struct BlockPlan {
+    int64_t M = 0, N = 0, n1 = 0, na = 0, max_batch = 1;
+    int nc = 0;
+    std::vector<BlockClassDev> hcls;
+    BlockClassDev* classes = nullptr;
+    BlockRowDev* rows = nullptr;
+    float* pbank = nullptr;
+    void* ctw = nullptr; void* ftw = nullptr;
+    void* items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t n_items[5] = {0, 0, 0, 0, 0};
+    int64_t ftw_off[5] = {0, 0, 0, 0, 0};
+    float* blocks = nullptr;         // gathered signal blocks of one class
+    struct c32_ { float x, y; };
+    c32_* xb = nullptr;              // block spectra of every class
+    std::vector<FftPlan> ffts;
+    int64_t n_generic = 0;
+
+    int create(const ssq_cwt_blocks_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na,
+               int64_t max_batch, int64_t& bytes);
+    void destroy();
+    // block spectra of all classes for the padded batch xp (max_batch x M)
+    int spectra(const float* xp, int64_t batch, hipStream_t stream);
+    // all block rows of signal `sig`
+    int run(int sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+            const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
+};
+
+}  // namespace ssq

@@ -18,6 +18,7 @@
 // ssq_kernels.hip).
 #include "ssq_common.h"
 #include "ssq_fft.h"
+#include "ssq_blocks.h"
 #include <algorithm>
 #include <map>
 #include <string>
@@ -35,9 +36,9 @@ __global__ __launch_bounds__(256) void bank_multiply_kernel(
     const T* __restrict__ bank, const int64_t* __restrict__ band_off,
     const int32_t* __restrict__ band_lo,
     T* __restrict__ prod,            // [rows][nplanes][M] complex
-    int64_t M, int64_t row0, int nplanes, double h, T inv_dt) {
+    int64_t M, const int32_t* __restrict__ rowlist, int64_t row0, int nplanes, double h, T inv_dt) {
     const int64_t r = blockIdx.y;            // row within the chunk
-    const int64_t i = row0 + r;
+    const int64_t i = rowlist[row0 + r];
     const int64_t lo = band_lo[i];
     const int64_t off = band_off[i];
     const int64_t len = band_off[i + 1] - off;
@@ -71,6 +72,7 @@ struct EpilogueArgs {
     int64_t out_cols;     // N, or M when rpadded
     int64_t col0;         // n1, or 0 when rpadded
     int64_t row0;
+    const int32_t* rowlist;
     const void* row_scale;
     double gamma;
     int have_ssq;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void cwt_epilogue_kernel(const T* __restrict__
                                                            int nplanes, int64_t na,
                                                            EpilogueArgs ea, SsqParams sp) {
     const int64_t r = blockIdx.y;
-    const int64_t i = ea.row0 + r;
+    const int64_t i = ea.rowlist[ea.row0 + r];
     const T* P = prod + (size_t)r * nplanes * 2 * M;
     const T* dP = P + 2 * M;
     const int64_t omax = na - 1;
@@ -138,6 +140,13 @@ struct ssq_cwt_plan {
     // ssq
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr;
     std::string algo = "rocfft";
+    // rows evaluated by the exact full-length path (all rows unless a block plan
+    // took some over)
+    int32_t* gen_rows = nullptr; int64_t n_gen = 0;
+    int32_t* all_rows = nullptr;          // identity list (rpadded output bypasses blocks)
+    const int32_t* gen_rows_for(bool use_blocks) const { return use_blocks ? gen_rows : all_rows; }
+    BlockPlan* blk = nullptr;
+    bool executed = false;
 };
 
 static int dev_alloc(void** p, size_t bytes, int64_t& acc) {
@@ -194,6 +203,15 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
     TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
     TRY(dev_alloc((void**)&pl->kidx, (size_t)d.na * d.n * 2, pl->bytes));
+    {
+        std::vector<int32_t> all((size_t)d.na);
+        for (int64_t i = 0; i < d.na; ++i) all[i] = (int32_t)i;
+        TRY(dev_alloc((void**)&pl->gen_rows, (size_t)d.na * 4, pl->bytes));
+        TRY(dev_alloc((void**)&pl->all_rows, (size_t)d.na * 4, pl->bytes));
+        SSQ_CHECK_HIP(hipMemcpy(pl->gen_rows, all.data(), (size_t)d.na * 4, hipMemcpyHostToDevice));
+        SSQ_CHECK_HIP(hipMemcpy(pl->all_rows, all.data(), (size_t)d.na * 4, hipMemcpyHostToDevice));
+        pl->n_gen = d.na;
+    }
     TRY(pl->fwd.create(0, d.dtype, (size_t)d.m, (size_t)pl->d.max_batch, 1.0));
     pl->bytes += (int64_t)pl->fwd.work_bytes;
 #undef TRY
@@ -205,8 +223,9 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     if (!pl) return;
     pl->fwd.destroy();
     for (auto& kv : pl->inv) kv.second.destroy();
+    if (pl->blk) { pl->blk->destroy(); delete pl->blk; }
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
-                    pl->kidx, pl->cst};
+                    pl->kidx, pl->cst, pl->gen_rows, pl->all_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -222,6 +241,28 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->d.na * 8));
     SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, bytes, hipMemcpyHostToDevice));
     pl->have_ssq = true;
+    return 0;
+}
+
+int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
+    SSQ_REQUIRE(pl && bd, "ssq_cwt_plan_set_blocks: null pointer");
+    SSQ_REQUIRE(!pl->executed && !pl->blk, "block tables must be set once, before the first execute");
+    SSQ_REQUIRE(pl->d.dtype == SSQ_F32, "the block path is float32 only");
+    SSQ_REQUIRE(pl->d.padtype != SSQ_PAD_NONE, "the block path needs a padded (power-of-two) length");
+    SSQ_REQUIRE((pl->d.m & (pl->d.m - 1)) == 0, "the block path needs a power-of-two padded length");
+    SSQ_REQUIRE(bd->n_classes >= 1 && bd->n_generic >= 0 && bd->n_generic <= pl->d.na, "bad block tables");
+    for (int c = 0; c < bd->n_classes; ++c) {
+        int64_t P = bd->classes[4 * c];
+        SSQ_REQUIRE(P >= 4096 && (P & (P - 1)) == 0 && P <= pl->d.m, "class %d: bad block length %lld", c, (long long)P);
+    }
+    auto* b = new BlockPlan();
+    int rc = b->create(*bd, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->d.max_batch, pl->bytes);
+    if (rc) { b->destroy(); delete b; return rc; }
+    pl->blk = b;
+    pl->n_gen = bd->n_generic;
+    if (pl->n_gen)
+        SSQ_CHECK_HIP(hipMemcpy(pl->gen_rows, bd->generic_rows, (size_t)pl->n_gen * 4, hipMemcpyHostToDevice));
+    pl->algo = pl->n_gen ? "blockzoom+rocfft" : "blockzoom";
     return 0;
 }
 
@@ -261,18 +302,35 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         if (rc) return rc;
     }
 
+    pl->executed = true;
+    const bool use_blocks = pl->blk && !rpadded;
+    const int64_t n_gen = use_blocks ? pl->n_gen : na;
+    if (use_blocks) {
+        if constexpr (sizeof(T) == 4) {
+            int rc = pl->blk->spectra((const float*)pl->xp, batch, stream);
+            if (rc) return rc;
+        }
+    }
     for (int64_t b = 0; b < batch; ++b) {
         const T* xh = (const T*)pl->xh + (size_t)b * (M / 2 + 1) * 2;
         T* Wx_b = Wx ? (T*)Wx + (size_t)b * na * out_cols * 2 : nullptr;
         T* dWx_b = dWx ? (T*)dWx + (size_t)b * na * out_cols * 2 : nullptr;
         T* w_b = w ? (T*)w + (size_t)b * na * out_cols : nullptr;
         T* Tx_b = Tx ? (T*)Tx + (size_t)b * na * out_cols * 2 : nullptr;
-        for (int64_t row0 = 0; row0 < na; row0 += pl->rows_chunk) {
-            const int64_t rows = std::min(pl->rows_chunk, na - row0);
+        if (use_blocks) {
+            if constexpr (sizeof(T) == 4) {
+                int rc = pl->blk->run((int)b, (float*)Wx, (float*)dWx, (float*)w,
+                                      (Tx && !w) ? pl->kidx : nullptr, (const float*)pl->row_scale,
+                                      d.dt, pl->sp, stream);
+                if (rc) return rc;
+            }
+        }
+        for (int64_t row0 = 0; row0 < n_gen; row0 += pl->rows_chunk) {
+            const int64_t rows = std::min(pl->rows_chunk, n_gen - row0);
             unsigned gx = (unsigned)std::min<int64_t>((M + 255) / 256, 4096);
             hipLaunchKernelGGL((bank_multiply_kernel<T>), dim3(gx, (unsigned)rows), dim3(256), 0, stream,
-                               xh, (const T*)pl->bank, pl->band_off, pl->band_lo, (T*)pl->prod, M, row0,
-                               nplanes, h, inv_dt);
+                               xh, (const T*)pl->bank, pl->band_off, pl->band_lo, (T*)pl->prod, M,
+                               pl->gen_rows_for(use_blocks), row0, nplanes, h, inv_dt);
             SSQ_LAUNCH_CHECK();
             const int64_t ntrans = rows * nplanes;
             auto it = pl->inv.find(ntrans);
@@ -289,6 +347,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
             ea.Wx = Wx_b; ea.dWx = dWx_b; ea.w = w_b;
             ea.kidx = (Tx && !w) ? pl->kidx : nullptr;
             ea.out_cols = out_cols; ea.col0 = rpadded ? 0 : d.n1; ea.row0 = row0;
+            ea.rowlist = pl->gen_rows_for(use_blocks);
             ea.row_scale = pl->row_scale; ea.gamma = pl->sp.gamma; ea.have_ssq = pl->have_ssq;
             unsigned ex = (unsigned)std::min<int64_t>((out_cols + 255) / 256, 4096);
             hipLaunchKernelGGL((cwt_epilogue_kernel<T>), dim3(ex, (unsigned)rows), dim3(256), 0, stream,

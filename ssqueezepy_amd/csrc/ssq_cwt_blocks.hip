@@ -1,0 +1,385 @@
+// ssq_cwt_blocks.hip -- the CWT fast path: overlap-save "zoom" iFFT, LDS-resident,
+// fused with the unpad / phase-transform / bin-map epilogue.  gfx950, float32.
+//
+// Math (see ssqueezepy_amd/_blocks.py for the derivation and the host planning):
+// a row whose impulse response fits +-m samples is evaluated block by block; block b
+// of class (P, m, V) covers padded samples t0 = n1 - m + b*V ... t0 + P and is exact
+// on its central V samples. With X_b = FFT_P(block) and the wavelet's P-grid samples
+// psi[kappa] (the M-grid bank at every (M/P)-th bin), block output sample
+//   t = q*R' + c   (R' = P/L', q in [0, L'), c in [0, R'))
+// is   y[t] = sum_kappa  psi[kappa] X_b[kappa] e^{2i pi kappa c / P} / P  *  e^{2i pi kappa q / L'}
+// i.e. entry q of an L'-point inverse FFT whose input at (kappa mod L') is the band
+// entry times a per-column twiddle. The derivative row uses inputs times 1j*xi/dt.
+//
+// One workgroup (256 threads) = one (row, block, group of G adjacent columns):
+// D = L'*G = 4096 complex points, 16 per thread, laid out in LDS as [q][g] with the
+// column index fastest -- so every LDS access of the Stockham passes is
+// conflict-free for G >= 16, and the final outputs (held in registers) go to HBM as
+// runs of G adjacent time samples (128-byte segments for G = 16). Per workgroup:
+// 32 KiB of LDS, so 4-5 workgroups per CU. HBM traffic: Wx (8 B/pt) + bin map
+// (2 B/pt) written once; the inputs (band of X_b, psi, twiddles: a few KiB per
+// workgroup) come from L2. No intermediate array is ever written.
+//
+// Compiled with -ffp-contract=off because the epilogue computes bin indices with the
+// exact operation sequence of the CPU path (ssq_point_math.inl); the FFT butterflies
+// use explicit fmaf.
+#include "ssq_common.h"
+#include "ssq_blocks.h"
+
+namespace ssq {
+
+#include "ssq_point_math.inl"
+
+struct c32 { float x, y; };
+
+__device__ __forceinline__ c32 cmul(c32 a, c32 b) {
+    return {__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x)};
+}
+__device__ __forceinline__ c32 cadd(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c32 csub(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
+// multiply by +i (inverse-transform rotation)
+__device__ __forceinline__ c32 mul_i(c32 a) { return {-a.y, a.x}; }
+
+// in-place inverse DFTs: V[k] = sum_t v[t] e^{+2 pi i t k / R}
+__device__ __forceinline__ void dft2(c32& a, c32& b) { c32 t = a; a = cadd(t, b); b = csub(t, b); }
+
+__device__ __forceinline__ void dft4(c32& v0, c32& v1, c32& v2, c32& v3) {
+    c32 a = cadd(v0, v2), b = csub(v0, v2), c = cadd(v1, v3), d = mul_i(csub(v1, v3));
+    v0 = cadd(a, c); v1 = cadd(b, d); v2 = csub(a, c); v3 = csub(b, d);
+}
+
+template <int R> struct Dft;
+template <> struct Dft<4> {
+    static __device__ __forceinline__ void run(c32 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Dft<8> {
+    static __device__ __forceinline__ void run(c32 (&v)[8]) {
+        // 8 = 2 x 4, decimation in time: even/odd 4-point DFTs, twiddle W8^k
+        c32 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        dft4(e[0], e[1], e[2], e[3]);
+        dft4(o[0], o[1], o[2], o[3]);
+        const float h = 0.70710678118654752440f;
+        o[1] = {h * (o[1].x - o[1].y), h * (o[1].x + o[1].y)};     // * e^{+i pi/4}
+        o[2] = mul_i(o[2]);                                        // * e^{+i pi/2}
+        o[3] = {-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y)};    // * e^{+i 3pi/4}
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+    }
+};
+template <> struct Dft<16> {
+    static __device__ __forceinline__ void run(c32 (&v)[16]) {
+        // 16 = 4 x 4: t = t1 + 4 t2, k = 4 k1 + k2 ... columns t1, DFT over t2, twiddle, DFT over t1
+        const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // cos/sin(pi/8)
+        const float h = 0.70710678118654752440f;
+        c32 a[4][4];
+#pragma unroll
+        for (int t1 = 0; t1 < 4; ++t1) {
+            a[t1][0] = v[t1]; a[t1][1] = v[t1 + 4]; a[t1][2] = v[t1 + 8]; a[t1][3] = v[t1 + 12];
+            dft4(a[t1][0], a[t1][1], a[t1][2], a[t1][3]);      // index k2
+        }
+        // twiddle W16^{t1*k2} = e^{+2 pi i t1 k2 / 16}
+        const c32 w[10] = {{1, 0}, {c1, s1}, {h, h}, {s1, c1}, {0, 1}, {-s1, c1}, {-h, h}, {-c1, s1},
+                           {-1, 0}, {-c1, -s1}};
+#pragma unroll
+        for (int t1 = 1; t1 < 4; ++t1)
+#pragma unroll
+            for (int k2 = 1; k2 < 4; ++k2) a[t1][k2] = cmul(a[t1][k2], w[t1 * k2]);
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+            c32 b0 = a[0][k2], b1 = a[1][k2], b2 = a[2][k2], b3 = a[3][k2];
+            dft4(b0, b1, b2, b3);                               // index k1
+            v[k2] = b0; v[k2 + 4] = b1; v[k2 + 8] = b2; v[k2 + 12] = b3;
+        }
+    }
+};
+
+constexpr int D_POINTS = 4096;     // complex points per workgroup
+constexpr int NT = 256;            // threads per workgroup
+constexpr int PPT = D_POINTS / NT; // 16 points per thread
+
+// One L-point inverse FFT per column for G columns, Stockham autosort, LDS [q][g].
+// `v` holds the pass-1 inputs on entry (butterfly u = idx / G, column g = idx % G,
+// idx = tid + it*NT, input t at q = u + t*L/R1) and the final-pass outputs on exit
+// (n_hi = u + t*L/RL with RL the last radix, same idx -> (u, g) mapping).
+template <int L, int G, int R1, int R2, int R3>
+__device__ __forceinline__ void lds_ifft(c32 (&v)[PPT], c32* __restrict__ buf,
+                                         const c32* __restrict__ ftw, int tid) {
+    constexpr bool three = (R3 > 1);
+    __syncthreads();                               // LDS free (previous transform's reads done)
+    // ---- pass 1 (Ns = 1): inputs already in registers
+    {
+        constexpr int NB = PPT / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            c32 t[R1];
+#pragma unroll
+            for (int k = 0; k < R1; ++k) t[k] = v[it * R1 + k];
+            Dft<R1>::run(t);
+            int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) buf[(u * R1 + k) * G + g] = t[k];
+        }
+    }
+    __syncthreads();
+    // ---- pass 2 (Ns = R1)
+    {
+        constexpr int NB = PPT / R2, Ns = R1, STR = L / R2;
+        c32 t[NB][R2];
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R2; ++k) t[it][k] = buf[(u + k * STR) * G + g];
+        }
+        if (three) __syncthreads();                // in-place: all reads before any write
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            int idx = tid + it * NT, g = idx % G, u = idx / G;
+            int kk = u % Ns;
+            constexpr int TW = L / (Ns * R2);
+#pragma unroll
+            for (int k = 1; k < R2; ++k) t[it][k] = cmul(t[it][k], ftw[kk * k * TW]);
+            Dft<R2>::run(t[it]);
+            if (three) {
+                int j0 = (u / Ns) * Ns * R2 + kk;
+#pragma unroll
+                for (int k = 0; k < R2; ++k) buf[(j0 + k * Ns) * G + g] = t[it][k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < R2; ++k) v[it * R2 + k] = t[it][k];
+            }
+        }
+    }
+    if constexpr (three) {
+        __syncthreads();
+        constexpr int NB = PPT / R3, Ns = R1 * R2, STR = L / R3;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            int idx = tid + it * NT, g = idx % G, u = idx / G;
+            c32 t[R3];
+#pragma unroll
+            for (int k = 0; k < R3; ++k) t[k] = buf[(u + k * STR) * G + g];
+            int kk = u % Ns;                       // == u (Ns*R3 == L)
+#pragma unroll
+            for (int k = 1; k < R3; ++k) t[k] = cmul(t[k], ftw[kk * k]);
+            Dft<R3>::run(t);
+#pragma unroll
+            for (int k = 0; k < R3; ++k) v[it * R3 + k] = t[k];
+        }
+    }
+}
+
+struct BlockArgs {
+    const int4* items;                 // (row, block, c0, class)
+    const BlockRowDev* rows;
+    const BlockClassDev* classes;
+    const float* pbank;
+    const c32* ctw;                    // per-class column twiddles (pre-scaled by 1/P)
+    const c32* ftw;                    // e^{2 pi i q / L}
+    const c32* xb;                     // block spectra, all classes, all signals
+    const float* row_scale;
+    float* Wx; float* dWx; float* w; unsigned short* kidx;
+    int64_t M, N, na, n_items;
+    double h;                          // 2 pi / M
+    float inv_dt;
+    double gamma;
+    int sig;                           // signal index within the batch
+};
+
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp) {
+    __shared__ c32 buf[D_POINTS];
+    constexpr int RL = (R3 > 1) ? R3 : R2;         // last radix
+    const int tid = threadIdx.x;
+    const int4 item = A.items[blockIdx.x];
+    const int row = item.x, blk = item.y, c0 = item.z;
+    const BlockRowDev r = A.rows[row];
+    const BlockClassDev cl = A.classes[item.w];
+    const int P = (int)cl.P, Rp = P / L;
+    const int S = (int)(A.M / cl.P);
+    const c32* xb = A.xb + cl.xb_off + ((int64_t)A.sig * cl.nb + blk) * (cl.P / 2 + 1);
+    const c32* ctw = A.ctw + cl.ctw_off;
+    const float* psi = A.pbank + r.pb_off;
+
+    // ---- prologue: pass-1 inputs of both transforms, in registers
+    c32 zw[PPT], zd[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            int idx = tid + it * NT, g = idx % G, u = idx / G;
+            int col = c0 + g;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                int q = u + k * STR;
+                int off = (q - r.klo) & (L - 1);           // band element at FFT slot q
+                c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
+                if (off < r.KP) {
+                    int kap = r.klo + off;
+                    float p = psi[off];
+                    c32 X = xb[kap];
+                    c32 cw = ctw[(int)(((int64_t)kap * col) & (P - 1))];
+                    c32 bz = {p * X.x, p * X.y};
+                    z = cmul(bz, cw);
+                    float mm = (float)((double)((int64_t)kap * S) * A.h) * A.inv_dt;
+                    dz = {-(z.y * mm), z.x * mm};
+                }
+                zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
+            }
+        }
+    }
+    lds_ifft<L, G, R1, R2, R3>(zw, buf, A.ftw, tid);
+    lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
+
+    // ---- epilogue: unpad, store, phase transform, bin map
+    const int64_t omax = A.na - 1;
+    const float rs = A.row_scale ? A.row_scale[row] : 1.f;
+    constexpr int NB = PPT / RL, STR = L / RL;
+    const int64_t obase = ((int64_t)A.sig * A.na + row) * A.N;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            int64_t tb = (int64_t)(u + k * STR) * Rp + c0 + g;
+            int64_t j = (int64_t)blk * cl.V + tb - cl.m;
+            if (tb < cl.m || tb >= cl.m + cl.V || j >= A.N) continue;
+            float c = zw[it * RL + k].x, d = zw[it * RL + k].y;
+            float a = zd[it * RL + k].x, b = zd[it * RL + k].y;
+            if (A.row_scale) { c = c * rs; d = d * rs; a = a * rs; b = b * rs; }
+            int64_t q = obase + j;
+            reinterpret_cast<float2*>(A.Wx)[q] = make_float2(c, d);
+            if (A.dWx) reinterpret_cast<float2*>(A.dWx)[q] = make_float2(a, b);
+            if (A.w) {
+                float wv;
+                if (mag_of(c, d) < (double)(float)A.gamma) wv = INFINITY;
+                else wv = (float)fabs(phase_ratio(a, b, c, d));
+                A.w[q] = wv;
+            }
+            if (A.kidx) {
+                unsigned short kk = 0xFFFFu;
+                if (mag_of(c, d) > A.gamma) {
+                    int64_t kb = bin_from_w(fabs(phase_ratio(a, b, c, d)), sp, omax);
+                    kk = (unsigned short)(sp.flipud ? omax - kb : kb);
+                }
+                A.kidx[(int64_t)row * A.N + j] = kk;
+            }
+        }
+    }
+}
+
+// gather overlapping blocks of the (periodic) padded signal for one class
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const float* __restrict__ xp,
+                                                            float* __restrict__ blocks, int64_t M,
+                                                            int64_t n1, int64_t P, int64_t m,
+                                                            int64_t V, int64_t nb, int64_t total) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t p = t % P, bb = t / P, b = bb % nb, s = bb / nb;
+        int64_t src = (n1 - m + b * V + p) % M;
+        if (src < 0) src += M;
+        blocks[t] = xp[s * M + src];
+    }
+}
+
+template <int L, int G, int R1, int R2, int R3>
+static int launch_zoom(const BlockArgs& A, const SsqParams& sp, hipStream_t stream) {
+    if (A.n_items == 0) return 0;
+    hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items), dim3(NT), 0,
+                       stream, A, sp);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_,
+                      int64_t max_batch_, int64_t& bytes) {
+    M = M_; N = N_; n1 = n1_; na = na_; max_batch = max_batch_;
+    nc = d.n_classes;
+    hcls.resize(nc);
+    int64_t xb_total = 0, blk_max = 0;
+    for (int c = 0; c < nc; ++c) {
+        BlockClassDev& k = hcls[c];
+        k.P = d.classes[4 * c]; k.m = d.classes[4 * c + 1]; k.V = d.classes[4 * c + 2];
+        k.nb = d.classes[4 * c + 3];
+        k.ctw_off = d.ctw_off[c];
+        k.xb_off = xb_total;
+        xb_total += max_batch * k.nb * (k.P / 2 + 1);
+        blk_max = std::max<int64_t>(blk_max, max_batch * k.nb * k.P);
+    }
+    auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
+        SSQ_CHECK_HIP(hipMalloc(dst, nbytes ? nbytes : 1));
+        if (nbytes) SSQ_CHECK_HIP(hipMemcpy(*dst, src, nbytes, hipMemcpyHostToDevice));
+        bytes += (int64_t)nbytes;
+        return 0;
+    };
+    int rc;
+    if ((rc = up((void**)&classes, hcls.data(), sizeof(BlockClassDev) * nc))) return rc;
+    static_assert(sizeof(BlockRowDev) == 6 * sizeof(int32_t), "row table layout");
+    if ((rc = up((void**)&rows, d.rows, sizeof(BlockRowDev) * na))) return rc;
+    if ((rc = up((void**)&pbank, d.pbank, sizeof(float) * d.n_pbank))) return rc;
+    if ((rc = up((void**)&ctw, d.ctw, 8 * (size_t)d.ctw_off[nc]))) return rc;
+    if ((rc = up((void**)&ftw, d.ftw, 8 * (size_t)d.n_ftw))) return rc;
+    for (int s = 0; s < 5; ++s) {
+        n_items[s] = d.n_items[s];
+        ftw_off[s] = d.ftw_off[s];
+        if ((rc = up((void**)&items[s], d.items[s], sizeof(int4) * (size_t)d.n_items[s]))) return rc;
+    }
+    SSQ_CHECK_HIP(hipMalloc((void**)&xb, 8 * (size_t)xb_total)); bytes += 8 * xb_total;
+    SSQ_CHECK_HIP(hipMalloc((void**)&blocks, 4 * (size_t)blk_max)); bytes += 4 * blk_max;
+    ffts.resize(nc);
+    for (int c = 0; c < nc; ++c) {
+        rc = ffts[c].create(0, SSQ_F32, (size_t)hcls[c].P, (size_t)(max_batch * hcls[c].nb), 1.0);
+        if (rc) return rc;
+        bytes += (int64_t)ffts[c].work_bytes;
+    }
+    n_generic = d.n_generic;
+    return 0;
+}
+
+void BlockPlan::destroy() {
+    for (auto& f : ffts) f.destroy();
+    void* ptrs[] = {classes, rows, pbank, ctw, ftw, xb, blocks, items[0], items[1], items[2],
+                    items[3], items[4]};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+
+int BlockPlan::spectra(const float* xp, int64_t batch, hipStream_t stream) {
+    for (int c = 0; c < nc; ++c) {
+        const BlockClassDev& k = hcls[c];
+        int64_t total = max_batch * k.nb * k.P;
+        (void)batch;
+        unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(gather_blocks_kernel, dim3(g), dim3(256), 0, stream, xp, blocks, M, n1, k.P,
+                           k.m, k.V, k.nb, total);
+        SSQ_LAUNCH_CHECK();
+        int rc = ffts[c].execute(blocks, xb + k.xb_off, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int BlockPlan::run(int sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+                   const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
+    BlockArgs A;
+    A.rows = rows; A.classes = classes; A.pbank = pbank; A.ctw = (const c32*)ctw;
+    A.xb = (const c32*)xb; A.row_scale = row_scale;
+    A.Wx = Wx; A.dWx = dWx; A.w = w; A.kidx = kidx;
+    A.M = M; A.N = N; A.na = na;
+    A.h = (2.0 * 3.141592653589793) / (double)M;
+    A.inv_dt = 1.0f / (float)dt;
+    A.gamma = sp.gamma; A.sig = sig;
+    int rc = 0;
+#define ZOOM(slot, L, G, R1, R2, R3)                                                              \
+    A.items = (const int4*)items[slot]; A.n_items = n_items[slot];                                 \
+    A.ftw = (const c32*)ftw + ftw_off[slot];                                                       \
+    if ((rc = launch_zoom<L, G, R1, R2, R3>(A, sp, stream))) return rc;
+    ZOOM(0, 128, 32, 16, 8, 1)
+    ZOOM(1, 256, 16, 16, 16, 1)
+    ZOOM(2, 512, 8, 8, 8, 8)
+    ZOOM(3, 1024, 4, 16, 8, 8)
+    ZOOM(4, 2048, 2, 16, 16, 8)
+#undef ZOOM
+    return 0;
+}
+
+}  // namespace ssq

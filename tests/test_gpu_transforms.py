@@ -269,3 +269,46 @@ def test_full_size_properties(S):
     xb = np.stack([x, y])
     Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales=scales)
     assert torch.equal(Txb[0], Tx) and torch.equal(Wxb[1], Wy)
+
+
+@pytest.mark.parametrize('N,nv', [(6000, 16), (20000, 8), (40000, 4)])
+def test_block_fast_path_vs_oracle(S, orc, N, nv):
+    """The block ("overlap-save zoom") fast path -- active for float32 once the
+    padded length reaches 4096 -- against the CPU oracle of the reference's
+    full-length algorithm, and against this engine's own exact (rocFFT) path."""
+    import os
+    from ssqueezepy_amd import _cwt
+    x = two_chirps(N, seed=N)
+    wav = S.Wavelet()
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True,
+                                    astensor=False)
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+    assert plan.algo.startswith('blockzoom') and plan.block_rows > 0.8 * len(sc)
+    r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv, typing=1)
+    assert np.array_equal(sf, r['ssq_freqs']) and np.array_equal(sc, r['scales'])
+    eW, eD = relmax(Wx, r['Wx']), relmax(dWx, r['dWx'])
+    assert eW <= 1e-5 and eD <= 1e-5, (eW, eD)
+    check_Tx(orc, Tx, Wx, dWx, r, 'float32')
+    assert np.abs(Tx.sum(0) - r['Tx'].sum(0)).max() <= 1e-4 * np.abs(r['Tx'].sum(0)).max()
+    # exact path of this engine on the same input
+    os.environ['SSQ_CWT_ALGO'] = 'generic'
+    try:
+        _cwt.clear_plan_cache()
+        Tx2, Wx2, _, _, dWx2 = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True,
+                                         astensor=False)
+        plan2 = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan2.algo == 'rocfft'
+    finally:
+        del os.environ['SSQ_CWT_ALGO']
+        _cwt.clear_plan_cache()
+    assert relmax(Wx2, r['Wx']) <= 1e-5 and relmax(dWx2, r['dWx']) <= 1e-5
+    assert relmax(Wx, Wx2) <= 1e-5
+    # get_w / batched through the block path
+    out = S.ssq_cwt(x, wav, scales='log', nv=nv, get_w=True, astensor=False)
+    assert np.array_equal(out[4], orc.phase_cwt(out[1], dWx, r['gamma'], typing=0))
+    xb = np.stack([x, x[::-1].copy()])
+    Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
+    assert np.array_equal(Wxb[0], Wx) and np.array_equal(Txb[0], Tx)
+    T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
+    assert np.array_equal(Wxb[1], W1) and np.array_equal(Txb[1], T1)
