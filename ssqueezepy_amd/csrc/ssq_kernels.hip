@@ -166,6 +166,147 @@ __global__ __launch_bounds__(64) void accumulate_tile_kernel(
     }
 }
 
+// ------------------------------------- accumulate, LDS-tile form, fast variant
+// Same contract as accumulate_tile_kernel (TC = 16 columns, RL = 4 row-lanes per
+// wavefront) but built for memory-level parallelism and a short dependency chain:
+//   * lane = c*4 + rl: the four row-lanes of a column are one DPP quad, so the
+//     in-order combination of a row batch (rows i, i+1, i+2, i+3 of one column)
+//     happens in registers through quad_perm moves instead of four serialized LDS
+//     read-modify-writes: every lane reads its target cell once, folds in the terms
+//     of the lower row-lanes that hit the same cell (ascending row order -- the
+//     reference's summation order, bit for bit), and only the highest such lane
+//     writes the cell back. One LDS read + one LDS write per four rows.
+//   * the tile is stored skewed, cell (k, c) at k*16 + ((c + k) & 15), so the four
+//     lanes of a column (same c, different k) fall on different banks;
+//   * row batches are double-buffered in registers, U batches (4*U rows) deep, so
+//     ~64 rows of loads per column are in flight while the previous 64 are combined.
+template <int CTRL> __device__ __forceinline__ int dpp_quad(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(dpp_quad<CTRL>(__float_as_int(v)));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_quad(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(dpp_quad<CTRL>(hi), dpp_quad<CTRL>(lo));
+}
+
+// the additive term of one point and how it is folded into a cell, in the CPU path's
+// arithmetic: float32 data with a float64 weight vector accumulates through double
+template <typename T, bool CST64> struct Term {
+    using type = T;
+    static __device__ __forceinline__ T make(T z, const void* cst, int64_t i) { return z * ((const T*)cst)[i]; }
+    static __device__ __forceinline__ T fold(T o, T t) { return o + t; }
+};
+template <> struct Term<float, true> {
+    using type = double;
+    static __device__ __forceinline__ double make(float z, const void* cst, int64_t i) {
+        return (double)z * ((const double*)cst)[i];
+    }
+    static __device__ __forceinline__ float fold(float o, double t) { return (float)((double)o + t); }
+};
+
+template <typename T, int BINSRC, bool STFT, bool CST64, int U>
+__global__ __launch_bounds__(64) void accumulate_tile16_kernel(
+    const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
+    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na, int64_t n,
+    int32_t* __restrict__ kmap) {
+    constexpr int TC = 16, RL = 4;
+    using TM = Term<T, CST64>;
+    using term_t = typename TM::type;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* tile = reinterpret_cast<T*>(lds_raw);   // [na][16][2], skewed
+
+    const int lane = threadIdx.x;
+    const int c = lane >> 2, rl = lane & 3;
+    const int64_t j = (int64_t)blockIdx.x * TC + c;
+    const bool col_ok = j < n;
+    const int64_t omax = na - 1;
+    const int64_t base = (int64_t)blockIdx.y * na * n;
+
+    for (int64_t t = lane; t < na * TC; t += 64) { tile[2 * t] = T(0); tile[2 * t + 1] = T(0); }
+    __builtin_amdgcn_wave_barrier();
+
+    T zc[2][U], zd[2][U];
+    SideVal<T, BINSRC> sv[2][U];
+
+    auto load_batch = [&](int buf, int64_t i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * RL + rl;
+            zc[buf][u] = T(0); zd[buf][u] = T(0);
+            if (col_ok && i < na) {
+                int64_t q = base + i * n + j;
+                zc[buf][u] = Wx[2 * q];
+                zd[buf][u] = Wx[2 * q + 1];
+                sv[buf][u].load(src, q);
+            }
+        }
+    };
+    auto process_batch = [&](int buf, int64_t i0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int64_t i = i0 + u * RL + rl;
+            int k = -1;
+            if (col_ok && i < na) {
+                k = (int)point_bin<T, BINSRC, STFT>(zc[buf][u], zd[buf][u], sv[buf][u], i, Sfs, sp, omax);
+                if (kmap) kmap[base + i * n + j] = k;
+            }
+            term_t tr = term_t(0), ti = term_t(0);
+            T ore = T(0), oim = T(0);
+            T* cell = tile;
+            if (k >= 0) {
+                tr = TM::make(zc[buf][u], cst, i);
+                ti = TM::make(zd[buf][u], cst, i);
+                cell = tile + 2 * (k * TC + ((c + k) & 15));
+                ore = cell[0]; oim = cell[1];
+            }
+            // terms of the lower row-lanes (rows i-3, i-2, i-1 of this column), in
+            // ascending row order; quad_perm sources: [0,0,0,0], [0,0,0,1], [0,0,1,2]
+            int k3 = dpp_quad<0x00>(k), k2 = dpp_quad<0x40>(k), k1 = dpp_quad<0x90>(k);
+            term_t r3 = dpp_quad<0x00>(tr), i3 = dpp_quad<0x00>(ti);
+            term_t r2 = dpp_quad<0x40>(tr), i2 = dpp_quad<0x40>(ti);
+            term_t r1 = dpp_quad<0x90>(tr), i1 = dpp_quad<0x90>(ti);
+            if (rl >= 3 && k3 == k) { ore = TM::fold(ore, r3); oim = TM::fold(oim, i3); }
+            if (rl >= 2 && k2 == k) { ore = TM::fold(ore, r2); oim = TM::fold(oim, i2); }
+            if (rl >= 1 && k1 == k) { ore = TM::fold(ore, r1); oim = TM::fold(oim, i1); }
+            ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
+            // higher row-lanes hitting the same cell will write it instead:
+            // quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3]
+            int n1 = dpp_quad<0xF9>(k), n2 = dpp_quad<0xFE>(k), n3 = dpp_quad<0xFF>(k);
+            bool last = !((rl <= 2 && n1 == k) || (rl <= 1 && n2 == k) || (rl == 0 && n3 == k));
+            if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    constexpr int64_t STEP = RL * U;
+    load_batch(0, 0);
+    for (int64_t i0 = 0; i0 < na; i0 += 2 * STEP) {
+        if (i0 + STEP < na) load_batch(1, i0 + STEP);
+        process_batch(0, i0);
+        if (i0 + STEP < na) {
+            if (i0 + 2 * STEP < na) load_batch(0, i0 + 2 * STEP);
+            process_batch(1, i0 + STEP);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // write-out: lane (c', r) with c' = lane & 15 fastest so that a row of the tile
+    // goes out as one 16-column (128-byte for float32) segment
+    {
+        const int cc = lane & 15, rr = lane >> 4;
+        const int64_t jj = (int64_t)blockIdx.x * TC + cc;
+        if (jj < n) {
+            for (int64_t k = rr; k < na; k += 4) {
+                const T* cell = tile + 2 * (k * TC + ((cc + k) & 15));
+                int64_t q = base + k * n + jj;
+                Tx[2 * q] = cell[0];
+                Tx[2 * q + 1] = cell[1];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------- accumulate, global fallback
 // one thread per time column, serial over rows, Tx (pre-zeroed) updated in place.
 template <typename T, int BINSRC, bool STFT, bool CST64>
@@ -210,7 +351,20 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
         SSQ_LAUNCH_CHECK();
         return 0;
     };
-    // prefer >= 2 resident tiles per CU; shrink the tile before giving up on LDS
+    // 16-column tiles use the DPP-combined, double-buffered kernel
+    if ((size_t)na * 16 * cell <= lds_cap) {
+        constexpr int U = sizeof(T) == 4 ? 16 : 8;
+        size_t lds = (size_t)na * 16 * cell;
+        auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U>;
+        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)((n + 15) / 16), (unsigned)batch);
+        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                           (T*)Tx, cst, sp, na, n, kmap);
+        SSQ_LAUNCH_CHECK();
+        return 0;
+    }
+    // larger `na`: shrink the tile before giving up on LDS
     if ((size_t)na * 16 * cell <= lds_cap / 2) return launch_tile(std::integral_constant<int, 16>{});
     if ((size_t)na * 8 * cell <= lds_cap / 2) return launch_tile(std::integral_constant<int, 8>{});
     if ((size_t)na * 16 * cell <= lds_cap) return launch_tile(std::integral_constant<int, 16>{});
