@@ -50,7 +50,33 @@ struct SsqParams {
     int    grid;
     int    flipud;
     int    cst_f64;
+    // float32 screening of the bin map (ssq_point_math.inl: bin_screen_f32): the bin
+    // is first estimated in float32; only points whose estimate lies within `guard`
+    // bins of a rounding boundary are re-evaluated with the exact double sequence.
+    float  pf[5];     // p[] rounded to float (pf[1], pf[2], pf[3] hold reciprocals)
+    float  guard;     // >= 0.25 disables screening
 };
+
+// fill the float32 screening constants from p[]/grid
+static inline void finalize_params(SsqParams& sp) {
+    const double slack = 1.2e-5;          // abs. error budget of a float32 log2 chain
+    double g;
+    if (sp.grid == SSQ_GRID_LIN) {
+        sp.pf[0] = (float)sp.p[0]; sp.pf[1] = (float)(1.0 / sp.p[1]);
+        g = 1e-6;                         // relative part is added per point
+    } else if (sp.grid == SSQ_GRID_LOG) {
+        sp.pf[0] = (float)sp.p[0]; sp.pf[1] = (float)(1.0 / sp.p[1]);
+        g = slack / sp.p[1];
+    } else {
+        sp.pf[0] = (float)sp.p[0]; sp.pf[1] = (float)sp.p[1];
+        sp.pf[2] = (float)(1.0 / sp.p[2]); sp.pf[3] = (float)(1.0 / sp.p[3]);
+        sp.pf[4] = (float)sp.p[4];
+        double dmin = sp.p[2] < sp.p[3] ? sp.p[2] : sp.p[3];
+        g = slack / dmin;
+    }
+    if (!(g < 0.25)) g = 1.0;
+    sp.guard = (float)g;
+}
 
 // ---- launchers implemented in ssq_kernels.hip, used by the plans --------------
 // bin source for the accumulate kernel

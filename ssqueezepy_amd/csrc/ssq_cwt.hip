@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void cwt_epilogue_kernel(const T* __restrict__
                 // fused form (algos.py:859-953), threshold |Wx| > gamma
                 unsigned short kk = 0xFFFFu;
                 if (mag_of(c, d) > ea.gamma) {
-                    int64_t k = bin_from_w(fabs(phase_ratio(a, b, c, d)), sp, omax);
+                    int64_t k = bin_of_point(a, b, c, d, false, T(0), sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - k : k);
                 }
                 ea.kidx[q] = kk;
@@ -237,6 +237,7 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
     pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
     pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
+    finalize_params(pl->sp);
     size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
     if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->d.na * 8));
     SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, bytes, hipMemcpyHostToDevice));

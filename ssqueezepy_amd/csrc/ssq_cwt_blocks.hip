@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
             if (A.kidx) {
                 unsigned short kk = 0xFFFFu;
                 if (mag_of(c, d) > A.gamma) {
-                    int64_t kb = bin_from_w(fabs(phase_ratio(a, b, c, d)), sp, omax);
+                    int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - kb : kb);
                 }
                 A.kidx[(int64_t)row * A.N + j] = kk;

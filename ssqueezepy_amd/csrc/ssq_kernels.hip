@@ -76,10 +76,9 @@ __device__ __forceinline__ int64_t point_bin(T c, T d, const SideVal<T, BINSRC>&
     int64_t k;
     if constexpr (BINSRC == BIN_FROM_DWX) {
         if (!(mag_of(c, d) > sp.gamma)) return -1;
-        double r = phase_ratio(sv.a, sv.b, c, d);
-        double w;
-        if constexpr (STFT) w = fabs((double)Sfs[i] - r); else w = fabs(r);
-        k = bin_from_w(w, sp, omax);
+        T sf = T(0);
+        if constexpr (STFT) sf = Sfs[i];
+        k = bin_of_point(sv.a, sv.b, c, d, STFT, sf, sp, omax);
     } else if constexpr (BINSRC == BIN_FROM_W) {
         if (isinf(sv.w)) return -1;
         k = bin_from_stored_w(sv.w, sp, omax);
@@ -219,7 +218,14 @@ __global__ __launch_bounds__(64) void accumulate_tile16_kernel(
 
     const int lane = threadIdx.x;
     const int c = lane >> 2, rl = lane & 3;
-    const int64_t j = (int64_t)blockIdx.x * TC + c;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
+    // speed only). Adjacent 16-column tiles share 128-byte lines of the 2-byte bin map
+    // (and of any real-valued side input), so consecutive tiles are given to the same
+    // XCD, back to back, and the shared lines are served by that XCD's L2.
+    const int64_t per = gridDim.x >> 3;             // grid.x is a multiple of 8
+    const int64_t tile_id = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile_id >= (n + TC - 1) / TC) return;
+    const int64_t j = tile_id * TC + c;
     const bool col_ok = j < n;
     const int64_t omax = na - 1;
     const int64_t base = (int64_t)blockIdx.y * na * n;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(64) void accumulate_tile16_kernel(
     // goes out as one 16-column (128-byte for float32) segment
     {
         const int cc = lane & 15, rr = lane >> 4;
-        const int64_t jj = (int64_t)blockIdx.x * TC + cc;
+        const int64_t jj = tile_id * TC + cc;
         if (jj < n) {
             for (int64_t k = rr; k < na; k += 4) {
                 const T* cell = tile + 2 * (k * TC + ((cc + k) & 15));
@@ -358,7 +364,7 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
         auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U>;
         SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((unsigned)((n + 15) / 16), (unsigned)batch);
+        dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
         hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, (const T*)Wx, src, (const T*)Sfs,
                            (T*)Tx, cst, sp, na, n, kmap);
         SSQ_LAUNCH_CHECK();
@@ -591,6 +597,7 @@ static int fill_params(SsqParams& sp, int grid, const double* params, int flipud
     SSQ_REQUIRE(params, "grid params must not be null");
     for (int t = 0; t < 5; ++t) sp.p[t] = params[t];
     sp.grid = grid; sp.flipud = flipud ? 1 : 0; sp.gamma = gamma; sp.cst_f64 = cst_f64 ? 1 : 0;
+    finalize_params(sp);
     return 0;
 }
 

@@ -58,3 +58,71 @@ __device__ __forceinline__ int64_t bin_from_stored_w(double w, const SsqParams& 
     return bin_from_w(w, sp, omax);
 }
 
+
+// ---- float32 screening -------------------------------------------------------
+// Most of the cost of a point is the double division + double log2 of the exact bin
+// map. For float32 data the same bin can be obtained from a float32 estimate
+// t32 ~ (log2 w - vlmin)/dvl whenever t32 is not within `guard` bins of a rounding
+// boundary (k + 1/2): `guard` bounds the estimate's total error (v_log_f32 <= 1 ulp,
+// reciprocal-multiply division, float-rounded grid constants; finalize_params). Points
+// inside the guard band -- a fraction ~2*guard, well under 1 % -- and anything
+// non-finite take the exact path, so the result is identical to it everywhere.
+// Returns the pre-flip bin, or -2 when the point needs the exact path.
+// `werr` bounds the absolute error of the float32 `w` itself.
+__device__ __forceinline__ int bin_screen_f32(float w, float werr, const SsqParams& sp, int omax) {
+    if (!(w > 1e-30f && w < 1e30f) || sp.guard >= 0.25f) return -2;
+    float t, g = sp.guard;
+    if (sp.grid == SSQ_GRID_LIN) {
+        t = (w - sp.pf[0]) * sp.pf[1];
+        g = g + (werr + (fabsf(w) + fabsf(sp.pf[0])) * 2e-7f) * sp.pf[1];
+    } else {
+        float wl = __log2f(w);
+        float lerr = 1.4427f * werr / w;               // d(log2 w)
+        if (sp.grid == SSQ_GRID_LOG) {
+            t = (wl - sp.pf[0]) * sp.pf[1];
+            g = g + lerr * sp.pf[1];
+        } else {
+            float dv = wl - sp.pf[1];
+            if (fabsf(dv) < 2e-5f + lerr) return -2;   // on the segment boundary
+            if (dv > 0.f) {
+                t = dv * sp.pf[3];
+                g = g + lerr * sp.pf[3] + fabsf(t) * 4e-7f;
+                if (!(t < 1e9f) || !(g < 0.25f)) return -2;
+                if (fabsf((t - floorf(t)) - 0.5f) < g) return -2;
+                int k = (int)rintf(t) + (int)sp.pf[4];
+                return k > omax ? omax : (k < 0 ? 0 : k);
+            }
+            t = (wl - sp.pf[0]) * sp.pf[2];
+            g = g + lerr * sp.pf[2];
+        }
+    }
+    g = g + fabsf(t) * 4e-7f;
+    if (!(t < 1e9f) || !(t > -1e9f) || !(g < 0.25f)) return -2;
+    if (t < g) return 0;                 // exact map gives 0 for t <= 0 and for 0 < t < 1/2
+    if (fabsf((t - floorf(t)) - 0.5f) < g) return -2;
+    int k = (int)rintf(t);
+    return k > omax ? omax : k;
+}
+
+// bin (pre-flip) of a point from (dWx, Wx) = (a + ib, c + id), optional STFT row
+// frequency; float32 data goes through the screen, double data straight to the exact map
+__device__ __forceinline__ int64_t bin_of_point(float a, float b, float c, float d, bool stft,
+                                                float sfs, const SsqParams& sp, int64_t omax) {
+    float num = b * c - a * d;
+    float m2 = c * c + d * d;
+    float r32 = num * __frcp_rn(m2 * 6.2831855f);
+    float w32, werr;
+    if (stft) { w32 = fabsf(sfs - r32); werr = (fabsf(sfs) + fabsf(r32)) * 4e-7f; }
+    else { w32 = fabsf(r32); werr = w32 * 4e-7f; }
+    int k = bin_screen_f32(w32, werr, sp, (int)omax);
+    if (k != -2) return k;
+    double r = (double)num / ((double)m2 * SSQ_TWO_PI);
+    double w = stft ? fabs((double)sfs - r) : fabs(r);
+    return bin_from_w(w, sp, omax);
+}
+__device__ __forceinline__ int64_t bin_of_point(double a, double b, double c, double d, bool stft,
+                                                double sfs, const SsqParams& sp, int64_t omax) {
+    double r = phase_ratio(a, b, c, d);
+    double w = stft ? fabs(sfs - r) : fabs(r);
+    return bin_from_w(w, sp, omax);
+}

@@ -46,7 +46,7 @@ def test_phase_cwt_and_stft(A, orc, dtype):
 
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('shape', [(100, 512), (300, 1000), (513, 77), (37, 16),
-                                   (1500, 40), (6000, 24)])
+                                   (1500, 40), (6000, 24), (64, 60000)])
 def test_ssqueeze_fast_vs_oracle(A, orc, dtype, shape):
     na, n = shape
     gamma = 1e-2

@@ -13,8 +13,7 @@ def main(db, out=None):
                           "from top_kernels"))
     lines = ["%-112s %6s %13s %11s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct")]
     for name, calls, total, avg, pct in rows:
-        lines.append("%-112s %6d %13.1f %11.2f %7.2f" % (name[:112], calls, total / 1e3,
-                                                         avg / 1e3, pct))
+        lines.append("%-112s %6d %13.1f %11.2f %7.2f" % (name[:112], calls, total, avg, pct))
     txt = "\n".join(lines)
     print(txt)
     if out:
