@@ -19,6 +19,7 @@
 //   phase_kernel             w = |Im(dWx/Wx)|/2pi (CWT) or |Sfs - ...| (STFT).
 //   replace_under_abs_kernel, buffer_kernel, pad_kernel.
 #include "ssq_common.h"
+#include <cstdlib>
 #include <mutex>
 #include <string>
 
@@ -166,86 +167,115 @@ __global__ __launch_bounds__(64) void accumulate_tile_kernel(
 }
 
 // ------------------------------------- accumulate, LDS-tile form, fast variant
-// Same contract as accumulate_tile_kernel (TC = 16 columns, RL = 4 row-lanes per
-// wavefront) but built for memory-level parallelism and a short dependency chain:
-//   * lane = c*4 + rl: the four row-lanes of a column are one DPP quad, so the
-//     in-order combination of a row batch (rows i, i+1, i+2, i+3 of one column)
-//     happens in registers through quad_perm moves instead of four serialized LDS
-//     read-modify-writes: every lane reads its target cell once, folds in the terms
-//     of the lower row-lanes that hit the same cell (ascending row order -- the
-//     reference's summation order, bit for bit), and only the highest such lane
-//     writes the cell back. One LDS read + one LDS write per four rows.
-//   * the tile is stored skewed, cell (k, c) at k*16 + ((c + k) & 15), so the four
-//     lanes of a column (same c, different k) fall on different banks;
-//   * row batches are double-buffered in registers, U batches (4*U rows) deep, so
-//     ~64 rows of loads per column are in flight while the previous 64 are combined.
-template <int CTRL> __device__ __forceinline__ int dpp_quad(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+// Same contract as accumulate_tile_kernel, organised for latency hiding. The chain
+// "load -> bin -> LDS read -> fold -> LDS write" of one column is serial by
+// definition (ascending-row summation order), so the kernel (a) makes the chain short
+// and (b) keeps many independent chains per SIMD:
+//   * a wavefront owns 4 adjacent columns x 16 row-lanes (lane = 16*col + rl); the 16
+//     rows of a step are combined in registers: every lane reads its target cell once,
+//     folds in -- in ascending row order, the reference's summation order, bit for bit
+//     -- the terms of the lower row-lanes of its column that hit the same cell (DPP
+//     row_shr moves within the 16-lane row), and only the highest lane of a cell writes
+//     it back: one LDS read + one LDS write per 16 rows, 19 steps for 300 rows;
+//   * a workgroup is 4 such wavefronts (16 columns, 128-byte row segments between
+//     them); its Tx tile (na x 16 cells) lives in LDS, 4 workgroups = 16 wavefronts per
+//     CU, and the wavefronts never synchronise with each other;
+//   * row batches are double-buffered in registers (U steps = 16*U rows in flight per
+//     column), including the per-row weights.
+//   * cells are stored skewed (cell (k, c) at 4*k + ((c + k) & 3) of the wave's slab)
+//     to spread the four columns of a wave over LDS banks.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
 }
-template <int CTRL> __device__ __forceinline__ float dpp_quad(float v) {
-    return __int_as_float(dpp_quad<CTRL>(__float_as_int(v)));
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(dpp_mov<CTRL>(__float_as_int(old), __float_as_int(v)));
 }
-template <int CTRL> __device__ __forceinline__ double dpp_quad(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    return __hiloint2double(dpp_quad<CTRL>(hi), dpp_quad<CTRL>(lo));
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double old, double v) {
+    int lo = dpp_mov<CTRL>(__double2loint(old), __double2loint(v));
+    int hi = dpp_mov<CTRL>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // the additive term of one point and how it is folded into a cell, in the CPU path's
 // arithmetic: float32 data with a float64 weight vector accumulates through double
 template <typename T, bool CST64> struct Term {
     using type = T;
-    static __device__ __forceinline__ T make(T z, const void* cst, int64_t i) { return z * ((const T*)cst)[i]; }
+    using wtype = T;
+    static __device__ __forceinline__ T make(T z, T w) { return z * w; }
     static __device__ __forceinline__ T fold(T o, T t) { return o + t; }
 };
 template <> struct Term<float, true> {
     using type = double;
-    static __device__ __forceinline__ double make(float z, const void* cst, int64_t i) {
-        return (double)z * ((const double*)cst)[i];
-    }
+    using wtype = double;
+    static __device__ __forceinline__ double make(float z, double w) { return (double)z * w; }
     static __device__ __forceinline__ float fold(float o, double t) { return (float)((double)o + t); }
 };
 
-template <typename T, int BINSRC, bool STFT, bool CST64, int U>
-__global__ __launch_bounds__(64) void accumulate_tile16_kernel(
+// fold in the terms of row-lanes rl-15 .. rl-1 that target the same cell, ascending
+template <int N, typename TM, typename T, typename term_t>
+struct FoldLower {
+    static __device__ __forceinline__ void run(int k, term_t tr, term_t ti, T& ore, T& oim) {
+        int ks = dpp_mov<0x110 + N>(-1, k);                 // row_shr:N, -1 where no source
+        term_t rs = dpp_mov<0x110 + N>(term_t(0), tr), is = dpp_mov<0x110 + N>(term_t(0), ti);
+        if (ks == k) { ore = TM::fold(ore, rs); oim = TM::fold(oim, is); }
+        FoldLower<N - 1, TM, T, term_t>::run(k, tr, ti, ore, oim);
+    }
+};
+template <typename TM, typename T, typename term_t>
+struct FoldLower<0, TM, T, term_t> {
+    static __device__ __forceinline__ void run(int, term_t, term_t, T&, T&) {}
+};
+// does a higher row-lane of this column target the same cell?
+template <int N> struct AnyHigher {
+    static __device__ __forceinline__ bool run(int k) {
+        return (dpp_mov<0x100 + N>(-1, k) == k) | AnyHigher<N - 1>::run(k);   // row_shl:N
+    }
+};
+template <> struct AnyHigher<0> { static __device__ __forceinline__ bool run(int) { return false; } };
+
+template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS>
+__global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
     const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
     T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na, int64_t n,
     int32_t* __restrict__ kmap) {
-    constexpr int TC = 16, RL = 4;
+    constexpr int RL = 16, WC = 4;                 // row-lanes, columns per wavefront
     using TM = Term<T, CST64>;
     using term_t = typename TM::type;
+    using w_t = typename TM::wtype;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    T* tile = reinterpret_cast<T*>(lds_raw);   // [na][16][2], skewed
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    T* slab = reinterpret_cast<T*>(lds_raw) + (size_t)wave * na * WC * 2;   // [na][4][2] skewed
+    const int cl = lane >> 4, rl = lane & 15;
 
-    const int lane = threadIdx.x;
-    const int c = lane >> 2, rl = lane & 3;
-    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed placement, used for
-    // speed only). Adjacent 16-column tiles share 128-byte lines of the 2-byte bin map
-    // (and of any real-valued side input), so consecutive tiles are given to the same
-    // XCD, back to back, and the shared lines are served by that XCD's L2.
-    const int64_t per = gridDim.x >> 3;             // grid.x is a multiple of 8
+    // XCD-aware tile order (workgroup b runs on XCD b % 8: used for speed only):
+    // consecutive 16-column tiles share 128-byte lines of 2- and 4-byte side inputs,
+    // so they are issued to the same XCD back to back
+    const int64_t per = gridDim.x >> 3;            // grid.x is a multiple of 8
     const int64_t tile_id = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile_id >= (n + TC - 1) / TC) return;
-    const int64_t j = tile_id * TC + c;
+    if (tile_id >= (n + 15) / 16) return;
+    const int64_t j = tile_id * 16 + wave * WC + cl;
     const bool col_ok = j < n;
     const int64_t omax = na - 1;
     const int64_t base = (int64_t)blockIdx.y * na * n;
 
-    for (int64_t t = lane; t < na * TC; t += 64) { tile[2 * t] = T(0); tile[2 * t + 1] = T(0); }
+    for (int64_t t = lane; t < na * WC * 2; t += 64) slab[t] = T(0);
     __builtin_amdgcn_wave_barrier();
 
     T zc[2][U], zd[2][U];
+    w_t wt[2][U];
     SideVal<T, BINSRC> sv[2][U];
 
     auto load_batch = [&](int buf, int64_t i0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             int64_t i = i0 + u * RL + rl;
-            zc[buf][u] = T(0); zd[buf][u] = T(0);
+            zc[buf][u] = T(0); zd[buf][u] = T(0); wt[buf][u] = w_t(0);
             if (col_ok && i < na) {
                 int64_t q = base + i * n + j;
                 zc[buf][u] = Wx[2 * q];
                 zd[buf][u] = Wx[2 * q + 1];
                 sv[buf][u].load(src, q);
+                wt[buf][u] = ((const w_t*)cst)[i];
             }
         }
     };
@@ -260,27 +290,16 @@ __global__ __launch_bounds__(64) void accumulate_tile16_kernel(
             }
             term_t tr = term_t(0), ti = term_t(0);
             T ore = T(0), oim = T(0);
-            T* cell = tile;
+            T* cell = slab;
             if (k >= 0) {
-                tr = TM::make(zc[buf][u], cst, i);
-                ti = TM::make(zd[buf][u], cst, i);
-                cell = tile + 2 * (k * TC + ((c + k) & 15));
+                tr = TM::make(zc[buf][u], wt[buf][u]);
+                ti = TM::make(zd[buf][u], wt[buf][u]);
+                cell = slab + 2 * (k * WC + ((cl + k) & 3));
                 ore = cell[0]; oim = cell[1];
             }
-            // terms of the lower row-lanes (rows i-3, i-2, i-1 of this column), in
-            // ascending row order; quad_perm sources: [0,0,0,0], [0,0,0,1], [0,0,1,2]
-            int k3 = dpp_quad<0x00>(k), k2 = dpp_quad<0x40>(k), k1 = dpp_quad<0x90>(k);
-            term_t r3 = dpp_quad<0x00>(tr), i3 = dpp_quad<0x00>(ti);
-            term_t r2 = dpp_quad<0x40>(tr), i2 = dpp_quad<0x40>(ti);
-            term_t r1 = dpp_quad<0x90>(tr), i1 = dpp_quad<0x90>(ti);
-            if (rl >= 3 && k3 == k) { ore = TM::fold(ore, r3); oim = TM::fold(oim, i3); }
-            if (rl >= 2 && k2 == k) { ore = TM::fold(ore, r2); oim = TM::fold(oim, i2); }
-            if (rl >= 1 && k1 == k) { ore = TM::fold(ore, r1); oim = TM::fold(oim, i1); }
+            FoldLower<15, TM, T, term_t>::run(k, tr, ti, ore, oim);
             ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
-            // higher row-lanes hitting the same cell will write it instead:
-            // quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3]
-            int n1 = dpp_quad<0xF9>(k), n2 = dpp_quad<0xFE>(k), n3 = dpp_quad<0xFF>(k);
-            bool last = !((rl <= 2 && n1 == k) || (rl <= 1 && n2 == k) || (rl == 0 && n3 == k));
+            bool last = !AnyHigher<15>::run(k);
             if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
             __builtin_amdgcn_wave_barrier();
         }
@@ -297,14 +316,13 @@ __global__ __launch_bounds__(64) void accumulate_tile16_kernel(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    // write-out: lane (c', r) with c' = lane & 15 fastest so that a row of the tile
-    // goes out as one 16-column (128-byte for float32) segment
+    // write-out of the wave's 4 columns: lane (cc, rr), 16 rows per pass
     {
-        const int cc = lane & 15, rr = lane >> 4;
-        const int64_t jj = tile_id * TC + cc;
+        const int cc = lane & 3, rr = lane >> 2;
+        const int64_t jj = tile_id * 16 + wave * WC + cc;
         if (jj < n) {
-            for (int64_t k = rr; k < na; k += 4) {
-                const T* cell = tile + 2 * (k * TC + ((cc + k) & 15));
+            for (int64_t k = rr; k < na; k += 16) {
+                const T* cell = slab + 2 * (k * WC + ((cc + k) & 3));
                 int64_t q = base + k * n + jj;
                 Tx[2 * q] = cell[0];
                 Tx[2 * q + 1] = cell[1];
@@ -359,16 +377,25 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
     };
     // 16-column tiles use the DPP-combined, double-buffered kernel
     if ((size_t)na * 16 * cell <= lds_cap) {
-        constexpr int U = sizeof(T) == 4 ? 16 : 8;
         size_t lds = (size_t)na * 16 * cell;
-        auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U>;
-        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
-        hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, (const T*)Wx, src, (const T*)Sfs,
-                           (T*)Tx, cst, sp, na, n, kmap);
-        SSQ_LAUNCH_CHECK();
-        return 0;
+        // float32: 2 steps (32 rows) in flight fit the 128-VGPR budget of 4 waves/SIMD;
+        // SSQ_ACC_VARIANT=1 selects the deeper, 3-waves/SIMD build (tuning aid)
+        static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
+        auto go = [&](auto kern) -> int {
+            SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                               (T*)Tx, cst, sp, na, n, kmap);
+            SSQ_LAUNCH_CHECK();
+            return 0;
+        };
+        if constexpr (sizeof(T) == 4) {
+            if (variant == 1) return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 4, 3>);
+            return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 2, 4>);
+        } else {
+            return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 2, 4>);
+        }
     }
     // larger `na`: shrink the tile before giving up on LDS
     if ((size_t)na * 16 * cell <= lds_cap / 2) return launch_tile(std::integral_constant<int, 16>{});
