@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void cwt_epilogue_kernel(const T* __restrict__
                     int64_t k = bin_of_point(a, b, c, d, false, T(0), sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - k : k);
                 }
-                ea.kidx[q] = kk;
+                ea.kidx[kidx_index(i, j, na, ea.out_cols)] = kk;
             }
         }
     }
@@ -202,7 +202,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     const size_t budget = (size_t)2 << 30;
     pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
     TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
-    TRY(dev_alloc((void**)&pl->kidx, (size_t)d.na * d.n * 2, pl->bytes));
+    TRY(dev_alloc((void**)&pl->kidx, (size_t)d.na * ((d.n + 15) / 16 * 16) * 2, pl->bytes));
     {
         std::vector<int32_t> all((size_t)d.na);
         for (int64_t i = 0; i < d.na; ++i) all[i] = (int32_t)i;

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
                     int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - kb : kb);
                 }
-                A.kidx[(int64_t)row * A.N + j] = kk;
+                A.kidx[kidx_index(row, j, A.na, A.N)] = kk;
             }
         }
     }

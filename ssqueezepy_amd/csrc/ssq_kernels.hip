@@ -56,18 +56,23 @@ __device__ __forceinline__ void weighted_add(T& o_re, T& o_im, T c, T d, const v
 // of several rows are in flight together.
 template <typename T, int BINSRC> struct SideVal;
 template <typename T> struct SideVal<T, BIN_FROM_DWX> {
+    static constexpr size_t stride = 2 * sizeof(T);
     T a, b;
-    __device__ __forceinline__ void load(const void* src, int64_t q) {
+    __device__ __forceinline__ void load(const void* src, int64_t q, int64_t, int64_t, int64_t) {
         const T* dz = (const T*)src + 2 * q; a = dz[0]; b = dz[1];
     }
 };
 template <typename T> struct SideVal<T, BIN_FROM_W> {
+    static constexpr size_t stride = sizeof(T);
     T w;
-    __device__ __forceinline__ void load(const void* src, int64_t q) { w = ((const T*)src)[q]; }
+    __device__ __forceinline__ void load(const void* src, int64_t q, int64_t, int64_t, int64_t) { w = ((const T*)src)[q]; }
 };
 template <typename T> struct SideVal<T, BIN_FROM_KIDX> {
+    static constexpr size_t stride = 2;
     unsigned short k;
-    __device__ __forceinline__ void load(const void* src, int64_t q) { k = ((const unsigned short*)src)[q]; }
+    __device__ __forceinline__ void load(const void* src, int64_t q, int64_t, int64_t, int64_t) {
+        k = ((const unsigned short*)src)[q];
+    }
 };
 
 // One point of the fused kernel: returns bin (or -1) for row i
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(64) void accumulate_tile_kernel(
                 int64_t q = base + i * n + j;
                 zc[u] = Wx[2 * q];
                 zd[u] = Wx[2 * q + 1];
-                sv[u].load(src, q);
+                sv[u].load(src, q, i, j, na);
             }
         }
 #pragma unroll
@@ -211,121 +216,125 @@ template <> struct Term<float, true> {
     static __device__ __forceinline__ float fold(float o, double t) { return (float)((double)o + t); }
 };
 
-// fold in the terms of row-lanes rl-15 .. rl-1 that target the same cell, ascending
+// fold in the terms of row-lanes rl-15 .. rl-1 that target the same cell, ascending.
+// The match test of distance N yields a wave mask (one compare); from it come, for
+// free on the scalar unit, (a) the decision whether anything has to move at this
+// distance and (b) the "a higher row-lane hits my cell" mask: lane L+N matching at
+// distance N is lane L having a higher partner at distance N (row_shr never crosses a
+// 16-lane row, so mask >> N stays inside the column).
 template <int N, typename TM, typename T, typename term_t>
 struct FoldLower {
-    static __device__ __forceinline__ void run(int k, term_t tr, term_t ti, T& ore, T& oim) {
-        int ks = dpp_mov<0x110 + N>(-1, k);                 // row_shr:N, -1 where no source
-        term_t rs = dpp_mov<0x110 + N>(term_t(0), tr), is = dpp_mov<0x110 + N>(term_t(0), ti);
-        if (ks == k) { ore = TM::fold(ore, rs); oim = TM::fold(oim, is); }
-        FoldLower<N - 1, TM, T, term_t>::run(k, tr, ti, ore, oim);
+    static __device__ __forceinline__ void run(int k, term_t tr, term_t ti, T& ore, T& oim,
+                                               unsigned long long& higher) {
+        const int ks = dpp_mov<0x110 + N>(-1, k);           // row_shr:N, -1 where no source
+        const bool m = (ks == k) & (k >= 0);
+        const unsigned long long mask = __ballot(m);
+        if (mask) {                                         // wave-uniform
+            higher |= mask >> N;
+            term_t rs = dpp_mov<0x110 + N>(term_t(0), tr), is = dpp_mov<0x110 + N>(term_t(0), ti);
+            if (m) { ore = TM::fold(ore, rs); oim = TM::fold(oim, is); }
+        }
+        FoldLower<N - 1, TM, T, term_t>::run(k, tr, ti, ore, oim, higher);
     }
 };
 template <typename TM, typename T, typename term_t>
 struct FoldLower<0, TM, T, term_t> {
-    static __device__ __forceinline__ void run(int, term_t, term_t, T&, T&) {}
+    static __device__ __forceinline__ void run(int, term_t, term_t, T&, T&, unsigned long long&) {}
 };
-// does a higher row-lane of this column target the same cell?
-template <int N> struct AnyHigher {
-    static __device__ __forceinline__ bool run(int k) {
-        return (dpp_mov<0x100 + N>(-1, k) == k) | AnyHigher<N - 1>::run(k);   // row_shl:N
-    }
-};
-template <> struct AnyHigher<0> { static __device__ __forceinline__ bool run(int) { return false; } };
 
 template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS>
 __global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
     const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
-    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na, int64_t n,
+    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na64, int64_t n64,
     int32_t* __restrict__ kmap) {
     constexpr int RL = 16, WC = 4;                 // row-lanes, columns per wavefront
     using TM = Term<T, CST64>;
     using term_t = typename TM::type;
     using w_t = typename TM::wtype;
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int na = (int)na64, n = (int)n64;        // host guarantees na * n < 2^31
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    T* slab = reinterpret_cast<T*>(lds_raw) + (size_t)wave * na * WC * 2;   // [na][4][2] skewed
+    T* tile = reinterpret_cast<T*>(lds_raw);       // [4 waves][na][4][2], cells skewed
+    T* slab = tile + (size_t)wave * na * WC * 2;
     const int cl = lane >> 4, rl = lane & 15;
 
     // XCD-aware tile order (workgroup b runs on XCD b % 8: used for speed only):
-    // consecutive 16-column tiles share 128-byte lines of 2- and 4-byte side inputs,
-    // so they are issued to the same XCD back to back
-    const int64_t per = gridDim.x >> 3;            // grid.x is a multiple of 8
-    const int64_t tile_id = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile_id >= (n + 15) / 16) return;
-    const int64_t j = tile_id * 16 + wave * WC + cl;
+    // consecutive 16-column tiles are issued to the same XCD back to back
+    const int per = gridDim.x >> 3;                // grid.x is a multiple of 8
+    const int tile_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile_id * 16 >= n) return;
+    const int j = tile_id * 16 + wave * WC + cl;
     const bool col_ok = j < n;
     const int64_t omax = na - 1;
-    const int64_t base = (int64_t)blockIdx.y * na * n;
+    const size_t boff = (size_t)blockIdx.y * (size_t)na * (size_t)n;
+    const T* Wb = Wx + 2 * boff;
+    T* Tb = Tx + 2 * boff;
+    int32_t* kb = kmap ? kmap + boff : nullptr;
+    const char* sb = (const char*)src + boff * SideVal<T, BINSRC>::stride;
 
-    for (int64_t t = lane; t < na * WC * 2; t += 64) slab[t] = T(0);
+    for (int t = lane; t < na * WC * 2; t += 64) slab[t] = T(0);
     __builtin_amdgcn_wave_barrier();
 
-    T zc[2][U], zd[2][U];
-    w_t wt[2][U];
-    SideVal<T, BINSRC> sv[2][U];
-
-    auto load_batch = [&](int buf, int64_t i0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t i = i0 + u * RL + rl;
-            zc[buf][u] = T(0); zd[buf][u] = T(0); wt[buf][u] = w_t(0);
-            if (col_ok && i < na) {
-                int64_t q = base + i * n + j;
-                zc[buf][u] = Wx[2 * q];
-                zd[buf][u] = Wx[2 * q + 1];
-                sv[buf][u].load(src, q);
-                wt[buf][u] = ((const w_t*)cst)[i];
-            }
+    // rolling prefetch: slot u holds rows i0 + 16*u + rl; after a slot is consumed the
+    // row 16*U further down is requested into it, so 16*U rows per column are in flight
+    T zc[U], zd[U];
+    w_t wt[U];
+    SideVal<T, BINSRC> sv[U];
+    auto request = [&](int u, int i) {
+        zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
+        if (col_ok && i < na) {
+            unsigned q = (unsigned)i * (unsigned)n + (unsigned)j;
+            zc[u] = Wb[2 * (size_t)q];
+            zd[u] = Wb[2 * (size_t)q + 1];
+            sv[u].load(sb, q, i, j, na);
+            wt[u] = ((const w_t*)cst)[i];
         }
     };
-    auto process_batch = [&](int buf, int64_t i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(u, u * RL + rl);
+
+    for (int i0 = 0; i0 < na; i0 += RL * U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            int64_t i = i0 + u * RL + rl;
+            const int i = i0 + u * RL + rl;
             int k = -1;
             if (col_ok && i < na) {
-                k = (int)point_bin<T, BINSRC, STFT>(zc[buf][u], zd[buf][u], sv[buf][u], i, Sfs, sp, omax);
-                if (kmap) kmap[base + i * n + j] = k;
+                k = (int)point_bin<T, BINSRC, STFT>(zc[u], zd[u], sv[u], i, Sfs, sp, omax);
+                if (kb) kb[(unsigned)i * (unsigned)n + (unsigned)j] = k;
             }
             term_t tr = term_t(0), ti = term_t(0);
             T ore = T(0), oim = T(0);
             T* cell = slab;
             if (k >= 0) {
-                tr = TM::make(zc[buf][u], wt[buf][u]);
-                ti = TM::make(zd[buf][u], wt[buf][u]);
+                tr = TM::make(zc[u], wt[u]);
+                ti = TM::make(zd[u], wt[u]);
                 cell = slab + 2 * (k * WC + ((cl + k) & 3));
                 ore = cell[0]; oim = cell[1];
             }
-            FoldLower<15, TM, T, term_t>::run(k, tr, ti, ore, oim);
+            request(u, i + RL * U);                 // refill the slot
+            unsigned long long higher = 0;
+            FoldLower<15, TM, T, term_t>::run(k, tr, ti, ore, oim, higher);
             ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
-            bool last = !AnyHigher<15>::run(k);
+            const bool last = !((higher >> lane) & 1ull);
             if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
             __builtin_amdgcn_wave_barrier();
         }
-    };
-
-    constexpr int64_t STEP = RL * U;
-    load_batch(0, 0);
-    for (int64_t i0 = 0; i0 < na; i0 += 2 * STEP) {
-        if (i0 + STEP < na) load_batch(1, i0 + STEP);
-        process_batch(0, i0);
-        if (i0 + STEP < na) {
-            if (i0 + 2 * STEP < na) load_batch(0, i0 + 2 * STEP);
-            process_batch(1, i0 + STEP);
-        }
     }
-    __builtin_amdgcn_wave_barrier();
-    // write-out of the wave's 4 columns: lane (cc, rr), 16 rows per pass
+    // write-out by the whole workgroup: every row of the tile leaves as one 16-column
+    // segment (a full 128-byte line in float32), 16 rows per pass
+    __syncthreads();
     {
-        const int cc = lane & 3, rr = lane >> 2;
-        const int64_t jj = tile_id * 16 + wave * WC + cc;
+        const int cc = threadIdx.x & 15, rr = threadIdx.x >> 4;
+        const int jj = tile_id * 16 + cc;
+        const T* ws = tile + (size_t)(cc >> 2) * na * WC * 2;        // owning wave's slab
+        const int c4 = cc & 3;
         if (jj < n) {
-            for (int64_t k = rr; k < na; k += 16) {
-                const T* cell = slab + 2 * (k * WC + ((cc + k) & 3));
-                int64_t q = base + k * n + jj;
-                Tx[2 * q] = cell[0];
-                Tx[2 * q + 1] = cell[1];
+#pragma unroll 4
+            for (int k = rr; k < na; k += 16) {
+                const T* cell = ws + 2 * (k * WC + ((c4 + k) & 3));
+                size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)jj);
+                Tb[2 * q] = cell[0];
+                Tb[2 * q + 1] = cell[1];
             }
         }
     }
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256) void accumulate_global_kernel(
         int64_t q = base + i * n + j;
         T c = Wx[2 * q], d = Wx[2 * q + 1];
         SideVal<T, BINSRC> sv;
-        sv.load(src, q);
+        sv.load(src, q, i, j, na);
         int64_t k = point_bin<T, BINSRC, STFT>(c, d, sv, i, Sfs, sp, omax);
         if (kmap) kmap[q] = (int32_t)k;
         if (k < 0) continue;
@@ -378,23 +387,16 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
     // 16-column tiles use the DPP-combined, double-buffered kernel
     if ((size_t)na * 16 * cell <= lds_cap) {
         size_t lds = (size_t)na * 16 * cell;
-        dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
-        // float32: 2 steps (32 rows) in flight fit the 128-VGPR budget of 4 waves/SIMD;
-        // SSQ_ACC_VARIANT=1 selects the deeper, 3-waves/SIMD build (tuning aid)
-        static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
-        auto go = [&](auto kern) -> int {
+        if ((size_t)na * (size_t)n < ((size_t)1 << 31)) {      // 32-bit offsets inside
+            constexpr int U = sizeof(T) == 4 ? 8 : 4;
+            auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 4>;
             SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
                                (T*)Tx, cst, sp, na, n, kmap);
             SSQ_LAUNCH_CHECK();
             return 0;
-        };
-        if constexpr (sizeof(T) == 4) {
-            if (variant == 1) return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 4, 3>);
-            return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 2, 4>);
-        } else {
-            return go(accumulate_tile16_kernel<T, BINSRC, STFT, CST64, 2, 4>);
         }
     }
     // larger `na`: shrink the tile before giving up on LDS

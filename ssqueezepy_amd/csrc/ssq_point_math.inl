@@ -59,6 +59,14 @@ __device__ __forceinline__ int64_t bin_from_stored_w(double w, const SsqParams& 
 }
 
 
+// index of the internal bin map: row-major like Wx. (A tile-major layout, contiguous
+// per 16-column tile of the reassignment kernel, was measured: it turns the
+// producers' 32-byte runs into scattered writes and costs far more than it saves.)
+__device__ __forceinline__ int64_t kidx_index(int64_t i, int64_t j, int64_t na, int64_t n) {
+    (void)na;
+    return i * n + j;
+}
+
 // ---- float32 screening -------------------------------------------------------
 // Most of the cost of a point is the double division + double log2 of the exact bin
 // map. For float32 data the same bin can be obtained from a float32 estimate
