@@ -180,6 +180,7 @@ typedef struct {
     const int64_t* classes;      /* n_classes x 4: P, margin, valid, blocks/signal  */
     const int32_t* rows;         /* na x 6: class, kappa_lo, K_P, L', G, pbank_off  */
     const float*   pbank;        /* P-grid band values of the block rows            */
+    const float*   pxi;          /* xi at the same bins (same indexing as pbank)    */
     int64_t        n_pbank;
     const void*    ctw;          /* complex64 column twiddles exp(2i pi q/P)/P      */
     const int64_t* ctw_off;      /* n_classes + 1                                   */

@@ -77,6 +77,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
       classes  (nc, 4) int64: P, m (margin), V (valid), nb (blocks per signal)
       rows     (na, 6) int32: class (-1 = exact path), kappa_lo, K_P, L', G, pbank_off
       pbank    concatenated P-grid band values of the block rows (bank dtype)
+      pxi      xi (radian frequency) at the same bins, float32
       ctw      per class: exp(2i*pi*q/P)/P, q in [0, P)   (complex, concatenated)
       ctw_off  (nc + 1) int64 offsets into ctw
       ftw      per L': exp(2i*pi*q/L'), concatenated for L' = 128..2048
@@ -104,7 +105,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
     cls_of = np.full(na, -1, np.int64)
     rows = np.zeros((na, 6), np.int32)
     rows[:, 0] = -1
-    pb, pb_off = [], 0
+    pb, px, pb_off = [], [], 0
     for i in range(na):
         if lens[i] == 0:
             continue
@@ -128,6 +129,10 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
             cls_of[i] = c
             sel = (np.arange(k_lo, k_lo + KP) * S - int(lo[i])) + int(off[i])
             pb.append(vals[sel])
+            # xi at the band's bins, exactly the M-grid values the reference uses
+            # (k * 2pi/M formed in double, stored in float32: wavelets.py:473-484)
+            px.append((np.arange(k_lo, k_lo + KP) * S * (2 * np.pi / M)
+                       ).astype(np.float32))
             rows[i] = (c, k_lo, KP, Lp, G, pb_off)
             pb_off += KP
             break
@@ -179,6 +184,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
     return dict(classes=classes, rows=rows,
                 pbank=(np.concatenate(pb) if pb else np.zeros(1, vals.dtype)
                        ).astype(vals.dtype),
+                pxi=(np.concatenate(px) if px else np.zeros(1, np.float32)),
                 ctw=np.concatenate(ctw), ctw_off=np.array(ctw_off, np.int64),
                 ftw=np.concatenate(ftw), ftw_off=ftw_off, items=items,
                 generic_rows=generic_rows, margins=margins)

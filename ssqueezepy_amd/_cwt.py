@@ -103,15 +103,17 @@ class CwtPlan():
         cls[cls[:, 0] == self.M, 1] = self.n1
         rows = np.ascontiguousarray(bp['rows'], dtype=np.int32)
         pbank = np.ascontiguousarray(bp['pbank'], dtype=np.float32)
+        pxi = np.ascontiguousarray(bp['pxi'], dtype=np.float32)
         ctw = np.ascontiguousarray(bp['ctw'], dtype=np.complex64)
         ctw_off = np.ascontiguousarray(bp['ctw_off'], dtype=np.int64)
         ftw = np.ascontiguousarray(bp['ftw'], dtype=np.complex64)
         gen = np.ascontiguousarray(bp['generic_rows'], dtype=np.int32)
-        keep = [cls, rows, pbank, ctw, ctw_off, ftw, gen]
+        keep = [cls, rows, pbank, pxi, ctw, ctw_off, ftw, gen]
         d = CwtBlocksDesc()
         d.n_classes = len(cls)
         d.classes, d.rows = cls.ctypes.data, rows.ctypes.data
         d.pbank, d.n_pbank = pbank.ctypes.data, len(pbank)
+        d.pxi = pxi.ctypes.data
         d.ctw, d.ctw_off = ctw.ctypes.data, ctw_off.ctypes.data
         d.ftw, d.n_ftw = ftw.ctypes.data, len(ftw)
         for slot in range(5):

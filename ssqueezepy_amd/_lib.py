@@ -33,7 +33,7 @@ class CwtDesc(Structure):
 
 class CwtBlocksDesc(Structure):
     _fields_ = [('n_classes', c_int), ('classes', c_void_p), ('rows', c_void_p),
-                ('pbank', c_void_p), ('n_pbank', c_int64), ('ctw', c_void_p),
+                ('pbank', c_void_p), ('pxi', c_void_p), ('n_pbank', c_int64), ('ctw', c_void_p),
                 ('ctw_off', c_void_p), ('ftw', c_void_p), ('n_ftw', c_int64),
                 ('ftw_off', c_int64 * 5), ('items', c_void_p * 5),
                 ('n_items', c_int64 * 5), ('generic_rows', c_void_p),

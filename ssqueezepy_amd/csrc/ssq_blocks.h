@@ -30,6 +30,7 @@ struct BlockPlan {
     BlockClassDev* classes = nullptr;
     BlockRowDev* rows = nullptr;
     float* pbank = nullptr;
+    float* pxi = nullptr;
     void* ctw = nullptr; void* ftw = nullptr;
     void* items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t n_items[5] = {0, 0, 0, 0, 0};

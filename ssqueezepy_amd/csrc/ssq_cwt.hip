@@ -102,14 +102,14 @@ __global__ __launch_bounds__(256) void cwt_epilogue_kernel(const T* __restrict__
             if (ea.w) {
                 // two-step form: phase_cwt (algos.py:720-740), threshold |Wx| < gamma
                 T wv;
-                if (mag_of(c, d) < (double)(T)ea.gamma) wv = (T)INFINITY;
+                if (mag_lt(c, d, (T)ea.gamma)) wv = (T)INFINITY;
                 else wv = (T)fabs(phase_ratio(a, b, c, d));
                 ((T*)ea.w)[q] = wv;
             }
             if (ea.kidx) {
                 // fused form (algos.py:859-953), threshold |Wx| > gamma
                 unsigned short kk = 0xFFFFu;
-                if (mag_of(c, d) > ea.gamma) {
+                if (mag_gt(c, d, ea.gamma)) {
                     int64_t k = bin_of_point(a, b, c, d, false, T(0), sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - k : k);
                 }

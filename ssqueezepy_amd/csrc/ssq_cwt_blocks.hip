@@ -174,6 +174,7 @@ struct BlockArgs {
     const BlockRowDev* rows;
     const BlockClassDev* classes;
     const float* pbank;
+    const float* pxi;
     const c32* ctw;                    // per-class column twiddles (pre-scaled by 1/P)
     const c32* ftw;                    // e^{2 pi i q / L}
     const c32* xb;                     // block spectra, all classes, all signals
@@ -196,10 +197,10 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const BlockRowDev r = A.rows[row];
     const BlockClassDev cl = A.classes[item.w];
     const int P = (int)cl.P, Rp = P / L;
-    const int S = (int)(A.M / cl.P);
     const c32* xb = A.xb + cl.xb_off + ((int64_t)A.sig * cl.nb + blk) * (cl.P / 2 + 1);
     const c32* ctw = A.ctw + cl.ctw_off;
     const float* psi = A.pbank + r.pb_off;
+    const float* pxi = A.pxi + r.pb_off;
 
     // ---- prologue: pass-1 inputs of both transforms, in registers
     c32 zw[PPT], zd[PPT];
@@ -207,21 +208,21 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
         constexpr int NB = PPT / R1, STR = L / R1;
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
-            int idx = tid + it * NT, g = idx % G, u = idx / G;
-            int col = c0 + g;
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+            const unsigned col = (unsigned)(c0 + g);
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                int q = u + k * STR;
-                int off = (q - r.klo) & (L - 1);           // band element at FFT slot q
+                const int q = u + k * STR;
+                const int off = (q - r.klo) & (L - 1);     // band element at FFT slot q
                 c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
                 if (off < r.KP) {
-                    int kap = r.klo + off;
-                    float p = psi[off];
-                    c32 X = xb[kap];
-                    c32 cw = ctw[(int)(((int64_t)kap * col) & (P - 1))];
-                    c32 bz = {p * X.x, p * X.y};
+                    const unsigned kap = (unsigned)(r.klo + off);
+                    const float p = psi[off];
+                    const c32 X = xb[kap];
+                    const c32 cw = ctw[(kap * col) & (unsigned)(P - 1)];   // kap*col < 2^31
+                    const c32 bz = {p * X.x, p * X.y};
                     z = cmul(bz, cw);
-                    float mm = (float)((double)((int64_t)kap * S) * A.h) * A.inv_dt;
+                    const float mm = pxi[off] * A.inv_dt;   // 1j*xi/dt, xi as the reference stores it
                     dz = {-(z.y * mm), z.x * mm};
                 }
                 zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
@@ -235,34 +236,38 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const int64_t omax = A.na - 1;
     const float rs = A.row_scale ? A.row_scale[row] : 1.f;
     constexpr int NB = PPT / RL, STR = L / RL;
-    const int64_t obase = ((int64_t)A.sig * A.na + row) * A.N;
+    float2* __restrict__ Wrow = reinterpret_cast<float2*>(A.Wx) + ((int64_t)A.sig * A.na + row) * A.N;
+    float2* __restrict__ Drow = A.dWx ? reinterpret_cast<float2*>(A.dWx) + ((int64_t)A.sig * A.na + row) * A.N : nullptr;
+    float* __restrict__ wrow = A.w ? A.w + ((int64_t)A.sig * A.na + row) * A.N : nullptr;
+    unsigned short* __restrict__ krow = A.kidx ? A.kidx + kidx_index(row, 0, A.na, A.N) : nullptr;
+    const int m = (int)cl.m, hiv = (int)(cl.m + cl.V), N = (int)A.N;
+    const int jbase = blk * (int)cl.V - m + c0;
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
-        int idx = tid + it * NT, g = idx % G, u = idx / G;
+        const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
         for (int k = 0; k < RL; ++k) {
-            int64_t tb = (int64_t)(u + k * STR) * Rp + c0 + g;
-            int64_t j = (int64_t)blk * cl.V + tb - cl.m;
-            if (tb < cl.m || tb >= cl.m + cl.V || j >= A.N) continue;
+            const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
+            const int j = jbase + (u + k * STR) * Rp + g;       // output column
+            if (tb < m || tb >= hiv || j >= N) continue;
             float c = zw[it * RL + k].x, d = zw[it * RL + k].y;
             float a = zd[it * RL + k].x, b = zd[it * RL + k].y;
             if (A.row_scale) { c = c * rs; d = d * rs; a = a * rs; b = b * rs; }
-            int64_t q = obase + j;
-            reinterpret_cast<float2*>(A.Wx)[q] = make_float2(c, d);
-            if (A.dWx) reinterpret_cast<float2*>(A.dWx)[q] = make_float2(a, b);
-            if (A.w) {
+            Wrow[j] = make_float2(c, d);
+            if (Drow) Drow[j] = make_float2(a, b);
+            if (wrow) {
                 float wv;
-                if (mag_of(c, d) < (double)(float)A.gamma) wv = INFINITY;
+                if (mag_lt(c, d, (float)A.gamma)) wv = INFINITY;
                 else wv = (float)fabs(phase_ratio(a, b, c, d));
-                A.w[q] = wv;
+                wrow[j] = wv;
             }
-            if (A.kidx) {
+            if (krow) {
                 unsigned short kk = 0xFFFFu;
-                if (mag_of(c, d) > A.gamma) {
+                if (mag_gt(c, d, A.gamma)) {
                     int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, omax);
                     kk = (unsigned short)(sp.flipud ? omax - kb : kb);
                 }
-                A.kidx[kidx_index(row, j, A.na, A.N)] = kk;
+                krow[j] = kk;
             }
         }
     }
@@ -317,6 +322,7 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int6
     static_assert(sizeof(BlockRowDev) == 6 * sizeof(int32_t), "row table layout");
     if ((rc = up((void**)&rows, d.rows, sizeof(BlockRowDev) * na))) return rc;
     if ((rc = up((void**)&pbank, d.pbank, sizeof(float) * d.n_pbank))) return rc;
+    if ((rc = up((void**)&pxi, d.pxi, sizeof(float) * d.n_pbank))) return rc;
     if ((rc = up((void**)&ctw, d.ctw, 8 * (size_t)d.ctw_off[nc]))) return rc;
     if ((rc = up((void**)&ftw, d.ftw, 8 * (size_t)d.n_ftw))) return rc;
     for (int s = 0; s < 5; ++s) {
@@ -338,7 +344,7 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int6
 
 void BlockPlan::destroy() {
     for (auto& f : ffts) f.destroy();
-    void* ptrs[] = {classes, rows, pbank, ctw, ftw, xb, blocks, items[0], items[1], items[2],
+    void* ptrs[] = {classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
                     items[3], items[4]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -361,7 +367,7 @@ int BlockPlan::spectra(const float* xp, int64_t batch, hipStream_t stream) {
 int BlockPlan::run(int sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
                    const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
     BlockArgs A;
-    A.rows = rows; A.classes = classes; A.pbank = pbank; A.ctw = (const c32*)ctw;
+    A.rows = rows; A.classes = classes; A.pbank = pbank; A.pxi = pxi; A.ctw = (const c32*)ctw;
     A.xb = (const c32*)xb; A.row_scale = row_scale;
     A.Wx = Wx; A.dWx = dWx; A.w = w; A.kidx = kidx;
     A.M = M; A.N = N; A.na = na;

@@ -81,7 +81,7 @@ __device__ __forceinline__ int64_t point_bin(T c, T d, const SideVal<T, BINSRC>&
                                              const T* Sfs, const SsqParams& sp, int64_t omax) {
     int64_t k;
     if constexpr (BINSRC == BIN_FROM_DWX) {
-        if (!(mag_of(c, d) > sp.gamma)) return -1;
+        if (!mag_gt(c, d, sp.gamma)) return -1;
         T sf = T(0);
         if constexpr (STFT) sf = Sfs[i];
         k = bin_of_point(sv.a, sv.b, c, d, STFT, sf, sp, omax);
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void phase_kernel(const T* __restrict__ Wx,
          q += (int64_t)gridDim.x * blockDim.x) {
         T c = Wx[2 * q], d = Wx[2 * q + 1];
         // the two-step path thresholds with `abs(Wx) < gamma`, gamma in the data dtype
-        if (mag_of(c, d) < (double)(T)gamma) { w[q] = (T)INFINITY; continue; }
+        if (mag_lt(c, d, (T)gamma)) { w[q] = (T)INFINITY; continue; }
         double r = phase_ratio(dWx[2 * q], dWx[2 * q + 1], c, d);
         if constexpr (STFT) {
             int64_t i = (q / n) % na;

@@ -67,6 +67,26 @@ __device__ __forceinline__ int64_t kidx_index(int64_t i, int64_t j, int64_t na, 
     return i * n + j;
 }
 
+// |z| > gamma (fused form) and |z| < gamma (two-step form) for float32 data, screened in
+// float32: |z|^2 is compared with gamma^2 scaled by (1 +- 2e-6); only values inside
+// that sliver need the exact float-rounded hypot. `g2lo`/`g2hi` come from the host.
+__device__ __forceinline__ bool mag_gt(float c, float d, double gamma) {
+    float m2 = c * c + d * d;
+    float g2 = (float)(gamma * gamma);
+    if (m2 > g2 * 1.000004f) return true;
+    if (m2 < g2 * 0.999996f) return false;
+    return mag_of(c, d) > gamma;
+}
+__device__ __forceinline__ bool mag_gt(double c, double d, double gamma) { return mag_of(c, d) > gamma; }
+__device__ __forceinline__ bool mag_lt(float c, float d, float gamma) {
+    float m2 = c * c + d * d;
+    float g2 = gamma * gamma;
+    if (m2 > g2 * 1.000004f) return false;
+    if (m2 < g2 * 0.999996f && g2 > 1e-36f) return true;
+    return mag_of(c, d) < (double)gamma;
+}
+__device__ __forceinline__ bool mag_lt(double c, double d, double gamma) { return mag_of(c, d) < gamma; }
+
 // ---- float32 screening -------------------------------------------------------
 // Most of the cost of a point is the double division + double log2 of the exact bin
 // map. For float32 data the same bin can be obtained from a float32 estimate
