@@ -40,6 +40,17 @@ struct BlockPlan {
     c32_* xb = nullptr;              // block spectra of every class
     std::vector<FftPlan> ffts;
     int64_t n_generic = 0;
+    // exact (full-length, four-step) path for the rows the blocks cannot take
+    bool exact_ok = false;
+    int exA = 0, exB = 0, n_exact = 0;
+    void* twM = nullptr; void* zbuf = nullptr;
+    const float* e_bank = nullptr; const int64_t* e_off = nullptr; const int32_t* e_lo = nullptr;
+    const int32_t* e_rows = nullptr;
+    int setup_exact(const float* bank_dev, const int64_t* band_off_dev, const int32_t* band_lo_dev,
+                    const int32_t* gen_rows_dev, const std::vector<int64_t>& h_off,
+                    const std::vector<int32_t>& h_lo, const std::vector<int32_t>& h_gen, int64_t& bytes);
+    int run_exact(int sig, const void* xh_sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+                  const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
 
     int create(const ssq_cwt_blocks_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na,
                int64_t max_batch, int64_t& bytes);

@@ -263,7 +263,13 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
     pl->n_gen = bd->n_generic;
     if (pl->n_gen)
         SSQ_CHECK_HIP(hipMemcpy(pl->gen_rows, bd->generic_rows, (size_t)pl->n_gen * 4, hipMemcpyHostToDevice));
-    pl->algo = pl->n_gen ? "blockzoom+rocfft" : "blockzoom";
+    if (pl->n_gen) {
+        std::vector<int32_t> hg(bd->generic_rows, bd->generic_rows + bd->n_generic);
+        rc = b->setup_exact((const float*)pl->bank, pl->band_off, pl->band_lo, pl->gen_rows,
+                            pl->h_band_off, pl->h_band_lo, hg, pl->bytes);
+        if (rc) return rc;
+    }
+    pl->algo = !pl->n_gen ? "blockzoom" : (b->exact_ok ? "blockzoom+fourstep" : "blockzoom+rocfft");
     return 0;
 }
 
@@ -326,6 +332,14 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
                 if (rc) return rc;
             }
         }
+        if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
+            if constexpr (sizeof(T) == 4) {
+                int rc = pl->blk->run_exact((int)b, xh, (float*)Wx, (float*)dWx, (float*)w,
+                                            (Tx && !w) ? pl->kidx : nullptr, (const float*)pl->row_scale,
+                                            d.dt, pl->sp, stream);
+                if (rc) return rc;
+            }
+        } else
         for (int64_t row0 = 0; row0 < n_gen; row0 += pl->rows_chunk) {
             const int64_t rows = std::min(pl->rows_chunk, n_gen - row0);
             unsigned gx = (unsigned)std::min<int64_t>((M + 255) / 256, 4096);

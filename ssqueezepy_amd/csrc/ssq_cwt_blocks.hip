@@ -25,6 +25,7 @@
 // use explicit fmaf.
 #include "ssq_common.h"
 #include "ssq_blocks.h"
+#include <cmath>
 
 namespace ssq {
 
@@ -169,6 +170,46 @@ __device__ __forceinline__ void lds_ifft(c32 (&v)[PPT], c32* __restrict__ buf,
     }
 }
 
+// ---- per-point output of the fused epilogues (unpadded Wx [, dWx, w, bin map])
+struct EmitRow {
+    float2* W; float2* D; float* w; unsigned short* k;
+    float rs; bool scale; double gamma; int64_t omax;
+};
+__device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w, unsigned short* kidx,
+                                                 const float* row_scale, int sig, int row, int64_t na,
+                                                 int64_t N, double gamma) {
+    EmitRow e;
+    const int64_t base = ((int64_t)sig * na + row) * N;
+    e.W = reinterpret_cast<float2*>(Wx) + base;
+    e.D = dWx ? reinterpret_cast<float2*>(dWx) + base : nullptr;
+    e.w = w ? w + base : nullptr;
+    e.k = kidx ? kidx + kidx_index(row, 0, na, N) : nullptr;
+    e.scale = row_scale != nullptr;
+    e.rs = row_scale ? row_scale[row] : 1.f;
+    e.gamma = gamma; e.omax = na - 1;
+    return e;
+}
+__device__ __forceinline__ void emit_point(const EmitRow& e, int j, c32 W, c32 D, const SsqParams& sp) {
+    float c = W.x, d = W.y, a = D.x, b = D.y;
+    if (e.scale) { c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs; }
+    e.W[j] = make_float2(c, d);
+    if (e.D) e.D[j] = make_float2(a, b);
+    if (e.w) {
+        float wv;
+        if (mag_lt(c, d, (float)e.gamma)) wv = INFINITY;
+        else wv = (float)fabs(phase_ratio(a, b, c, d));
+        e.w[j] = wv;
+    }
+    if (e.k) {
+        unsigned short kk = 0xFFFFu;
+        if (mag_gt(c, d, e.gamma)) {
+            int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, e.omax);
+            kk = (unsigned short)(sp.flipud ? e.omax - kb : kb);
+        }
+        e.k[j] = kk;
+    }
+}
+
 struct BlockArgs {
     const int4* items;                 // (row, block, c0, class)
     const BlockRowDev* rows;
@@ -233,13 +274,8 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
 
     // ---- epilogue: unpad, store, phase transform, bin map
-    const int64_t omax = A.na - 1;
-    const float rs = A.row_scale ? A.row_scale[row] : 1.f;
     constexpr int NB = PPT / RL, STR = L / RL;
-    float2* __restrict__ Wrow = reinterpret_cast<float2*>(A.Wx) + ((int64_t)A.sig * A.na + row) * A.N;
-    float2* __restrict__ Drow = A.dWx ? reinterpret_cast<float2*>(A.dWx) + ((int64_t)A.sig * A.na + row) * A.N : nullptr;
-    float* __restrict__ wrow = A.w ? A.w + ((int64_t)A.sig * A.na + row) * A.N : nullptr;
-    unsigned short* __restrict__ krow = A.kidx ? A.kidx + kidx_index(row, 0, A.na, A.N) : nullptr;
+    const EmitRow er = make_emit_row(A.Wx, A.dWx, A.w, A.kidx, A.row_scale, A.sig, row, A.na, A.N, A.gamma);
     const int m = (int)cl.m, hiv = (int)(cl.m + cl.V), N = (int)A.N;
     const int jbase = blk * (int)cl.V - m + c0;
 #pragma unroll
@@ -250,25 +286,122 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
             const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
             const int j = jbase + (u + k * STR) * Rp + g;       // output column
             if (tb < m || tb >= hiv || j >= N) continue;
-            float c = zw[it * RL + k].x, d = zw[it * RL + k].y;
-            float a = zd[it * RL + k].x, b = zd[it * RL + k].y;
-            if (A.row_scale) { c = c * rs; d = d * rs; a = a * rs; b = b * rs; }
-            Wrow[j] = make_float2(c, d);
-            if (Drow) Drow[j] = make_float2(a, b);
-            if (wrow) {
-                float wv;
-                if (mag_lt(c, d, (float)A.gamma)) wv = INFINITY;
-                else wv = (float)fabs(phase_ratio(a, b, c, d));
-                wrow[j] = wv;
-            }
-            if (krow) {
-                unsigned short kk = 0xFFFFu;
-                if (mag_gt(c, d, A.gamma)) {
-                    int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, omax);
-                    kk = (unsigned short)(sp.flipud ? omax - kb : kb);
+            emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp);
+        }
+    }
+}
+
+// ======================================================================= exact rows
+// Rows whose impulse response is not compact (pass-band cut by the Nyquist frequency)
+// get the reference's full-length transform, as a four-step FFT over M = A x B with
+// one intermediate array Z in HBM (the only one on the fast path; ~4 MB per row):
+//   pass 1: for every k1 < A, B-point iFFT over k2 of X[k1 + A k2] = psih[k] xh[k]
+//           (and of the derivative spectrum), times e^{2 pi i k1 n2 / M} / M,
+//           transposed through LDS so that Z[k1][n2] is written in long runs;
+//   pass 2: for every n2 < B, A-point iFFT over k1 of Z[k1][n2] -> y[n2 + B n1],
+//           fused with the same unpad / phase / bin-map epilogue as the block kernel.
+struct ExactArgs {
+    const float* bank; const int64_t* band_off; const int32_t* band_lo;
+    const int32_t* rows; const c32* xh; c32* Z; const c32* twM; const c32* ftw;
+    const float* row_scale;
+    float* Wx; float* dWx; float* w; unsigned short* kidx;
+    int64_t M, N, na; int A, B, n1pad, sig;
+    double h; float inv_dt; double gamma;
+};
+
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
+    __shared__ c32 buf[D_POINTS + 64];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x, r = blockIdx.y, row = E.rows[r];
+    const int c0 = blockIdx.x * G;                          // first k1 of this workgroup
+    const int lo = E.band_lo[row];
+    const int64_t off0 = E.band_off[row];
+    const int len = (int)(E.band_off[row + 1] - off0);
+    const float* psi = E.bank + off0;
+    c32 zw[PPT], zd[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int kk = (c0 + g) + E.A * (u + k * STR);       // DFT bin
+                const int off = kk - lo;
+                c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
+                if (off >= 0 && off < len) {
+                    const float p = psi[off];
+                    const c32 X = E.xh[kk];
+                    z = {p * X.x, p * X.y};
+                    const float mm = (float)((double)kk * E.h) * E.inv_dt;
+                    dz = {-(z.y * mm), z.x * mm};
                 }
-                krow[j] = kk;
+                zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
             }
+        }
+    }
+    constexpr int NBL = PPT / RL, STRL = L / RL;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {
+        c32 (&v)[PPT] = tr ? zd : zw;
+        lds_ifft<L, G, R1, R2, R3>(v, buf, E.ftw, tid);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NBL; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) {
+                const int n2 = u + k * STRL;
+                const c32 tw = E.twM[(unsigned)(c0 + g) * (unsigned)n2];   // k1 * n2 < M
+                buf[g * (L + 1) + n2] = cmul(v[it * RL + k], tw);
+            }
+        }
+        __syncthreads();
+        c32* Zt = E.Z + ((int64_t)r * 2 + tr) * E.M + (int64_t)c0 * L;
+#pragma unroll
+        for (int it = 0; it < PPT; ++it) {
+            const int idx = tid + it * NT, n2 = idx % L, g = idx / L;
+            Zt[g * L + n2] = buf[g * (L + 1) + n2];
+        }
+    }
+}
+
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams sp) {
+    __shared__ c32 buf[D_POINTS];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x, r = blockIdx.y, row = E.rows[r];
+    const int c0 = blockIdx.x * G;                          // first n2 of this workgroup
+    const c32* ZW = E.Z + ((int64_t)r * 2) * E.M;
+    const c32* ZD = ZW + E.M;
+    c32 zw[PPT], zd[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int64_t q = (int64_t)(u + k * STR) * E.B + c0 + g;   // Z[k1][n2]
+                zw[it * R1 + k] = ZW[q]; zd[it * R1 + k] = ZD[q];
+            }
+        }
+    }
+    lds_ifft<L, G, R1, R2, R3>(zw, buf, E.ftw, tid);
+    lds_ifft<L, G, R1, R2, R3>(zd, buf, E.ftw, tid);
+    constexpr int NB = PPT / RL, STR = L / RL;
+    const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig, row, E.na, E.N, E.gamma);
+    const int N = (int)E.N;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int n = (c0 + g) + E.B * (u + k * STR);
+            const int j = n - E.n1pad;
+            if (j < 0 || j >= N) continue;
+            emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp);
         }
     }
 }
@@ -344,7 +477,7 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int6
 
 void BlockPlan::destroy() {
     for (auto& f : ffts) f.destroy();
-    void* ptrs[] = {classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
+    void* ptrs[] = {twM, zbuf, classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
                     items[3], items[4]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
@@ -386,6 +519,82 @@ int BlockPlan::run(int sig, float* Wx, float* dWx, float* w, unsigned short* kid
     ZOOM(4, 2048, 2, 16, 16, 8)
 #undef ZOOM
     return 0;
+}
+
+
+// ---- exact rows: host side
+static int log2i(int64_t v) { int l = 0; while ((1ll << l) < v) ++l; return l; }
+
+int BlockPlan::setup_exact(const float* bank_dev, const int64_t* band_off_dev, const int32_t* band_lo_dev,
+                           const int32_t* gen_rows_dev, const std::vector<int64_t>& h_off,
+                           const std::vector<int32_t>& h_lo, const std::vector<int32_t>& h_gen,
+                           int64_t& bytes) {
+    exact_ok = false;
+    if (h_gen.empty()) return 0;
+    const int lm = log2i(M);
+    if ((1ll << lm) != M || lm < 14 || lm > 22) return 0;
+    for (int32_t i : h_gen) {                       // analytic rows only
+        int64_t len = h_off[i + 1] - h_off[i];
+        if (h_lo[i] + len > M / 2 + 1) return 0;
+    }
+    exA = 1 << ((lm + 1) / 2); exB = (int)(M / exA);
+    e_bank = bank_dev; e_off = band_off_dev; e_lo = band_lo_dev; e_rows = gen_rows_dev;
+    n_exact = (int)h_gen.size();
+    std::vector<float> tw((size_t)2 * M);
+    for (int64_t q = 0; q < M; ++q) {
+        double ang = 2.0 * 3.14159265358979323846 * (double)q / (double)M;
+        tw[2 * q] = (float)(cos(ang) / (double)M); tw[2 * q + 1] = (float)(sin(ang) / (double)M);
+    }
+    SSQ_CHECK_HIP(hipMalloc(&twM, 8 * (size_t)M)); bytes += 8 * M;
+    SSQ_CHECK_HIP(hipMemcpy(twM, tw.data(), 8 * (size_t)M, hipMemcpyHostToDevice));
+    SSQ_CHECK_HIP(hipMalloc(&zbuf, (size_t)n_exact * 2 * M * 8)); bytes += (int64_t)n_exact * 2 * M * 8;
+    exact_ok = true;
+    return 0;
+}
+
+template <int L, int G, int R1, int R2, int R3>
+static int launch_exact1(const ExactArgs& E, int n_rows, hipStream_t stream) {
+    hipLaunchKernelGGL((exact_pass1_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.A / G), (unsigned)n_rows),
+                       dim3(NT), 0, stream, E);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+template <int L, int G, int R1, int R2, int R3>
+static int launch_exact2(const ExactArgs& E, const SsqParams& sp, int n_rows, hipStream_t stream) {
+    hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)n_rows),
+                       dim3(NT), 0, stream, E, sp);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int BlockPlan::run_exact(int sig, const void* xh_sig, float* Wx, float* dWx, float* w,
+                         unsigned short* kidx, const float* row_scale, double dt, const SsqParams& sp,
+                         hipStream_t stream) {
+    ExactArgs E;
+    E.bank = e_bank; E.band_off = e_off; E.band_lo = e_lo; E.rows = e_rows;
+    E.xh = (const c32*)xh_sig; E.Z = (c32*)zbuf; E.twM = (const c32*)twM; E.row_scale = row_scale;
+    E.Wx = Wx; E.dWx = dWx; E.w = w; E.kidx = kidx;
+    E.M = M; E.N = N; E.na = na; E.A = exA; E.B = exB; E.n1pad = (int)n1; E.sig = sig;
+    E.h = (2.0 * 3.141592653589793) / (double)M; E.inv_dt = 1.0f / (float)dt; E.gamma = sp.gamma;
+    auto slot_of = [](int L) { return L == 128 ? 0 : L == 256 ? 1 : L == 512 ? 2 : L == 1024 ? 3 : 4; };
+    int rc = 0;
+    E.ftw = (const c32*)ftw + ftw_off[slot_of(exB)];
+    switch (exB) {
+        case 128: rc = launch_exact1<128, 32, 16, 8, 1>(E, n_exact, stream); break;
+        case 256: rc = launch_exact1<256, 16, 16, 16, 1>(E, n_exact, stream); break;
+        case 512: rc = launch_exact1<512, 8, 8, 8, 8>(E, n_exact, stream); break;
+        case 1024: rc = launch_exact1<1024, 4, 16, 8, 8>(E, n_exact, stream); break;
+        default: rc = launch_exact1<2048, 2, 16, 16, 8>(E, n_exact, stream); break;
+    }
+    if (rc) return rc;
+    E.ftw = (const c32*)ftw + ftw_off[slot_of(exA)];
+    switch (exA) {
+        case 128: return launch_exact2<128, 32, 16, 8, 1>(E, sp, n_exact, stream);
+        case 256: return launch_exact2<256, 16, 16, 16, 1>(E, sp, n_exact, stream);
+        case 512: return launch_exact2<512, 8, 8, 8, 8>(E, sp, n_exact, stream);
+        case 1024: return launch_exact2<1024, 4, 16, 8, 8>(E, sp, n_exact, stream);
+        default: return launch_exact2<2048, 2, 16, 16, 8>(E, sp, n_exact, stream);
+    }
 }
 
 }  // namespace ssq
