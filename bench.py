@@ -123,8 +123,11 @@ def main():
     N, na, B = args.n, args.na, args.batch
     wav = S.Wavelet()
     scales = S.process_scales('log', N, wav, nv=32)[:na]
-    # every rank owns its own signals (seeds disjoint across ranks)
-    x_host = np.stack([two_chirps(N, seed=rank * B + b) for b in range(B)])
+    # weak scaling: the job's batch is B*world signals; rank r owns a contiguous block
+    # (ssqueezepy_amd/sharding.py) -- its own signals, its own plan, no exchange
+    from ssqueezepy_amd.sharding import shard_bounds, gather_summaries, signal_summary
+    lo, hi = shard_bounds(B * world, world, rank)
+    x_host = np.stack([two_chirps(N, seed=s) for s in range(lo, hi)])
     x = torch.as_tensor(x_host, dtype=torch.float32, device=dev)
 
     def step():
@@ -143,10 +146,9 @@ def main():
         out = step()
     ev1.record()
     if world > 1:
-        # the single collective of the job: per-signal checksums of Tx to every rank
-        chk = out[0].abs().sum(dim=(1, 2)).float()
-        gathered = [torch.empty_like(chk) for _ in range(world)]
-        dist.all_gather(gathered, chk)
+        # the single collective of the job: per-signal summaries to every rank (RCCL)
+        table = gather_summaries(signal_summary(out[0], out[1]), B * world)
+        assert table.shape[0] == B * world
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,6 +168,15 @@ def main():
         achieved = bytes_alg / t_transform / 1e9
         from ssqueezepy_amd._cwt import _PLAN_CACHE
         plan = next(iter(_PLAN_CACHE.values()))
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.isfile(tfile) and (N, na) == (160000, 300):
+            # HBM bytes per transform from rocprofv3 PMC passes of this same command
+            # (tools/pmc_collect.sh + tools/pmc_traffic.py; FETCH_SIZE doubled as the
+            # gfx950 guide prescribes, calibrated on the reassignment kernel's known
+            # read volume). Measured offline, not in this run.
+            with open(tfile) as fh:
+                traffic = json.load(fh).get('bytes_per_transform')
         line = {
             "metric": "ssq_cwt transforms/sec (N=160k, 300 scales, f32)",
             "value": value, "unit": "transforms/s", "n_gpus": world,
@@ -181,7 +192,7 @@ def main():
                        "algo": plan.algo},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic,
                          "scope": "whole transform (all kernels), HIP-event timed",
                          "bytes_alg_per_transform": bytes_alg,
                          "us_per_transform": t_transform * 1e6},

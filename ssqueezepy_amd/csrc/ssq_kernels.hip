@@ -340,6 +340,113 @@ __global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
     }
 }
 
+// ------------------------------------------- accumulate, LDS-tile form, quad variant
+// Same tile and same exactness contract as accumulate_tile16_kernel, organised the
+// other way round: one wavefront owns the whole 16-column tile, lane = 4*col + rl, so
+// the four rows of a step that belong to one column are a DPP quad. A step therefore
+// needs only 3 pair tests (quad_perm moves) instead of 15, loads and stores are full
+// 128-byte row segments (4 rows per instruction), and the per-step instruction count
+// drops ~2.5x. The price is one wavefront per SIMD (4 tiles per CU), so memory latency
+// is covered by a deep rolling prefetch (4*U rows in flight per column) rather than by
+// other waves.
+template <typename T, int BINSRC, bool STFT, bool CST64, int U>
+__global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
+    const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
+    T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na64, int64_t n64,
+    int32_t* __restrict__ kmap) {
+    constexpr int RL = 4, TC = 16;
+    using TM = Term<T, CST64>;
+    using term_t = typename TM::type;
+    using w_t = typename TM::wtype;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T* tile = reinterpret_cast<T*>(lds_raw);       // [na][16][2], cells skewed
+    const int na = (int)na64, n = (int)n64;        // host guarantees na * n < 2^31
+    const int lane = threadIdx.x;
+    const int c = lane >> 2, rl = lane & 3;
+    const int per = gridDim.x >> 3;                // grid.x is a multiple of 8
+    const int tile_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile_id * TC >= n) return;
+    const int j = tile_id * TC + c;
+    const bool col_ok = j < n;
+    const int64_t omax = na - 1;
+    const size_t boff = (size_t)blockIdx.y * (size_t)na * (size_t)n;
+    const T* Wb = Wx + 2 * boff;
+    T* Tb = Tx + 2 * boff;
+    int32_t* kb = kmap ? kmap + boff : nullptr;
+    const char* sb = (const char*)src + boff * SideVal<T, BINSRC>::stride;
+
+    for (int t = lane; t < na * TC; t += 64) { tile[2 * t] = T(0); tile[2 * t + 1] = T(0); }
+    __builtin_amdgcn_wave_barrier();
+
+    T zc[U], zd[U];
+    w_t wt[U];
+    SideVal<T, BINSRC> sv[U];
+    auto request = [&](int u, int i) {
+        zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
+        if (col_ok && i < na) {
+            unsigned q = (unsigned)i * (unsigned)n + (unsigned)j;
+            zc[u] = Wb[2 * (size_t)q];
+            zd[u] = Wb[2 * (size_t)q + 1];
+            sv[u].load(sb, q, i, j, na);
+            wt[u] = ((const w_t*)cst)[i];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(u, u * RL + rl);
+
+    for (int i0 = 0; i0 < na; i0 += RL * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * RL + rl;
+            int k = -1;
+            if (col_ok && i < na) {
+                k = (int)point_bin<T, BINSRC, STFT>(zc[u], zd[u], sv[u], i, Sfs, sp, omax);
+                if (kb) kb[(unsigned)i * (unsigned)n + (unsigned)j] = k;
+            }
+            term_t tr = term_t(0), ti = term_t(0);
+            T ore = T(0), oim = T(0);
+            T* cell = tile;
+            if (k >= 0) {
+                tr = TM::make(zc[u], wt[u]);
+                ti = TM::make(zd[u], wt[u]);
+                cell = tile + 2 * (k * TC + ((c + k) & 15));
+                ore = cell[0]; oim = cell[1];
+            }
+            request(u, i + RL * U);                 // refill the slot
+            // lower rows of this column, ascending: quad lanes rl-3, rl-2, rl-1
+            // (quad_perm [0,0,0,0], [0,0,0,1], [0,0,1,2]); -1 never matches a valid bin
+            const int k3 = dpp_mov<0x00>(-1, k), k2 = dpp_mov<0x40>(-1, k), k1 = dpp_mov<0x90>(-1, k);
+            const term_t r3 = dpp_mov<0x00>(term_t(0), tr), i3 = dpp_mov<0x00>(term_t(0), ti);
+            const term_t r2 = dpp_mov<0x40>(term_t(0), tr), i2 = dpp_mov<0x40>(term_t(0), ti);
+            const term_t r1 = dpp_mov<0x90>(term_t(0), tr), i1 = dpp_mov<0x90>(term_t(0), ti);
+            if (rl >= 3 && k3 == k) { ore = TM::fold(ore, r3); oim = TM::fold(oim, i3); }
+            if (rl >= 2 && k2 == k) { ore = TM::fold(ore, r2); oim = TM::fold(oim, i2); }
+            if (rl >= 1 && k1 == k) { ore = TM::fold(ore, r1); oim = TM::fold(oim, i1); }
+            ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
+            // a higher row of the quad hitting the same cell writes it instead
+            // (quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3])
+            const int h1 = dpp_mov<0xF9>(-1, k), h2 = dpp_mov<0xFE>(-1, k), h3 = dpp_mov<0xFF>(-1, k);
+            const bool last = !((rl <= 2 && h1 == k) || (rl <= 1 && h2 == k) || (rl == 0 && h3 == k));
+            if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int cc = lane & 15, rr = lane >> 4;
+        const int jj = tile_id * TC + cc;
+        if (jj < n) {
+#pragma unroll 4
+            for (int k = rr; k < na; k += 4) {
+                const T* cell = tile + 2 * (k * TC + ((cc + k) & 15));
+                size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)jj);
+                Tb[2 * q] = cell[0];
+                Tb[2 * q + 1] = cell[1];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------- accumulate, global fallback
 // one thread per time column, serial over rows, Tx (pre-zeroed) updated in place.
 template <typename T, int BINSRC, bool STFT, bool CST64>
@@ -388,13 +495,23 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
     if ((size_t)na * 16 * cell <= lds_cap) {
         size_t lds = (size_t)na * 16 * cell;
         if ((size_t)na * (size_t)n < ((size_t)1 << 31)) {      // 32-bit offsets inside
-            constexpr int U = sizeof(T) == 4 ? 8 : 4;
-            auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 4>;
-            SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
-                               (T*)Tx, cst, sp, na, n, kmap);
+            static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
+            if (variant != 2) {        // default: 16 row-lanes x 4 waves per tile
+                constexpr int U = sizeof(T) == 4 ? 8 : 4;
+                auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 4>;
+                SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                                   (T*)Tx, cst, sp, na, n, kmap);
+            } else {                   // SSQ_ACC_VARIANT=2: one wave per tile, quads (tuning aid)
+                constexpr int U = sizeof(T) == 4 ? 16 : 8;
+                auto kern = accumulate_quad_kernel<T, BINSRC, STFT, CST64, U>;
+                SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, grid, dim3(64), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                                   (T*)Tx, cst, sp, na, n, kmap);
+            }
             SSQ_LAUNCH_CHECK();
             return 0;
         }

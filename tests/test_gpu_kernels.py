@@ -188,3 +188,32 @@ def test_error_paths(A):
     lib = _lib.load()
     rc = lib.ssq_pad_signal(7, None, None, 1, 4, 1, 1, 1, None)
     assert rc != 0 and b'dtype' in lib.ssq_last_error()
+
+
+def test_quad_variant_of_accumulate_is_bit_identical(orc):
+    """SSQ_ACC_VARIANT=2 selects the one-wave-per-tile (DPP quad) build of the
+    reassignment kernel; it must produce the same bits. Run in a subprocess because the
+    variant is latched at first launch."""
+    import subprocess, sys, os
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import kernel_inputs, make_ssq_freqs
+from oracle import oracle as orc
+from ssqueezepy_amd import algos as A
+from ssqueezepy_amd.ssqueezing import ssq_grid_params
+for dtype in ('float32', 'float64'):
+    Wx, dWx, *_ = kernel_inputs(dtype, 300, 1000)
+    for st in ('log-piecewise', 'log', 'linear'):
+        sf = make_ssq_freqs(300, st)
+        _, p = ssq_grid_params(sf, st.startswith('log'))
+        out = A.ssqueeze_fast(Wx, dWx, sf, 0.02, st.startswith('log'), True, 1e-2).cpu().numpy()
+        ref = orc.ssqueeze(Wx, dWx, st, p, 0.02, 1e-2, True, typing=0)
+        assert np.array_equal(out, ref), (dtype, st)
+print("QUAD_OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSQ_ACC_VARIANT='2')
+    res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert 'QUAD_OK' in res.stdout, res.stdout + res.stderr

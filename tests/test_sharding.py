@@ -1,0 +1,79 @@
+# -*- coding: utf-8 -*-
+"""The N > 1 path (ssqueezepy_amd/sharding.py) with world_size 2 on CPU ('gloo'):
+partition of the batch, independence of the shards, and the one collective. The
+transform itself is stood in for by the CPU oracle -- what is under test is the
+sharding logic the GPU job uses unchanged with the 'nccl' (RCCL) backend. CPU-only."""
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ssqueezepy_amd.sharding import shard_bounds, shard_signals
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 512, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _worker(rank, world, port, q):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from conftest import two_chirps
+    from pipeline import oracle_ssq_cwt
+    from oracle import oracle as orc
+    from ssqueezepy_amd.sharding import gather_summaries, signal_summary
+    B, N = 5, 256
+    x = np.stack([two_chirps(N, seed=s) for s in range(B)])
+    mine = shard_signals(x, world, rank)
+    Tx, Wx = [], []
+    for xi in mine:
+        r = oracle_ssq_cwt(orc, xi, 'float32', scales='log', nv=8)
+        Tx.append(r['Tx']); Wx.append(r['Wx'])
+    na = oracle_ssq_cwt(orc, x[0], 'float32', scales='log', nv=8)['Tx'].shape[0]
+    Tx = torch.as_tensor(np.stack(Tx)) if Tx else torch.zeros((0, na, N), dtype=torch.complex64)
+    Wx = torch.as_tensor(np.stack(Wx)) if Wx else torch.zeros((0, na, N), dtype=torch.complex64)
+    table = gather_summaries(signal_summary(Tx, Wx), B)
+    q.put((rank, table.numpy(), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_batch_matches_single_process():
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert [g[2] for g in got] == [3, 2]                      # 5 signals over 2 ranks
+    assert np.array_equal(got[0][1], got[1][1])               # every rank has the table
+    # single-process reference
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__)))
+    from conftest import two_chirps
+    from pipeline import oracle_ssq_cwt
+    from oracle import oracle as orc
+    ref = []
+    for s in range(5):
+        r = oracle_ssq_cwt(orc, two_chirps(256, seed=s), 'float32', scales='log', nv=8)
+        ref.append([np.abs(r['Tx']).sum(dtype=np.float64), np.abs(r['Wx']).sum(dtype=np.float64)])
+    assert np.allclose(got[0][1], np.array(ref), rtol=1e-6)
