@@ -312,3 +312,55 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv):
     assert np.array_equal(Wxb[0], Wx) and np.array_equal(Txb[0], Tx)
     T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
     assert np.array_equal(Wxb[1], W1) and np.array_equal(Txb[1], T1)
+
+
+def test_ssqueeze_squeezing_modes_and_stft_config3(S, orc):
+    """`ssqueeze` with squeezing='lebesgue' / 'abs' (ssqueezing.py:197-202), and
+    BASELINE config 3 (ssq_stft N=160 000, n_fft=1024, hop=256) at full size against the
+    oracle reassignment of the device's own Sx, dSx."""
+    import torch
+    x = two_chirps(1024, seed=2)
+    wav = S.Wavelet()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=8, get_dWx=True)
+    r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=8)
+    Wn, dWn = _np(Wx), _np(dWx)
+    for mode in ('lebesgue', 'abs'):
+        T2, _ = S.ssqueeze(Wx, None, 'log', sc, wavelet=wav, maprange='peak',
+                           gamma=r['gamma'], flipud=True, dWx=dWx, squeezing=mode)
+        # |Wx| as the device forms it (torch.abs and hypotf may differ in the last bit)
+        Wm = ((np.ones_like(Wn) / len(Wn)) if mode == 'lebesgue' else
+              _np(torch.abs(Wx)).astype(Wn.dtype))
+        ref = orc.ssqueeze(Wm, dWn, 'log', r['params'], r['const'], r['gamma'], True, typing=NUMBA)
+        assert np.array_equal(_np(T2), ref), mode
+    # config 3
+    N = 160000
+    x = two_chirps(N, seed=3)
+    Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=1024, hop_len=256, dtype='float32',
+                                      get_dWx=True, astensor=False)
+    assert Sx.shape == (513, 625)
+    ro = oracle_ssq_stft(orc, x, 'float32', n_fft=1024, hop_len=256)
+    assert relmax(Sx, ro['Sx']) <= 1e-5 and relmax(dSx, ro['dSx']) <= 1e-5
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    _, p = ssq_grid_params(Sfs, False)
+    ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], ro['gamma'], False, Sfs=Sfs,
+                       typing=NUMBA)
+    assert np.array_equal(Tx, ref)
+
+
+def test_float64_long_signal_properties(S):
+    """BASELINE config 5 shape (float64, long signal) at reduced length: float64
+    column-sum identity to 1e-12 and linearity."""
+    import torch
+    N, na = 131072, 128
+    wav = S.Wavelet(('gmw', {'dtype': 'float64'}))
+    scales = S.process_scales('log', N, wav, nv=16)[:na]
+    x = two_chirps(N, seed=11)
+    Tx, Wx, sf, sc = S.ssq_cwt(x, wav, scales=scales)
+    assert Tx.dtype == torch.complex128 and sc.dtype == np.float64
+    const = np.log(2) / 16
+    lhs, rhs = Tx.sum(0), (Wx * const).sum(0)
+    assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() < 1e-12
+    y = two_chirps(N, seed=12)
+    Wy, _ = S.cwt(y, wav, scales=scales)
+    Wxy, _ = S.cwt(x - 2 * y, wav, scales=scales)
+    assert ((Wxy - (Wx - 2 * Wy)).abs().max() / Wxy.abs().max()).item() < 1e-13

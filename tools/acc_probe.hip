@@ -3,16 +3,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
-template <int MODE, int U>
-__global__ __launch_bounds__(256, 4) void acc(const float2* __restrict__ W, const unsigned short* __restrict__ K,
+template <int MODE, int U, int TCOLS>
+__global__ __launch_bounds__(TCOLS * 16) void acc(const float2* __restrict__ W, const unsigned short* __restrict__ K,
                                               const float* __restrict__ cst, float2* __restrict__ Tx, int na, int n) {
     extern __shared__ float2 tile[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, cl = lane >> 4, rl = lane & 15;
     float2* slab = tile + wave * na * 4;
     const int per = gridDim.x >> 3;
     const int tile_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile_id * 16 >= n) return;
-    const int j = tile_id * 16 + wave * 4 + cl;
+    if (tile_id * TCOLS >= n) return;
+    const int j = tile_id * TCOLS + wave * 4 + cl;
     if (MODE >= 1) { for (int t = lane; t < na * 4; t += 64) slab[t] = make_float2(0.f, 0.f); }
     float2 z[U]; unsigned short kk[U]; float wt[U];
     auto req = [&](int u, int i) {
@@ -49,20 +49,22 @@ __global__ __launch_bounds__(256, 4) void acc(const float2* __restrict__ W, cons
     }
     if (MODE == 0) { if (acc.x == 12345.f) Tx[j] = acc; return; }
     if (MODE >= 2) {
-        const int cc = lane & 3, rr = lane >> 2, jj = tile_id * 16 + wave * 4 + cc;
-        for (int k = rr; k < na; k += 16) Tx[(unsigned)k * n + jj] = slab[k * 4 + ((cc + k) & 3)];
+        __syncthreads();
+        const int cc = threadIdx.x % TCOLS, rr = threadIdx.x / TCOLS, jj = tile_id * TCOLS + cc;
+        const float2* ws = tile + (cc >> 2) * na * 4;
+        for (int k = rr; k < na; k += 16) Tx[(unsigned)k * n + jj] = ws[k * 4 + (((cc & 3) + k) & 3)];
     }
 }
-template <int MODE, int U> void run(const float2* W, const unsigned short* K, const float* c, float2* T, int na, int n) {
+template <int MODE, int U, int TCOLS> void run(const float2* W, const unsigned short* K, const float* c, float2* T, int na, int n) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    int grid = ((n / 16 + 7) / 8) * 8; size_t lds = (size_t)na * 16 * 8;
-    hipFuncSetAttribute((const void*)acc<MODE, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((acc<MODE, U>), dim3(grid), dim3(256), lds, 0, W, K, c, T, na, n);
+    int grid = ((n / TCOLS + 7) / 8) * 8; size_t lds = (size_t)na * TCOLS * 8;
+    hipFuncSetAttribute((const void*)acc<MODE, U, TCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int r = 0; r < 2; ++r) hipLaunchKernelGGL((acc<MODE, U, TCOLS>), dim3(grid), dim3(TCOLS * 16), lds, 0, W, K, c, T, na, n);
     hipEventRecord(e0);
-    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((acc<MODE, U>), dim3(grid), dim3(256), lds, 0, W, K, c, T, na, n);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((acc<MODE, U, TCOLS>), dim3(grid), dim3(TCOLS * 16), lds, 0, W, K, c, T, na, n);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("MODE=%d U=%d  %8.1f us\n", MODE, U, ms * 100);
+    printf("MODE=%d U=%d TC=%d  %8.1f us\n", MODE, U, TCOLS, ms * 100);
 }
 int main() {
     const int na = 300, n = 160000;
@@ -72,11 +74,14 @@ int main() {
     unsigned short* hk = (unsigned short*)malloc((size_t)na * n * 2);
     srand(1); for (size_t q = 0; q < (size_t)na * n; ++q) { int i = q / n; int k = i + (rand() % 33) - 16; hk[q] = k < 0 ? 0 : (k >= na ? na - 1 : k); }
     hipMemcpy(K, hk, (size_t)na * n * 2, hipMemcpyHostToDevice);
-    run<0, 4>(W, K, c, T, na, n);   // loads only
-    run<0, 8>(W, K, c, T, na, n);
-    run<1, 8>(W, K, c, T, na, n);   // + LDS init + RMW
-    run<2, 8>(W, K, c, T, na, n);   // + write-out
-    run<3, 8>(W, K, c, T, na, n);   // + all-pairs fold
-    run<3, 4>(W, K, c, T, na, n);
+    run<0, 8, 16>(W, K, c, T, na, n);
+    run<2, 8, 16>(W, K, c, T, na, n);
+    run<3, 8, 16>(W, K, c, T, na, n);
+    run<0, 8, 32>(W, K, c, T, na, n);
+    run<2, 8, 32>(W, K, c, T, na, n);
+    run<3, 8, 32>(W, K, c, T, na, n);
+    run<0, 8, 64>(W, K, c, T, na, n);
+    run<2, 8, 64>(W, K, c, T, na, n);
+    run<3, 8, 64>(W, K, c, T, na, n);
     return 0;
 }
