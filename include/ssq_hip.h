@@ -182,7 +182,7 @@ typedef struct {
     const float*   pbank;        /* P-grid band values of the block rows            */
     const float*   pxi;          /* xi at the same bins (same indexing as pbank)    */
     int64_t        n_pbank;
-    const void*    ctw;          /* complex64 column twiddles exp(2i pi q/P)/P      */
+    const void*    ctw;          /* complex64 column twiddles exp(2i pi q/P)        */
     const int64_t* ctw_off;      /* n_classes + 1                                   */
     const void*    ftw;          /* complex64 FFT twiddles exp(2i pi q/L')          */
     int64_t        n_ftw;

@@ -78,7 +78,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
       rows     (na, 6) int32: class (-1 = exact path), kappa_lo, K_P, L', G, pbank_off
       pbank    concatenated P-grid band values of the block rows (bank dtype)
       pxi      xi (radian frequency) at the same bins, float32
-      ctw      per class: exp(2i*pi*q/P)/P, q in [0, P)   (complex, concatenated)
+      ctw      per class: exp(2i*pi*q/P), q in [0, P)   (complex, concatenated)
       ctw_off  (nc + 1) int64 offsets into ctw
       ftw      per L': exp(2i*pi*q/L'), concatenated for L' = 128..2048
       items    dict L' -> (n_items, 4) int32: row, block, c0, class
@@ -151,7 +151,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
             nb = -(-N // V)
         classes[remap[c]] = (P, m, V, nb)
         q = np.arange(P)
-        w = np.exp(2j * np.pi * q / P) / P
+        w = np.exp(2j * np.pi * q / P)
         ctw.append(w.astype(np.complex64))
         ctw_off.append(ctw_off[-1] + P)
     for i in range(na):

@@ -216,7 +216,7 @@ struct BlockArgs {
     const BlockClassDev* classes;
     const float* pbank;
     const float* pxi;
-    const c32* ctw;                    // per-class column twiddles (pre-scaled by 1/P)
+    const c32* ctw;                    // per-class column twiddles e^{2 pi i q / P}
     const c32* ftw;                    // e^{2 pi i q / L}
     const c32* xb;                     // block spectra, all classes, all signals
     const float* row_scale;
@@ -243,7 +243,29 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const float* psi = A.pbank + r.pb_off;
     const float* pxi = A.pxi + r.pb_off;
 
-    // ---- prologue: pass-1 inputs of both transforms, in registers
+    // ---- prologue: pass-1 inputs of both transforms, in registers.
+    // Input slot q of column c holds  psi[kap] X[kap] e^{2 pi i kap c / P} / P  with
+    // kap = klo + ((q - klo) mod L). A thread's R1 slots are q = u + t*STR, so its bins
+    // advance by STR (minus L on wrap-around): the column twiddle is one table gather
+    // for t = 0 times a power of s_c = e^{2 pi i STR c / P} (and the wrap factor
+    // e^{-2 pi i L c / P}), and those powers -- R1 x G values per workgroup -- are staged
+    // in LDS once. 8x fewer scattered table gathers than one per point (the gathers,
+    // not the arithmetic, bounded this stage).
+    __shared__ c32 spow[R1 * G];
+    __shared__ c32 wrapf[G];
+    {
+        constexpr int STR = L / R1;
+        for (int i = tid; i < R1 * G; i += NT) {
+            const unsigned t = (unsigned)(i / G), col = (unsigned)(c0 + i % G);
+            spow[i] = ctw[(t * (unsigned)STR * col) & (unsigned)(P - 1)];
+        }
+        if (tid < G) {
+            const unsigned col = (unsigned)(c0 + tid);
+            wrapf[tid] = ctw[(0u - (unsigned)L * col) & (unsigned)(P - 1)];
+        }
+    }
+    __syncthreads();
+    const float invP = 1.0f / (float)P;             // exact (P is a power of two)
     c32 zw[PPT], zd[PPT];
     {
         constexpr int NB = PPT / R1, STR = L / R1;
@@ -251,16 +273,19 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
         for (int it = 0; it < NB; ++it) {
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
             const unsigned col = (unsigned)(c0 + g);
+            const int off0 = (u - r.klo) & (L - 1);
+            const c32 cw0 = ctw[((unsigned)(r.klo + off0) * col) & (unsigned)(P - 1)];
+            const c32 wf = wrapf[g];
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                const int q = u + k * STR;
-                const int off = (q - r.klo) & (L - 1);     // band element at FFT slot q
+                const int offu = off0 + k * STR;            // < 2L
+                const int off = offu & (L - 1);             // band element at FFT slot q
                 c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
                 if (off < r.KP) {
-                    const unsigned kap = (unsigned)(r.klo + off);
-                    const float p = psi[off];
-                    const c32 X = xb[kap];
-                    const c32 cw = ctw[(kap * col) & (unsigned)(P - 1)];   // kap*col < 2^31
+                    const float p = psi[off] * invP;
+                    const c32 X = xb[r.klo + off];
+                    c32 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
+                    if (offu >= L) cw = cmul(cw, wf);
                     const c32 bz = {p * X.x, p * X.y};
                     z = cmul(bz, cw);
                     const float mm = pxi[off] * A.inv_dt;   // 1j*xi/dt, xi as the reference stores it
