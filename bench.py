@@ -160,14 +160,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, gpu_ms = t.tolist()
 
+    # per-stage times of the same workload, HIP events inside the plan on the launch
+    # stream (outside the timed region: the plan synchronises while it measures)
+    stages = None
+    if rank == 0:
+        from ssqueezepy_amd._cwt import _PLAN_CACHE
+        plan = next(iter(_PLAN_CACHE.values()))
+        plan.timing(1)
+        for _ in range(3):
+            out = step()
+        torch.cuda.synchronize()
+        ms, nsig = plan.timing(0)
+        if nsig:
+            stages = {k: v / nsig * 1e3 for k, v in zip(
+                ("pad_fft_spectra_us", "block_rows_us", "exact_rows_us", "reassignment_us"), ms)}
+
     if rank == 0:
         transforms = args.steps * B * world
         value = transforms / wall
         bytes_alg = N * 4 + 2 * na * N * 8          # per transform
         t_transform = (gpu_ms / 1e3) / (args.steps * B)   # per GPU, event-timed
         achieved = bytes_alg / t_transform / 1e9
-        from ssqueezepy_amd._cwt import _PLAN_CACHE
-        plan = next(iter(_PLAN_CACHE.values()))
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.isfile(tfile) and (N, na) == (160000, 300):
@@ -197,6 +210,16 @@ def main():
                          "bytes_alg_per_transform": bytes_alg,
                          "us_per_transform": t_transform * 1e6},
         }
+        if stages:
+            # the single largest kernel is the reassignment (one launch per transform);
+            # it moves Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point
+            acc_bytes = na * N * 18
+            line["stages_us_per_transform"] = stages
+            line["dominant_kernel"] = {
+                "name": "ssq::accumulate_tile16_kernel", "us": stages["reassignment_us"],
+                "bytes_moved": acc_bytes,
+                "GBps": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9,
+                "frac_of_hbm_peak": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu:
             try:
                 line["cpu_baseline"] = cpu_baseline(N, na)

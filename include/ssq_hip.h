@@ -195,6 +195,13 @@ typedef struct {
 
 int  ssq_cwt_plan_set_blocks(ssq_cwt_plan* plan, const ssq_cwt_blocks_desc* desc);
 
+/* Per-stage timing with HIP events on the execute stream (measurement aid, off by
+ * default; execute synchronises when it is on). `stage_ms[4]` receives the time
+ * accumulated since the last reset: 0 = pad + forward FFT + block spectra, 1 = block
+ * rows, 2 = exact / generic rows, 3 = reassignment; `*signals` the transforms covered.
+ * `enable` = 1 / 0 switches timing on / off and resets the accumulators, -1 only reads. */
+int  ssq_cwt_plan_timing(ssq_cwt_plan* plan, int enable, double* stage_ms, int64_t* signals);
+
 /* bytes of device memory held by the plan (bank + workspace) */
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);
 /* name of the compute path the plan selected ("rocfft", "zoom+rocfft", ...) */

@@ -147,6 +147,15 @@ class CwtPlan():
     def device_bytes(self):
         return int(self.lib.ssq_cwt_plan_bytes(self._h))
 
+    def timing(self, enable=-1):
+        """Per-stage HIP-event timing (see `ssq_cwt_plan_timing`): returns
+        ``(stage_ms[4], n_signals)`` accumulated so far; `enable` 1/0 switches it on/off
+        and resets, -1 only reads."""
+        ms = (ctypes.c_double * 4)()
+        n = ctypes.c_int64()
+        check(self.lib.ssq_cwt_plan_timing(self._h, int(enable), ms, ctypes.byref(n)))
+        return list(ms), int(n.value)
+
     def set_ssq(self, grid, params, const, flipud, gamma):
         """Synchrosqueezing parameters for subsequent `execute(..., Tx=...)`."""
         # as the reference materialises it (algos.py:66-79): a scalar becomes a

@@ -147,6 +147,12 @@ struct ssq_cwt_plan {
     const int32_t* gen_rows_for(bool use_blocks) const { return use_blocks ? gen_rows : all_rows; }
     BlockPlan* blk = nullptr;
     bool executed = false;
+    // optional per-stage HIP-event timing (bench.py reads it): 0 = pad + forward FFT +
+    // block spectra, 1 = block rows, 2 = exact / generic rows, 3 = reassignment
+    bool timing = false;
+    std::vector<hipEvent_t> tev;          // 5 events per signal slot + 2 per execute
+    double stage_ms[4] = {0, 0, 0, 0};
+    int64_t timed_signals = 0;
 };
 
 static int dev_alloc(void** p, size_t bytes, int64_t& acc) {
@@ -224,6 +230,7 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     pl->fwd.destroy();
     for (auto& kv : pl->inv) kv.second.destroy();
     if (pl->blk) { pl->blk->destroy(); delete pl->blk; }
+    for (hipEvent_t e : pl->tev) (void)hipEventDestroy(e);
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
                     pl->kidx, pl->cst, pl->gen_rows, pl->all_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -273,6 +280,18 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
     return 0;
 }
 
+int ssq_cwt_plan_timing(ssq_cwt_plan* pl, int enable, double* stage_ms, int64_t* signals) {
+    SSQ_REQUIRE(pl, "ssq_cwt_plan_timing: null plan");
+    if (stage_ms) for (int t = 0; t < 4; ++t) stage_ms[t] = pl->stage_ms[t];
+    if (signals) *signals = pl->timed_signals;
+    if (enable >= 0) {
+        pl->timing = enable != 0;
+        for (int t = 0; t < 4; ++t) pl->stage_ms[t] = 0;
+        pl->timed_signals = 0;
+    }
+    return 0;
+}
+
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* pl) { return pl ? pl->bytes : 0; }
 const char* ssq_cwt_plan_algo(const ssq_cwt_plan* pl) { return pl ? pl->algo.c_str() : ""; }
 
@@ -288,6 +307,10 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     const int nplanes = deriv ? 2 : 1;
     const double h = (2.0 * 3.141592653589793) / (double)M;
     const T inv_dt = T(1) / (T)d.dt;
+    if (pl->timing && pl->tev.size() < 2) {
+        for (int t = 0; t < 2; ++t) { hipEvent_t e; SSQ_CHECK_HIP(hipEventCreate(&e)); pl->tev.push_back(e); }
+    }
+    if (pl->timing) (void)hipEventRecord(pl->tev[0], stream);
 
     // pad (or copy) the whole batch, forward FFT of all signals at once
     const T* xsrc = (const T*)x;
@@ -310,6 +333,14 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     }
 
     pl->executed = true;
+    const bool tm = pl->timing;
+    if (tm && pl->tev.size() < (size_t)(2 + 4 * batch)) {
+        size_t need = (size_t)(2 + 4 * batch);
+        while (pl->tev.size() < need) {
+            hipEvent_t e; SSQ_CHECK_HIP(hipEventCreate(&e)); pl->tev.push_back(e);
+        }
+    }
+    auto mark = [&](size_t idx) { if (tm) (void)hipEventRecord(pl->tev[idx], stream); };
     const bool use_blocks = pl->blk && !rpadded;
     const int64_t n_gen = use_blocks ? pl->n_gen : na;
     if (use_blocks) {
@@ -318,7 +349,9 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
             if (rc) return rc;
         }
     }
+    mark(1);
     for (int64_t b = 0; b < batch; ++b) {
+        mark(2 + 4 * b);
         const T* xh = (const T*)pl->xh + (size_t)b * (M / 2 + 1) * 2;
         T* Wx_b = Wx ? (T*)Wx + (size_t)b * na * out_cols * 2 : nullptr;
         T* dWx_b = dWx ? (T*)dWx + (size_t)b * na * out_cols * 2 : nullptr;
@@ -332,6 +365,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
                 if (rc) return rc;
             }
         }
+        mark(2 + 4 * b + 1);
         if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
             if constexpr (sizeof(T) == 4) {
                 int rc = pl->blk->run_exact((int)b, xh, (float*)Wx, (float*)dWx, (float*)w,
@@ -369,12 +403,25 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
                                (const T*)pl->prod, M, nplanes, na, ea, pl->sp);
             SSQ_LAUNCH_CHECK();
         }
+        mark(2 + 4 * b + 2);
         if (Tx) {
             int rc2 = launch_accumulate(d.dtype, w ? BIN_FROM_W : BIN_FROM_KIDX, Wx_b,
                                         w ? (const void*)w_b : (const void*)pl->kidx, nullptr, Tx_b,
                                         pl->cst, pl->sp, 1, na, N, nullptr, stream);
             if (rc2) return rc2;
         }
+        mark(2 + 4 * b + 3);
+    }
+    if (tm) {
+        SSQ_CHECK_HIP(hipEventSynchronize(pl->tev[2 + 4 * (batch - 1) + 3]));
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, pl->tev[0], pl->tev[1]); pl->stage_ms[0] += ms;
+        for (int64_t b = 0; b < batch; ++b)
+            for (int st = 0; st < 3; ++st) {
+                (void)hipEventElapsedTime(&ms, pl->tev[2 + 4 * b + st], pl->tev[2 + 4 * b + st + 1]);
+                pl->stage_ms[1 + st] += ms;
+            }
+        pl->timed_signals += batch;
     }
     return 0;
 }
