@@ -1,0 +1,107 @@
+# -*- coding: utf-8 -*-
+"""Edge cases of the public API on the MI355X against the oracle pipeline (itself
+pinned to the reference): odd / tiny lengths, unpadded transforms, custom scale arrays,
+time vectors, odd n_fft, short windows, single-scale banks, plan-cache reuse."""
+import numpy as np
+import pytest
+from conftest import two_chirps
+from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
+
+pytestmark = pytest.mark.gpu
+NUMBA = 0
+
+
+@pytest.fixture(scope='module')
+def S():
+    import torch
+    assert torch.cuda.is_available()
+    import ssqueezepy_amd
+    from ssqueezepy_amd import _lib
+    _lib.load(build_if_missing=False)
+    return ssqueezepy_amd
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize('N', [129, 1001, 4097, 9000])
+def test_cwt_odd_and_boundary_lengths(S, orc, N):
+    x = two_chirps(N, seed=N)
+    for dtype, tol in (('float32', 1e-5), ('float64', 1e-12)):
+        wav = S.Wavelet(('gmw', {'dtype': dtype}))
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=8, get_dWx=True,
+                                        astensor=False)
+        r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=8, typing=1)
+        assert Wx.shape == r['Wx'].shape
+        assert relmax(Wx, r['Wx']) <= tol and relmax(dWx, r['dWx']) <= tol
+        ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
+                           True, typing=NUMBA)
+        assert np.array_equal(Tx, ref)
+
+
+def test_cwt_unpadded_custom_scales_and_time_vector(S, orc):
+    x = two_chirps(777, seed=1)
+    wav = S.Wavelet()
+    # padtype=None: transform length = signal length (odd, not a power of two)
+    Wx, sc = S.cwt(x, wav, scales='log', nv=8, padtype=None, astensor=False)
+    r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=8, padtype=None, ssq=False)
+    assert relmax(Wx, r['Wx']) <= 1e-5
+    # explicit scale array (log) and a time vector instead of fs
+    scales = np.power(2., np.arange(8, 60) / 8.)
+    t = np.arange(len(x)) / 250.
+    Tx, Wx, sf, sc2, dWx = S.ssq_cwt(x, wav, scales=scales, t=t, get_dWx=True, astensor=False)
+    r = oracle_ssq_cwt(orc, x, 'float32', scales=scales, fs=250., typing=1)
+    assert np.array_equal(sc2, scales.astype('float32'))
+    assert np.allclose(sf, r['ssq_freqs'], rtol=1e-12)
+    assert relmax(Wx, r['Wx']) <= 1e-5 and relmax(dWx, r['dWx']) <= 1e-5
+    # a three-scale bank (the fewest the scale-type inference accepts), and maprange='maximal' with a linear frequency axis
+    W1, s1 = S.cwt(x, wav, scales=np.array([4., 8., 16.]), astensor=False)
+    assert W1.shape == (3, len(x))
+    Tx, Wx, sf, sc = S.ssq_cwt(x, wav, scales='log', nv=8, ssq_freqs='linear',
+                               maprange='maximal', astensor=False)
+    assert Tx.shape == Wx.shape and np.all(np.diff(sf) < 0)
+    with pytest.raises(ValueError):
+        S.ssq_cwt(x, wav, scales='log-piecewise', maprange='maximal')
+
+
+def test_plan_cache_and_repeated_calls(S):
+    from ssqueezepy_amd import _cwt
+    _cwt.clear_plan_cache()
+    x = two_chirps(5000, seed=4)
+    wav = S.Wavelet()
+    a = S.ssq_cwt(x, wav, scales='log', nv=8, astensor=False)
+    assert len(_cwt._PLAN_CACHE) == 1
+    b = S.ssq_cwt(x, wav, scales='log', nv=8, astensor=False)
+    assert len(_cwt._PLAN_CACHE) == 1                      # same plan reused
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])   # deterministic
+    c = S.ssq_cwt(x, wav, scales='log', nv=8, flipud=False, astensor=False)
+    assert np.array_equal(c[0], a[0][::-1])                # new ssq params on the same plan
+    S.ssq_cwt(np.stack([x, x]), wav, scales='log', nv=8)   # larger batch -> plan rebuilt
+    d = S.ssq_cwt(x, wav, scales='log', nv=8, astensor=False)
+    assert np.array_equal(d[0], a[0])
+    for n in (300, 400, 500, 600, 700, 800, 900, 1000, 1100):   # cache eviction
+        S.cwt(two_chirps(n, 0), wav, scales='log', nv=4)
+    assert len(_cwt._PLAN_CACHE) <= 8
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_stft_odd_sizes_and_windows(S, orc, dtype):
+    tol = 1e-5 if dtype == 'float32' else 1e-12
+    x = two_chirps(1237, seed=8)
+    for kw in (dict(n_fft=127, hop_len=5), dict(n_fft=64, hop_len=64),
+               dict(n_fft=200, win_len=150, hop_len=13, window='hamming'),
+               dict(n_fft=128, hop_len=3, modulated=False, padtype='zero')):
+        Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, dtype=dtype, get_dWx=True, astensor=False, **kw)
+        okw = {k: v for k, v in kw.items()}
+        r = oracle_ssq_stft(orc, x, dtype, **okw)
+        assert Sx.shape == r['Sx'].shape, kw
+        assert relmax(Sx, r['Sx']) <= tol and relmax(dSx, r['dSx']) <= tol, kw
+        from ssqueezepy_amd.ssqueezing import ssq_grid_params
+        _, p = ssq_grid_params(Sfs, False)
+        ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], r['gamma'], False, Sfs=Sfs,
+                           typing=NUMBA)
+        assert np.array_equal(Tx, ref), kw
+    Tf = S.ssq_stft(x, n_fft=64, hop_len=8, dtype=dtype, flipud=True, astensor=False)
+    Tn = S.ssq_stft(x, n_fft=64, hop_len=8, dtype=dtype, astensor=False)
+    assert np.array_equal(Tf[0], Tn[0][::-1]) and np.array_equal(Tf[2], Tn[2][::-1])
