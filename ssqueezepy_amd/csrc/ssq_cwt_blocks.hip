@@ -253,6 +253,12 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     // not the arithmetic, bounded this stage).
     __shared__ c32 spow[R1 * G];
     __shared__ c32 wrapf[G];
+    // The band itself (psi X / P and its derivative multiple) is the same for all G
+    // columns of the workgroup: for the small transforms it is formed once per
+    // workgroup in LDS instead of once per point from global memory.
+    constexpr bool STAGE = (L <= 512);
+    __shared__ c32 bandW[STAGE ? L : 1], bandD[STAGE ? L : 1];
+    const float invP = 1.0f / (float)P;             // exact (P is a power of two)
     {
         constexpr int STR = L / R1;
         for (int i = tid; i < R1 * G; i += NT) {
@@ -263,9 +269,21 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
             const unsigned col = (unsigned)(c0 + tid);
             wrapf[tid] = ctw[(0u - (unsigned)L * col) & (unsigned)(P - 1)];
         }
+        if constexpr (STAGE) {
+            for (int off = tid; off < L; off += NT) {
+                c32 b = {0.f, 0.f}, d = {0.f, 0.f};
+                if (off < r.KP) {
+                    const float p = psi[off] * invP;
+                    const c32 X = xb[r.klo + off];
+                    b = {p * X.x, p * X.y};
+                    const float mm = pxi[off] * A.inv_dt;   // 1j*xi/dt, xi as the reference stores it
+                    d = {-(b.y * mm), b.x * mm};
+                }
+                bandW[off] = b; bandD[off] = d;
+            }
+        }
     }
     __syncthreads();
-    const float invP = 1.0f / (float)P;             // exact (P is a power of two)
     c32 zw[PPT], zd[PPT];
     {
         constexpr int NB = PPT / R1, STR = L / R1;
@@ -281,14 +299,20 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
                 const int offu = off0 + k * STR;            // < 2L
                 const int off = offu & (L - 1);             // band element at FFT slot q
                 c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
-                if (off < r.KP) {
+                if constexpr (STAGE) {
+                    // zero-padded band: slots past KP hold zeros, no branch needed
+                    c32 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
+                    if (offu >= L) cw = cmul(cw, wf);
+                    z = cmul(bandW[off], cw);
+                    dz = cmul(bandD[off], cw);
+                } else if (off < r.KP) {
                     const float p = psi[off] * invP;
                     const c32 X = xb[r.klo + off];
                     c32 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
                     if (offu >= L) cw = cmul(cw, wf);
                     const c32 bz = {p * X.x, p * X.y};
                     z = cmul(bz, cw);
-                    const float mm = pxi[off] * A.inv_dt;   // 1j*xi/dt, xi as the reference stores it
+                    const float mm = pxi[off] * A.inv_dt;
                     dz = {-(z.y * mm), z.x * mm};
                 }
                 zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
