@@ -25,6 +25,7 @@ struct BlockClassDev {
 
 struct BlockPlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0, max_batch = 1;
+    int group = 1;                   // signals per launch (kernels take them as a grid dimension)
     int nc = 0;
     std::vector<BlockClassDev> hcls;
     BlockClassDev* classes = nullptr;
@@ -49,7 +50,8 @@ struct BlockPlan {
     int setup_exact(const float* bank_dev, const int64_t* band_off_dev, const int32_t* band_lo_dev,
                     const int32_t* gen_rows_dev, const std::vector<int64_t>& h_off,
                     const std::vector<int32_t>& h_lo, const std::vector<int32_t>& h_gen, int64_t& bytes);
-    int run_exact(int sig, const void* xh_sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+    // exact rows of signals sig .. sig+nsig-1 (nsig <= group); xh_all: spectra of the whole batch
+    int run_exact(int sig, int nsig, const void* xh_all, float* Wx, float* dWx, float* w, unsigned short* kidx,
                   const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
 
     int create(const ssq_cwt_blocks_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na,
@@ -57,8 +59,8 @@ struct BlockPlan {
     void destroy();
     // block spectra of all classes for the padded batch xp (max_batch x M)
     int spectra(const float* xp, int64_t batch, hipStream_t stream);
-    // all block rows of signal `sig`
-    int run(int sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+    // all block rows of signals sig .. sig+nsig-1; kidx holds nsig maps
+    int run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
             const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
 };
 

@@ -59,7 +59,10 @@ struct SsqParams {
 
 // fill the float32 screening constants from p[]/grid
 static inline void finalize_params(SsqParams& sp) {
-    const double slack = 1.2e-5;          // abs. error budget of a float32 log2 chain
+    // abs. error budget of the float32 chain (log2 w - vlmin): v_log_f32 is good to 1 ulp
+    // (<= 1e-6 for |log2 w| < 16), float(vlmin) and the subtraction round by <= 5e-7
+    // each -> 2e-6; budgeted 2.5x. Relative terms are added per point.
+    const double slack = 5e-6;
     double g;
     if (sp.grid == SSQ_GRID_LIN) {
         sp.pf[0] = (float)sp.p[0]; sp.pf[1] = (float)(1.0 / sp.p[1]);

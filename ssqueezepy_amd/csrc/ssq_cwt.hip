@@ -135,6 +135,9 @@ struct ssq_cwt_plan {
     void* xp = nullptr; void* xh = nullptr; void* prod = nullptr; unsigned short* kidx = nullptr;
     int64_t rows_chunk = 0;
     int64_t bytes = 0;
+    // signals per launch group: the fast-path kernels and the reassignment take `group`
+    // signals as a grid dimension (fewer, longer launches; the bin map holds `group` maps)
+    int group = 1;
     FftPlan fwd;                          // R2C, batch = max_batch
     std::map<int64_t, FftPlan> inv;       // C2C inverse keyed by transform count
     // ssq
@@ -208,7 +211,13 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     const size_t budget = (size_t)2 << 30;
     pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
     TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
-    TRY(dev_alloc((void**)&pl->kidx, (size_t)d.na * ((d.n + 15) / 16 * 16) * 2, pl->bytes));
+    {
+        // default: up to 8 signals per launch, bin maps bounded to ~2 GiB
+        int64_t g = std::min<int64_t>(8, std::max<int64_t>(1, ((int64_t)1 << 30) / (d.na * d.n)));
+        if (const char* e = getenv("SSQ_CWT_GROUP")) g = atoi(e);
+        pl->group = (int)std::max<int64_t>(1, std::min<int64_t>(g, pl->d.max_batch));
+    }
+    TRY(dev_alloc((void**)&pl->kidx, ((size_t)pl->group * d.na * d.n + 64) * 2, pl->bytes));
     {
         std::vector<int32_t> all((size_t)d.na);
         for (int64_t i = 0; i < d.na; ++i) all[i] = (int32_t)i;
@@ -264,6 +273,7 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
         SSQ_REQUIRE(P >= 4096 && (P & (P - 1)) == 0 && P <= pl->d.m, "class %d: bad block length %lld", c, (long long)P);
     }
     auto* b = new BlockPlan();
+    b->group = pl->group;
     int rc = b->create(*bd, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->d.max_batch, pl->bytes);
     if (rc) { b->destroy(); delete b; return rc; }
     pl->blk = b;
@@ -350,30 +360,31 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         }
     }
     mark(1);
-    for (int64_t b = 0; b < batch; ++b) {
-        mark(2 + 4 * b);
+    int64_t slot = 0;                                   // timing slot = launch group
+    for (int64_t b0 = 0; b0 < batch; b0 += pl->group, ++slot) {
+        const int ng = (int)std::min<int64_t>(pl->group, batch - b0);
+        mark(2 + 4 * slot);
+        unsigned short* kidx = (Tx && !w) ? pl->kidx : nullptr;
+        if (use_blocks) {
+            if constexpr (sizeof(T) == 4) {
+                int rc = pl->blk->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)w, kidx,
+                                      (const float*)pl->row_scale, d.dt, pl->sp, stream);
+                if (rc) return rc;
+            }
+        }
+        mark(2 + 4 * slot + 1);
+        if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
+            if constexpr (sizeof(T) == 4) {
+                int rc = pl->blk->run_exact((int)b0, ng, pl->xh, (float*)Wx, (float*)dWx, (float*)w, kidx,
+                                            (const float*)pl->row_scale, d.dt, pl->sp, stream);
+                if (rc) return rc;
+            }
+        } else
+        for (int64_t b = b0; b < b0 + ng; ++b) {
         const T* xh = (const T*)pl->xh + (size_t)b * (M / 2 + 1) * 2;
         T* Wx_b = Wx ? (T*)Wx + (size_t)b * na * out_cols * 2 : nullptr;
         T* dWx_b = dWx ? (T*)dWx + (size_t)b * na * out_cols * 2 : nullptr;
         T* w_b = w ? (T*)w + (size_t)b * na * out_cols : nullptr;
-        T* Tx_b = Tx ? (T*)Tx + (size_t)b * na * out_cols * 2 : nullptr;
-        if (use_blocks) {
-            if constexpr (sizeof(T) == 4) {
-                int rc = pl->blk->run((int)b, (float*)Wx, (float*)dWx, (float*)w,
-                                      (Tx && !w) ? pl->kidx : nullptr, (const float*)pl->row_scale,
-                                      d.dt, pl->sp, stream);
-                if (rc) return rc;
-            }
-        }
-        mark(2 + 4 * b + 1);
-        if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
-            if constexpr (sizeof(T) == 4) {
-                int rc = pl->blk->run_exact((int)b, xh, (float*)Wx, (float*)dWx, (float*)w,
-                                            (Tx && !w) ? pl->kidx : nullptr, (const float*)pl->row_scale,
-                                            d.dt, pl->sp, stream);
-                if (rc) return rc;
-            }
-        } else
         for (int64_t row0 = 0; row0 < n_gen; row0 += pl->rows_chunk) {
             const int64_t rows = std::min(pl->rows_chunk, n_gen - row0);
             unsigned gx = (unsigned)std::min<int64_t>((M + 255) / 256, 4096);
@@ -394,7 +405,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
             if (rc) return rc;
             EpilogueArgs ea;
             ea.Wx = Wx_b; ea.dWx = dWx_b; ea.w = w_b;
-            ea.kidx = (Tx && !w) ? pl->kidx : nullptr;
+            ea.kidx = kidx ? kidx + (size_t)(b - b0) * na * N : nullptr;
             ea.out_cols = out_cols; ea.col0 = rpadded ? 0 : d.n1; ea.row0 = row0;
             ea.rowlist = pl->gen_rows_for(use_blocks);
             ea.row_scale = pl->row_scale; ea.gamma = pl->sp.gamma; ea.have_ssq = pl->have_ssq;
@@ -403,20 +414,25 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
                                (const T*)pl->prod, M, nplanes, na, ea, pl->sp);
             SSQ_LAUNCH_CHECK();
         }
-        mark(2 + 4 * b + 2);
+        }
+        mark(2 + 4 * slot + 2);
         if (Tx) {
-            int rc2 = launch_accumulate(d.dtype, w ? BIN_FROM_W : BIN_FROM_KIDX, Wx_b,
-                                        w ? (const void*)w_b : (const void*)pl->kidx, nullptr, Tx_b,
-                                        pl->cst, pl->sp, 1, na, N, nullptr, stream);
+            T* Wx_g = (T*)Wx + (size_t)b0 * na * out_cols * 2;
+            T* w_g = w ? (T*)w + (size_t)b0 * na * out_cols : nullptr;
+            T* Tx_g = (T*)Tx + (size_t)b0 * na * out_cols * 2;
+            int rc2 = launch_accumulate(d.dtype, w ? BIN_FROM_W : BIN_FROM_KIDX, Wx_g,
+                                        w ? (const void*)w_g : (const void*)pl->kidx, nullptr, Tx_g,
+                                        pl->cst, pl->sp, ng, na, N, nullptr, stream);
             if (rc2) return rc2;
         }
-        mark(2 + 4 * b + 3);
+        mark(2 + 4 * slot + 3);
     }
+    const int64_t nslots = slot;
     if (tm) {
-        SSQ_CHECK_HIP(hipEventSynchronize(pl->tev[2 + 4 * (batch - 1) + 3]));
+        SSQ_CHECK_HIP(hipEventSynchronize(pl->tev[2 + 4 * (nslots - 1) + 3]));
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, pl->tev[0], pl->tev[1]); pl->stage_ms[0] += ms;
-        for (int64_t b = 0; b < batch; ++b)
+        for (int64_t b = 0; b < nslots; ++b)
             for (int st = 0; st < 3; ++st) {
                 (void)hipEventElapsedTime(&ms, pl->tev[2 + 4 * b + st], pl->tev[2 + 4 * b + st + 1]);
                 pl->stage_ms[1 + st] += ms;

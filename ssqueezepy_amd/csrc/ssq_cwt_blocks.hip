@@ -176,22 +176,26 @@ struct EmitRow {
     float rs; bool scale; double gamma; int64_t omax;
 };
 __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w, unsigned short* kidx,
-                                                 const float* row_scale, int sig, int row, int64_t na,
-                                                 int64_t N, double gamma) {
+                                                 const float* row_scale, int sig, int ksig, int row,
+                                                 int64_t na, int64_t N, double gamma) {
     EmitRow e;
     const int64_t base = ((int64_t)sig * na + row) * N;
     e.W = reinterpret_cast<float2*>(Wx) + base;
     e.D = dWx ? reinterpret_cast<float2*>(dWx) + base : nullptr;
     e.w = w ? w + base : nullptr;
-    e.k = kidx ? kidx + kidx_index(row, 0, na, N) : nullptr;
+    e.k = kidx ? kidx + (int64_t)ksig * na * N + kidx_index(row, 0, na, N) : nullptr;
     e.scale = row_scale != nullptr;
     e.rs = row_scale ? row_scale[row] : 1.f;
     e.gamma = gamma; e.omax = na - 1;
     return e;
 }
-__device__ __forceinline__ void emit_point(const EmitRow& e, int j, c32 W, c32 D, const SsqParams& sp) {
+// Stores one point. Returns true when its bin could not be decided by the float32
+// screens: the caller then runs `emit_point_exact` for it outside the unrolled loop
+// (one copy of the double-precision code per kernel instead of one per point -- the
+// unrolled epilogue stays small enough for the instruction cache).
+__device__ __forceinline__ bool emit_point(const EmitRow& e, int j, c32 W, c32 D, const SsqParams& sp) {
     float c = W.x, d = W.y, a = D.x, b = D.y;
-    if (e.scale) { c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs; }
+    c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs;        // rs == 1 (exact) when unscaled
     e.W[j] = make_float2(c, d);
     if (e.D) e.D[j] = make_float2(a, b);
     if (e.w) {
@@ -201,15 +205,28 @@ __device__ __forceinline__ void emit_point(const EmitRow& e, int j, c32 W, c32 D
         e.w[j] = wv;
     }
     if (e.k) {
+        const int above = mag_gt_screen(c, d, e.gamma);
+        if (above < 0) return true;
         unsigned short kk = 0xFFFFu;
-        if (mag_gt(c, d, e.gamma)) {
-            int64_t kb = bin_of_point(a, b, c, d, false, 0.f, sp, e.omax);
-            kk = (unsigned short)(sp.flipud ? e.omax - kb : kb);
+        if (above) {
+            const int kb = bin_of_point_screen(a, b, c, d, sp, (int)e.omax);
+            if (kb == -2) return true;
+            kk = (unsigned short)(sp.flipud ? (int)e.omax - kb : kb);
         }
         e.k[j] = kk;
     }
+    return false;
 }
-
+__device__ __forceinline__ void emit_point_exact(const EmitRow& e, unsigned short* kout, c32 W, c32 D,
+                                                 const SsqParams& sp) {
+    const float c = W.x * e.rs, d = W.y * e.rs, a = D.x * e.rs, b = D.y * e.rs;
+    unsigned short kk = 0xFFFFu;
+    if (mag_of(c, d) > e.gamma) {
+        const int64_t kb = bin_of_point_exact(a, b, c, d, sp, e.omax);
+        kk = (unsigned short)(sp.flipud ? e.omax - kb : kb);
+    }
+    *kout = kk;
+}
 struct BlockArgs {
     const int4* items;                 // (row, block, c0, class)
     const BlockRowDev* rows;
@@ -225,7 +242,7 @@ struct BlockArgs {
     double h;                          // 2 pi / M
     float inv_dt;
     double gamma;
-    int sig;                           // signal index within the batch
+    int sig;                           // first signal of the launch (blockIdx.y adds to it)
 };
 
 template <int L, int G, int R1, int R2, int R3>
@@ -238,7 +255,8 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const BlockRowDev r = A.rows[row];
     const BlockClassDev cl = A.classes[item.w];
     const int P = (int)cl.P, Rp = P / L;
-    const c32* xb = A.xb + cl.xb_off + ((int64_t)A.sig * cl.nb + blk) * (cl.P / 2 + 1);
+    const int sig = A.sig + (int)blockIdx.y;
+    const c32* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * (cl.P / 2 + 1);
     const c32* ctw = A.ctw + cl.ctw_off;
     const float* psi = A.pbank + r.pb_off;
     const float* pxi = A.pxi + r.pb_off;
@@ -324,9 +342,10 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
 
     // ---- epilogue: unpad, store, phase transform, bin map
     constexpr int NB = PPT / RL, STR = L / RL;
-    const EmitRow er = make_emit_row(A.Wx, A.dWx, A.w, A.kidx, A.row_scale, A.sig, row, A.na, A.N, A.gamma);
+    const EmitRow er = make_emit_row(A.Wx, A.dWx, A.w, A.kidx, A.row_scale, sig, (int)blockIdx.y, row, A.na, A.N, A.gamma);
     const int m = (int)cl.m, hiv = (int)(cl.m + cl.V), N = (int)A.N;
     const int jbase = blk * (int)cl.V - m + c0;
+    unsigned pend = 0;                              // slots whose bin needs the exact map
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
         const int idx = tid + it * NT, g = idx % G, u = idx / G;
@@ -335,8 +354,26 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
             const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
             const int j = jbase + (u + k * STR) * Rp + g;       // output column
             if (tb < m || tb >= hiv || j >= N) continue;
-            emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp);
+            if (emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp)) pend |= 1u << (it * RL + k);
         }
+    }
+    // rare: points inside a screen's guard band. One pending point per lane and round,
+    // picked with compile-time slot indices (zw/zd stay in registers).
+    while (__builtin_amdgcn_ballot_w64(pend != 0)) {
+        const unsigned low = pend & (0u - pend);
+        pend ^= low;
+        c32 W = {0.f, 0.f}, D = {0.f, 0.f};
+        int j = 0;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < RL; ++k)
+                if (low == (1u << (it * RL + k))) {
+                    W = zw[it * RL + k]; D = zd[it * RL + k]; j = jbase + (u + k * STR) * Rp + g;
+                }
+        }
+        if (low) emit_point_exact(er, er.k + j, W, D, sp);
     }
 }
 
@@ -354,7 +391,7 @@ struct ExactArgs {
     const int32_t* rows; const c32* xh; c32* Z; const c32* twM; const c32* ftw;
     const float* row_scale;
     float* Wx; float* dWx; float* w; unsigned short* kidx;
-    int64_t M, N, na; int A, B, n1pad, sig;
+    int64_t M, N, na; int A, B, n1pad, sig, n_rows;   // sig: first signal (blockIdx.z adds)
     double h; float inv_dt; double gamma;
 };
 
@@ -368,6 +405,7 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
     const int64_t off0 = E.band_off[row];
     const int len = (int)(E.band_off[row + 1] - off0);
     const float* psi = E.bank + off0;
+    const c32* xh = E.xh + (int64_t)(E.sig + (int)blockIdx.z) * (E.M / 2 + 1);
     c32 zw[PPT], zd[PPT];
     {
         constexpr int NB = PPT / R1, STR = L / R1;
@@ -381,7 +419,7 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
                 c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
                 if (off >= 0 && off < len) {
                     const float p = psi[off];
-                    const c32 X = E.xh[kk];
+                    const c32 X = xh[kk];
                     z = {p * X.x, p * X.y};
                     const float mm = (float)((double)kk * E.h) * E.inv_dt;
                     dz = {-(z.y * mm), z.x * mm};
@@ -407,7 +445,7 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
             }
         }
         __syncthreads();
-        c32* Zt = E.Z + ((int64_t)r * 2 + tr) * E.M + (int64_t)c0 * L;
+        c32* Zt = E.Z + (((int64_t)blockIdx.z * E.n_rows + r) * 2 + tr) * E.M + (int64_t)c0 * L;
 #pragma unroll
         for (int it = 0; it < PPT; ++it) {
             const int idx = tid + it * NT, n2 = idx % L, g = idx / L;
@@ -422,7 +460,7 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     constexpr int RL = (R3 > 1) ? R3 : R2;
     const int tid = threadIdx.x, r = blockIdx.y, row = E.rows[r];
     const int c0 = blockIdx.x * G;                          // first n2 of this workgroup
-    const c32* ZW = E.Z + ((int64_t)r * 2) * E.M;
+    const c32* ZW = E.Z + (((int64_t)blockIdx.z * E.n_rows + r) * 2) * E.M;
     const c32* ZD = ZW + E.M;
     c32 zw[PPT], zd[PPT];
     {
@@ -440,8 +478,9 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     lds_ifft<L, G, R1, R2, R3>(zw, buf, E.ftw, tid);
     lds_ifft<L, G, R1, R2, R3>(zd, buf, E.ftw, tid);
     constexpr int NB = PPT / RL, STR = L / RL;
-    const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig, row, E.na, E.N, E.gamma);
+    const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig + (int)blockIdx.z, (int)blockIdx.z, row, E.na, E.N, E.gamma);
     const int N = (int)E.N;
+    unsigned pend = 0;
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
         const int idx = tid + it * NT, g = idx % G, u = idx / G;
@@ -450,8 +489,24 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
             const int n = (c0 + g) + E.B * (u + k * STR);
             const int j = n - E.n1pad;
             if (j < 0 || j >= N) continue;
-            emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp);
+            if (emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp)) pend |= 1u << (it * RL + k);
         }
+    }
+    while (__builtin_amdgcn_ballot_w64(pend != 0)) {
+        const unsigned low = pend & (0u - pend);
+        pend ^= low;
+        c32 W = {0.f, 0.f}, D = {0.f, 0.f};
+        int j = 0;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < RL; ++k)
+                if (low == (1u << (it * RL + k))) {
+                    W = zw[it * RL + k]; D = zd[it * RL + k]; j = (c0 + g) + E.B * (u + k * STR) - E.n1pad;
+                }
+        }
+        if (low) emit_point_exact(er, er.k + j, W, D, sp);
     }
 }
 
@@ -470,9 +525,9 @@ __global__ __launch_bounds__(256) void gather_blocks_kernel(const float* __restr
 }
 
 template <int L, int G, int R1, int R2, int R3>
-static int launch_zoom(const BlockArgs& A, const SsqParams& sp, hipStream_t stream) {
+static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
-    hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items), dim3(NT), 0,
+    hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items, (unsigned)nsig), dim3(NT), 0,
                        stream, A, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
@@ -546,7 +601,7 @@ int BlockPlan::spectra(const float* xp, int64_t batch, hipStream_t stream) {
     return 0;
 }
 
-int BlockPlan::run(int sig, float* Wx, float* dWx, float* w, unsigned short* kidx,
+int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
                    const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
     BlockArgs A;
     A.rows = rows; A.classes = classes; A.pbank = pbank; A.pxi = pxi; A.ctw = (const c32*)ctw;
@@ -560,7 +615,7 @@ int BlockPlan::run(int sig, float* Wx, float* dWx, float* w, unsigned short* kid
 #define ZOOM(slot, L, G, R1, R2, R3)                                                              \
     A.items = (const int4*)items[slot]; A.n_items = n_items[slot];                                 \
     A.ftw = (const c32*)ftw + ftw_off[slot];                                                       \
-    if ((rc = launch_zoom<L, G, R1, R2, R3>(A, sp, stream))) return rc;
+    if ((rc = launch_zoom<L, G, R1, R2, R3>(A, sp, nsig, stream))) return rc;
     ZOOM(0, 128, 32, 16, 8, 1)
     ZOOM(1, 256, 16, 16, 16, 1)
     ZOOM(2, 512, 8, 8, 8, 8)
@@ -596,53 +651,53 @@ int BlockPlan::setup_exact(const float* bank_dev, const int64_t* band_off_dev, c
     }
     SSQ_CHECK_HIP(hipMalloc(&twM, 8 * (size_t)M)); bytes += 8 * M;
     SSQ_CHECK_HIP(hipMemcpy(twM, tw.data(), 8 * (size_t)M, hipMemcpyHostToDevice));
-    SSQ_CHECK_HIP(hipMalloc(&zbuf, (size_t)n_exact * 2 * M * 8)); bytes += (int64_t)n_exact * 2 * M * 8;
+    SSQ_CHECK_HIP(hipMalloc(&zbuf, (size_t)group * n_exact * 2 * M * 8)); bytes += (int64_t)group * n_exact * 2 * M * 8;
     exact_ok = true;
     return 0;
 }
 
 template <int L, int G, int R1, int R2, int R3>
-static int launch_exact1(const ExactArgs& E, int n_rows, hipStream_t stream) {
-    hipLaunchKernelGGL((exact_pass1_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.A / G), (unsigned)n_rows),
+static int launch_exact1(const ExactArgs& E, int n_rows, int nsig, hipStream_t stream) {
+    hipLaunchKernelGGL((exact_pass1_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.A / G), (unsigned)n_rows, (unsigned)nsig),
                        dim3(NT), 0, stream, E);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
 template <int L, int G, int R1, int R2, int R3>
-static int launch_exact2(const ExactArgs& E, const SsqParams& sp, int n_rows, hipStream_t stream) {
-    hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)n_rows),
+static int launch_exact2(const ExactArgs& E, const SsqParams& sp, int n_rows, int nsig, hipStream_t stream) {
+    hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)n_rows, (unsigned)nsig),
                        dim3(NT), 0, stream, E, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
 
-int BlockPlan::run_exact(int sig, const void* xh_sig, float* Wx, float* dWx, float* w,
+int BlockPlan::run_exact(int sig, int nsig, const void* xh_all, float* Wx, float* dWx, float* w,
                          unsigned short* kidx, const float* row_scale, double dt, const SsqParams& sp,
                          hipStream_t stream) {
     ExactArgs E;
     E.bank = e_bank; E.band_off = e_off; E.band_lo = e_lo; E.rows = e_rows;
-    E.xh = (const c32*)xh_sig; E.Z = (c32*)zbuf; E.twM = (const c32*)twM; E.row_scale = row_scale;
+    E.xh = (const c32*)xh_all; E.Z = (c32*)zbuf; E.twM = (const c32*)twM; E.row_scale = row_scale;
     E.Wx = Wx; E.dWx = dWx; E.w = w; E.kidx = kidx;
-    E.M = M; E.N = N; E.na = na; E.A = exA; E.B = exB; E.n1pad = (int)n1; E.sig = sig;
+    E.M = M; E.N = N; E.na = na; E.A = exA; E.B = exB; E.n1pad = (int)n1; E.sig = sig; E.n_rows = n_exact;
     E.h = (2.0 * 3.141592653589793) / (double)M; E.inv_dt = 1.0f / (float)dt; E.gamma = sp.gamma;
     auto slot_of = [](int L) { return L == 128 ? 0 : L == 256 ? 1 : L == 512 ? 2 : L == 1024 ? 3 : 4; };
     int rc = 0;
     E.ftw = (const c32*)ftw + ftw_off[slot_of(exB)];
     switch (exB) {
-        case 128: rc = launch_exact1<128, 32, 16, 8, 1>(E, n_exact, stream); break;
-        case 256: rc = launch_exact1<256, 16, 16, 16, 1>(E, n_exact, stream); break;
-        case 512: rc = launch_exact1<512, 8, 8, 8, 8>(E, n_exact, stream); break;
-        case 1024: rc = launch_exact1<1024, 4, 16, 8, 8>(E, n_exact, stream); break;
-        default: rc = launch_exact1<2048, 2, 16, 16, 8>(E, n_exact, stream); break;
+        case 128: rc = launch_exact1<128, 32, 16, 8, 1>(E, n_exact, nsig, stream); break;
+        case 256: rc = launch_exact1<256, 16, 16, 16, 1>(E, n_exact, nsig, stream); break;
+        case 512: rc = launch_exact1<512, 8, 8, 8, 8>(E, n_exact, nsig, stream); break;
+        case 1024: rc = launch_exact1<1024, 4, 16, 8, 8>(E, n_exact, nsig, stream); break;
+        default: rc = launch_exact1<2048, 2, 16, 16, 8>(E, n_exact, nsig, stream); break;
     }
     if (rc) return rc;
     E.ftw = (const c32*)ftw + ftw_off[slot_of(exA)];
     switch (exA) {
-        case 128: return launch_exact2<128, 32, 16, 8, 1>(E, sp, n_exact, stream);
-        case 256: return launch_exact2<256, 16, 16, 16, 1>(E, sp, n_exact, stream);
-        case 512: return launch_exact2<512, 8, 8, 8, 8>(E, sp, n_exact, stream);
-        case 1024: return launch_exact2<1024, 4, 16, 8, 8>(E, sp, n_exact, stream);
-        default: return launch_exact2<2048, 2, 16, 16, 8>(E, sp, n_exact, stream);
+        case 128: return launch_exact2<128, 32, 16, 8, 1>(E, sp, n_exact, nsig, stream);
+        case 256: return launch_exact2<256, 16, 16, 16, 1>(E, sp, n_exact, nsig, stream);
+        case 512: return launch_exact2<512, 8, 8, 8, 8>(E, sp, n_exact, nsig, stream);
+        case 1024: return launch_exact2<1024, 4, 16, 8, 8>(E, sp, n_exact, nsig, stream);
+        default: return launch_exact2<2048, 2, 16, 16, 8>(E, sp, n_exact, nsig, stream);
     }
 }
 

@@ -78,6 +78,14 @@ __device__ __forceinline__ bool mag_gt(float c, float d, double gamma) {
     return mag_of(c, d) > gamma;
 }
 __device__ __forceinline__ bool mag_gt(double c, double d, double gamma) { return mag_of(c, d) > gamma; }
+// the float32 screen of mag_gt on its own: 1 = above, 0 = below, -1 = inside the sliver
+__device__ __forceinline__ int mag_gt_screen(float c, float d, double gamma) {
+    float m2 = c * c + d * d;
+    float g2 = (float)(gamma * gamma);
+    if (m2 > g2 * 1.000004f) return 1;
+    if (m2 < g2 * 0.999996f) return 0;
+    return -1;
+}
 __device__ __forceinline__ bool mag_lt(float c, float d, float gamma) {
     float m2 = c * c + d * d;
     float g2 = gamma * gamma;
@@ -96,8 +104,10 @@ __device__ __forceinline__ bool mag_lt(double c, double d, double gamma) { retur
 // inside the guard band -- a fraction ~2*guard, well under 1 % -- and anything
 // non-finite take the exact path, so the result is identical to it everywhere.
 // Returns the pre-flip bin, or -2 when the point needs the exact path.
-// `werr` bounds the absolute error of the float32 `w` itself.
-__device__ __forceinline__ int bin_screen_f32(float w, float werr, const SsqParams& sp, int omax) {
+// `werr` bounds the absolute error of the float32 `w` itself, `lerr` that of log2(w)
+// (1.4427 * werr / w: a constant for the CWT, where the error of w is relative).
+__device__ __forceinline__ int bin_screen_f32(float w, float werr, float lerr, const SsqParams& sp,
+                                              int omax) {
     if (!(w > 1e-30f && w < 1e30f) || sp.guard >= 0.25f) return -2;
     float t, g = sp.guard;
     if (sp.grid == SSQ_GRID_LIN) {
@@ -105,7 +115,6 @@ __device__ __forceinline__ int bin_screen_f32(float w, float werr, const SsqPara
         g = g + (werr + (fabsf(w) + fabsf(sp.pf[0])) * 2e-7f) * sp.pf[1];
     } else {
         float wl = __log2f(w);
-        float lerr = 1.4427f * werr / w;               // d(log2 w)
         if (sp.grid == SSQ_GRID_LOG) {
             t = (wl - sp.pf[0]) * sp.pf[1];
             g = g + lerr * sp.pf[1];
@@ -134,15 +143,35 @@ __device__ __forceinline__ int bin_screen_f32(float w, float werr, const SsqPara
 
 // bin (pre-flip) of a point from (dWx, Wx) = (a + ib, c + id), optional STFT row
 // frequency; float32 data goes through the screen, double data straight to the exact map
+// the two halves of the float32 `bin_of_point` below, for kernels that keep the
+// exact path out of their unrolled loops: `_screen` returns -2 when undecided
+__device__ __forceinline__ int bin_of_point_screen(float a, float b, float c, float d,
+                                                   const SsqParams& sp, int omax) {
+    float num = b * c - a * d;
+    float m2 = c * c + d * d;
+    float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+    return bin_screen_f32(w32, w32 * 5e-7f, 1.4428f * 5e-7f, sp, omax);
+}
+__device__ __forceinline__ int64_t bin_of_point_exact(float a, float b, float c, float d,
+                                                      const SsqParams& sp, int64_t omax) {
+    float num = b * c - a * d;
+    float m2 = c * c + d * d;
+    return bin_from_w(fabs((double)num / ((double)m2 * SSQ_TWO_PI)), sp, omax);
+}
+
 __device__ __forceinline__ int64_t bin_of_point(float a, float b, float c, float d, bool stft,
                                                 float sfs, const SsqParams& sp, int64_t omax) {
     float num = b * c - a * d;
     float m2 = c * c + d * d;
-    float r32 = num * __frcp_rn(m2 * 6.2831855f);
-    float w32, werr;
-    if (stft) { w32 = fabsf(sfs - r32); werr = (fabsf(sfs) + fabsf(r32)) * 4e-7f; }
-    else { w32 = fabsf(r32); werr = w32 * 4e-7f; }
-    int k = bin_screen_f32(w32, werr, sp, (int)omax);
+    // hardware reciprocal (1 ulp): the estimate's relative error stays under 3e-7
+    // (2pi as float 3e-8, product 6e-8, v_rcp_f32 1.2e-7, product 6e-8)
+    float r32 = num * __builtin_amdgcn_rcpf(m2 * 6.2831855f);
+    float w32, werr, lerr;
+    if (stft) {
+        w32 = fabsf(sfs - r32); werr = (fabsf(sfs) + fabsf(r32)) * 5e-7f;
+        lerr = 1.4428f * werr * __builtin_amdgcn_rcpf(w32);
+    } else { w32 = fabsf(r32); werr = w32 * 5e-7f; lerr = 1.4428f * 5e-7f; }
+    int k = bin_screen_f32(w32, werr, lerr, sp, (int)omax);
     if (k != -2) return k;
     double r = (double)num / ((double)m2 * SSQ_TWO_PI);
     double w = stft ? fabs((double)sfs - r) : fabs(r);

@@ -217,3 +217,39 @@ print("QUAD_OK")
     res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
     assert 'QUAD_OK' in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize('st', ['log', 'log-piecewise', 'linear'])
+def test_bin_screening_stress(A, orc, st):
+    """float32 bin map under load: 6M points whose phase transform sweeps the whole
+    grid (and beyond both ends) densely, so that many land within the float32
+    screen's guard band of a rounding boundary. Every index must equal the exact
+    double-precision map of the CPU path (index work: bit-exact)."""
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    na, n = 300, 20000
+    rng = np.random.default_rng(123)
+    if st == 'linear':
+        sf = np.linspace(1e-3, 0.5, na)
+        wt = rng.uniform(-0.02, 0.55, (na, n))
+    else:
+        if st == 'log':
+            sf = 0.5 * 2.0 ** (-(np.arange(na)[::-1]) / 32.0)
+        else:                    # two log segments of different density (reference's test grid)
+            sf = make_ssq_freqs(na, st)
+        lo, hi = np.log2(sf[0]) - 1, np.log2(sf[-1]) + 1
+        wt = 2.0 ** rng.uniform(lo, hi, (na, n))
+    Wx = (rng.standard_normal((na, n)) + 1j * rng.standard_normal((na, n))).astype('complex64')
+    dWx = (Wx.astype('complex128') * (rng.standard_normal((na, n)) + 2j * np.pi * wt)
+           ).astype('complex64')
+    logscale = st.startswith('log')
+    kind, p = ssq_grid_params(sf, logscale)
+    assert kind == {'log': 0, 'log-piecewise': 1, 'linear': 2}[st]
+    const = np.log(2) / 32
+    for flipud in (False, True):
+        out, k = A.ssqueeze_fast(Wx, dWx, sf, const, logscale, flipud, 1e-3, get_k=True)
+        ref, kref = orc.ssqueeze(Wx, dWx, st, p, const, 1e-3, flipud, typing=NUMBA,
+                                 get_k=True)
+        k = _np(k)
+        assert np.array_equal(k, kref), (st, flipud, int((k != kref).sum()))
+        assert len(np.unique(kref)) > 0.9 * na          # the sweep really covers the grid
+        assert np.array_equal(_np(out), ref)
