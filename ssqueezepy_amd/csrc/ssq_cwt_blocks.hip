@@ -174,6 +174,7 @@ __device__ __forceinline__ void lds_ifft(c32 (&v)[PPT], c32* __restrict__ buf,
 struct EmitRow {
     float2* W; float2* D; float* w; unsigned short* k;
     float rs; bool scale; double gamma; int64_t omax;
+    float m2hi, m2lo;          // |Wx|^2 screens of mag_gt (ssq_point_math.inl)
 };
 __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w, unsigned short* kidx,
                                                  const float* row_scale, int sig, int ksig, int row,
@@ -187,35 +188,65 @@ __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w
     e.scale = row_scale != nullptr;
     e.rs = row_scale ? row_scale[row] : 1.f;
     e.gamma = gamma; e.omax = na - 1;
+    const float g2 = (float)(gamma * gamma);
+    e.m2hi = g2 * 1.000004f; e.m2lo = g2 * 0.999996f;
     return e;
 }
 // Stores one point. Returns true when its bin could not be decided by the float32
 // screens: the caller then runs `emit_point_exact` for it outside the unrolled loop
 // (one copy of the double-precision code per kernel instead of one per point -- the
 // unrolled epilogue stays small enough for the instruction cache).
+// LEAN: the fused ssq_cwt form (Wx + bin map only) -- the kernels are instantiated
+// separately for it so that its epilogue carries no code for the optional outputs, and
+// its bin screen is the branch-free one, specialised per grid kind (GRID).
+template <bool LEAN, int GRID>
 __device__ __forceinline__ bool emit_point(const EmitRow& e, int j, c32 W, c32 D, const SsqParams& sp) {
     float c = W.x, d = W.y, a = D.x, b = D.y;
     c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs;        // rs == 1 (exact) when unscaled
     e.W[j] = make_float2(c, d);
-    if (e.D) e.D[j] = make_float2(a, b);
-    if (e.w) {
-        float wv;
-        if (mag_lt(c, d, (float)e.gamma)) wv = INFINITY;
-        else wv = (float)fabs(phase_ratio(a, b, c, d));
-        e.w[j] = wv;
-    }
-    if (e.k) {
-        const int above = mag_gt_screen(c, d, e.gamma);
-        if (above < 0) return true;
-        unsigned short kk = 0xFFFFu;
-        if (above) {
-            const int kb = bin_of_point_screen(a, b, c, d, sp, (int)e.omax);
-            if (kb == -2) return true;
-            kk = (unsigned short)(sp.flipud ? (int)e.omax - kb : kb);
+    if constexpr (LEAN) {
+        const float m2 = c * c + d * d, num = b * c - a * d;
+        const bool above = m2 > e.m2hi, below = m2 < e.m2lo;
+        // hardware reciprocal: relative error of w under 3e-7 (see bin_of_point)
+        const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+        bool ok;
+        const int kb = bin_screen_cwt<GRID>(w32, sp, (int)e.omax, ok);
+        const int kf = sp.flipud ? (int)e.omax - kb : kb;
+        e.k[j] = (unsigned short)(above ? kf : 0xFFFF);   // overwritten by the exact path if undecided
+        return !(below | (above & ok));
+    } else {
+        if (e.D) e.D[j] = make_float2(a, b);
+        if (e.w) {
+            float wv;
+            if (mag_lt(c, d, (float)e.gamma)) wv = INFINITY;
+            else wv = (float)fabs(phase_ratio(a, b, c, d));
+            e.w[j] = wv;
         }
-        e.k[j] = kk;
+        if (e.k) {
+            const int above = mag_gt_screen(c, d, e.gamma);
+            if (above < 0) return true;
+            unsigned short kk = 0xFFFFu;
+            if (above) {
+                const int kb = bin_of_point_screen(a, b, c, d, sp, (int)e.omax);
+                if (kb == -2) return true;
+                kk = (unsigned short)(sp.flipud ? (int)e.omax - kb : kb);
+            }
+            e.k[j] = kk;
+        }
+        return false;
     }
-    return false;
+}
+// run the epilogue specialised for the grid kind (lean kernels) or generically
+template <int V> struct GridTag { static constexpr int value = V; };
+template <bool LEAN, typename F>
+__device__ __forceinline__ void dispatch_grid(int grid, F&& f) {
+    if constexpr (LEAN) {
+        if (grid == SSQ_GRID_LOG) f(GridTag<SSQ_GRID_LOG>{});
+        else if (grid == SSQ_GRID_LOG_PIECEWISE) f(GridTag<SSQ_GRID_LOG_PIECEWISE>{});
+        else f(GridTag<SSQ_GRID_LIN>{});
+    } else {
+        f(GridTag<-1>{});
+    }
 }
 __device__ __forceinline__ void emit_point_exact(const EmitRow& e, unsigned short* kout, c32 W, c32 D,
                                                  const SsqParams& sp) {
@@ -245,7 +276,7 @@ struct BlockArgs {
     int sig;                           // first signal of the launch (blockIdx.y adds to it)
 };
 
-template <int L, int G, int R1, int R2, int R3>
+template <int L, int G, int R1, int R2, int R3, bool LEAN>
 __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     constexpr int RL = (R3 > 1) ? R3 : R2;         // last radix
@@ -346,17 +377,22 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const int m = (int)cl.m, hiv = (int)(cl.m + cl.V), N = (int)A.N;
     const int jbase = blk * (int)cl.V - m + c0;
     unsigned pend = 0;                              // slots whose bin needs the exact map
+    auto emit_all = [&](auto grid_tag) {
+        constexpr int GRID = decltype(grid_tag)::value;
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
-        for (int k = 0; k < RL; ++k) {
-            const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
-            const int j = jbase + (u + k * STR) * Rp + g;       // output column
-            if (tb < m || tb >= hiv || j >= N) continue;
-            if (emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp)) pend |= 1u << (it * RL + k);
+            for (int k = 0; k < RL; ++k) {
+                const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
+                const int j = jbase + (u + k * STR) * Rp + g;       // output column
+                if (tb < m || tb >= hiv || j >= N) continue;
+                if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], zd[it * RL + k], sp))
+                    pend |= 1u << (it * RL + k);
+            }
         }
-    }
+    };
+    dispatch_grid<LEAN>(sp.grid, emit_all);
     // rare: points inside a screen's guard band. One pending point per lane and round,
     // picked with compile-time slot indices (zw/zd stay in registers).
     while (__builtin_amdgcn_ballot_w64(pend != 0)) {
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
     }
 }
 
-template <int L, int G, int R1, int R2, int R3>
+template <int L, int G, int R1, int R2, int R3, bool LEAN>
 __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     constexpr int RL = (R3 > 1) ? R3 : R2;
@@ -481,17 +517,22 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig + (int)blockIdx.z, (int)blockIdx.z, row, E.na, E.N, E.gamma);
     const int N = (int)E.N;
     unsigned pend = 0;
+    auto emit_all = [&](auto grid_tag) {
+        constexpr int GRID = decltype(grid_tag)::value;
 #pragma unroll
-    for (int it = 0; it < NB; ++it) {
-        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
-        for (int k = 0; k < RL; ++k) {
-            const int n = (c0 + g) + E.B * (u + k * STR);
-            const int j = n - E.n1pad;
-            if (j < 0 || j >= N) continue;
-            if (emit_point(er, j, zw[it * RL + k], zd[it * RL + k], sp)) pend |= 1u << (it * RL + k);
+            for (int k = 0; k < RL; ++k) {
+                const int n = (c0 + g) + E.B * (u + k * STR);
+                const int j = n - E.n1pad;
+                if (j < 0 || j >= N) continue;
+                if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], zd[it * RL + k], sp))
+                    pend |= 1u << (it * RL + k);
+            }
         }
-    }
+    };
+    dispatch_grid<LEAN>(sp.grid, emit_all);
     while (__builtin_amdgcn_ballot_w64(pend != 0)) {
         const unsigned low = pend & (0u - pend);
         pend ^= low;
@@ -527,8 +568,11 @@ __global__ __launch_bounds__(256) void gather_blocks_kernel(const float* __restr
 template <int L, int G, int R1, int R2, int R3>
 static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
-    hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items, (unsigned)nsig), dim3(NT), 0,
-                       stream, A, sp);
+    const dim3 grid((unsigned)A.n_items, (unsigned)nsig);
+    if (A.kidx && !A.dWx && !A.w)
+        hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, true>), grid, dim3(NT), 0, stream, A, sp);
+    else
+        hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, false>), grid, dim3(NT), 0, stream, A, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
@@ -665,8 +709,11 @@ static int launch_exact1(const ExactArgs& E, int n_rows, int nsig, hipStream_t s
 }
 template <int L, int G, int R1, int R2, int R3>
 static int launch_exact2(const ExactArgs& E, const SsqParams& sp, int n_rows, int nsig, hipStream_t stream) {
-    hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)n_rows, (unsigned)nsig),
-                       dim3(NT), 0, stream, E, sp);
+    const dim3 grid((unsigned)(E.B / G), (unsigned)n_rows, (unsigned)nsig);
+    if (E.kidx && !E.dWx && !E.w)
+        hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3, true>), grid, dim3(NT), 0, stream, E, sp);
+    else
+        hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3, false>), grid, dim3(NT), 0, stream, E, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }

@@ -143,6 +143,45 @@ __device__ __forceinline__ int bin_screen_f32(float w, float werr, float lerr, c
 
 // bin (pre-flip) of a point from (dWx, Wx) = (a + ib, c + id), optional STFT row
 // frequency; float32 data goes through the screen, double data straight to the exact map
+// Branch-free form of `bin_screen_f32` for the CWT (error of w relative: werr = 5e-7 w,
+// lerr = 1.4428 * 5e-7), grid kind as a template parameter: the same quantities and
+// the same decisions, as selects. `ok` = the screen decided; the return value is the
+// pre-flip bin when it did. Used inside the unrolled epilogues of the fused kernels,
+// where a dozen divergent early-outs per point cost more than the arithmetic.
+template <int GRID>
+__device__ __forceinline__ int bin_screen_cwt(float w, const SsqParams& sp, int omax, bool& ok) {
+    constexpr float REL = 5e-7f, LERR = 1.4428f * 5e-7f;
+    float t, g = sp.guard;
+    bool valid = (w > 1e-30f) & (w < 1e30f);
+    int kofs = 0;
+    bool seg1 = false;
+    if (GRID == SSQ_GRID_LIN) {
+        t = (w - sp.pf[0]) * sp.pf[1];
+        g = g + (w * REL + (fabsf(w) + fabsf(sp.pf[0])) * 2e-7f) * sp.pf[1];
+    } else {
+        const float wl = __log2f(w);
+        if (GRID == SSQ_GRID_LOG) {
+            t = (wl - sp.pf[0]) * sp.pf[1];
+            g = g + LERR * sp.pf[1];
+        } else {
+            const float dv = wl - sp.pf[1];
+            valid &= !(fabsf(dv) < 2e-5f + LERR);      // on the segment boundary
+            seg1 = dv > 0.f;
+            t = seg1 ? dv * sp.pf[3] : (wl - sp.pf[0]) * sp.pf[2];
+            g = g + LERR * (seg1 ? sp.pf[3] : sp.pf[2]);
+            kofs = seg1 ? (int)sp.pf[4] : 0;
+        }
+    }
+    g = g + fabsf(t) * 4e-7f;
+    valid &= (fabsf(t) < 1e9f) & (g < 0.25f);
+    const bool zero = !seg1 & (t < g);                 // exact map: 0 for t <= 0 and 0 < t < 1/2
+    const bool near = fabsf((t - floorf(t)) - 0.5f) < g;
+    ok = valid & (zero | !near);
+    int k = (int)rintf(t) + kofs;
+    k = k > omax ? omax : (k < 0 ? 0 : k);
+    return zero ? 0 : k;
+}
+
 // the two halves of the float32 `bin_of_point` below, for kernels that keep the
 // exact path out of their unrolled loops: `_screen` returns -2 when undecided
 __device__ __forceinline__ int bin_of_point_screen(float a, float b, float c, float d,
