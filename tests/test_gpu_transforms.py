@@ -271,6 +271,26 @@ def test_full_size_properties(S):
     assert torch.equal(Txb[0], Tx) and torch.equal(Wxb[1], Wy)
 
 
+def test_full_size_bin_map_exact(S, orc):
+    """BASELINE config 2 at full size, index work bit-exact: the fused kernels'
+    float32-screened bin map (48M points) must reproduce the exact double-precision
+    map of the CPU path. The oracle reassigns this engine's own (Wx, dWx): equal Tx,
+    cell for cell, means every one of the 48M indices and the summation order agree."""
+    N, na = 160000, 300
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    x = two_chirps(N, seed=3)
+    Tx, Wx, sf, sc = S.ssq_cwt(x, wav, scales=scales, astensor=False)          # lean kernels
+    Tx2, Wx2, _, _, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True, astensor=False)
+    assert np.array_equal(Wx, Wx2) and np.array_equal(Tx, Tx2)
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    kind, p = ssq_grid_params(sf[::-1], True)      # ssq_cwt returns the flipped (descending) grid
+    st = {0: 'log', 1: 'log-piecewise'}[kind]
+    gamma = 10 * np.finfo(np.float32).eps
+    ref = orc.ssqueeze(Wx, dWx, st, p, np.log(2) / 32, gamma, True, typing=0, parallel=True)
+    assert np.array_equal(Tx, ref)
+
+
 @pytest.mark.parametrize('N,nv', [(6000, 16), (20000, 8), (40000, 4)])
 def test_block_fast_path_vs_oracle(S, orc, N, nv):
     """The block ("overlap-save zoom") fast path -- active for float32 once the
