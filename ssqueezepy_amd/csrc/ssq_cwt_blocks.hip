@@ -418,16 +418,21 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
 // get the reference's full-length transform, as a four-step FFT over M = A x B with
 // one intermediate array Z in HBM (the only one on the fast path; ~4 MB per row):
 //   pass 1: for every k1 < A, B-point iFFT over k2 of X[k1 + A k2] = psih[k] xh[k]
-//           (and of the derivative spectrum), times e^{2 pi i k1 n2 / M} / M,
-//           transposed through LDS so that Z[k1][n2] is written in long runs;
+//           (and of the derivative spectrum), times e^{2 pi i k1 n2 / M} / M. The
+//           twiddle is the product of two small per-workgroup LDS tables
+//           (n2 = 32 n2_hi + n2_lo), not a gather from the M-entry table per point.
 //   pass 2: for every n2 < B, A-point iFFT over k1 of Z[k1][n2] -> y[n2 + B n1],
 //           fused with the same unpad / phase / bin-map epilogue as the block kernel.
+// Z is stored blocked for pass 2: [n2 / G2][k1][n2 % G2] with G2 the number of n2
+// columns a pass-2 workgroup owns, so that a pass-2 workgroup reads one contiguous
+// A*G2*8-byte slab and pass 1 (which transposes through LDS) writes G1*G2*8-byte runs.
 struct ExactArgs {
     const float* bank; const int64_t* band_off; const int32_t* band_lo;
     const int32_t* rows; const c32* xh; c32* Z; const c32* twM; const c32* ftw;
     const float* row_scale;
     float* Wx; float* dWx; float* w; unsigned short* kidx;
     int64_t M, N, na; int A, B, n1pad, sig, n_rows;   // sig: first signal (blockIdx.z adds)
+    int G2;                                           // n2 columns per pass-2 workgroup
     double h; float inv_dt; double gamma;
 };
 
@@ -464,7 +469,21 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
             }
         }
     }
+    // twiddle tables of this workgroup's G values of k1: e^{2 pi i k1 n2 / M} / M =
+    // thi[g][n2 >> 5] * tlo[g][n2 & 31]
+    constexpr int NH = (L + 31) / 32;
+    __shared__ c32 tlo[G * 32], thi[G * NH];
+    {
+        const float fM = (float)E.M;                          // power of two: exact
+        for (int i = tid; i < G * 32; i += NT)
+            tlo[i] = E.twM[(unsigned)(c0 + i / 32) * (unsigned)(i % 32)];
+        for (int i = tid; i < G * NH; i += NT) {
+            const c32 t = E.twM[(unsigned)(c0 + i / NH) * (unsigned)((i % NH) * 32)];   // < M
+            thi[i] = {t.x * fM, t.y * fM};
+        }
+    }
     constexpr int NBL = PPT / RL, STRL = L / RL;
+    const int G2 = E.G2;
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
         c32 (&v)[PPT] = tr ? zd : zw;
@@ -476,16 +495,18 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
                 const int n2 = u + k * STRL;
-                const c32 tw = E.twM[(unsigned)(c0 + g) * (unsigned)n2];   // k1 * n2 < M
+                const c32 tw = cmul(thi[g * NH + (n2 >> 5)], tlo[g * 32 + (n2 & 31)]);
                 buf[g * (L + 1) + n2] = cmul(v[it * RL + k], tw);
             }
         }
         __syncthreads();
-        c32* Zt = E.Z + (((int64_t)blockIdx.z * E.n_rows + r) * 2 + tr) * E.M + (int64_t)c0 * L;
+        c32* Zt = E.Z + (((int64_t)blockIdx.z * E.n_rows + r) * 2 + tr) * E.M;
 #pragma unroll
         for (int it = 0; it < PPT; ++it) {
-            const int idx = tid + it * NT, n2 = idx % L, g = idx / L;
-            Zt[g * L + n2] = buf[g * (L + 1) + n2];
+            // consecutive lanes: n2 % G2 fastest, then this workgroup's k1 -> G*G2-element runs
+            const int idx = tid + it * NT, n2i = idx % G2, g = (idx / G2) % G, n2t = idx / (G2 * G);
+            const int n2 = n2t * G2 + n2i;
+            Zt[(int64_t)n2t * E.A * G2 + (c0 + g) * G2 + n2i] = buf[g * (L + 1) + n2];
         }
     }
 }
@@ -506,7 +527,7 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                const int64_t q = (int64_t)(u + k * STR) * E.B + c0 + g;   // Z[k1][n2]
+                const int64_t q = (int64_t)blockIdx.x * E.A * G + (u + k * STR) * G + g;   // blocked Z
                 zw[it * R1 + k] = ZW[q]; zd[it * R1 + k] = ZD[q];
             }
         }
@@ -726,6 +747,7 @@ int BlockPlan::run_exact(int sig, int nsig, const void* xh_all, float* Wx, float
     E.xh = (const c32*)xh_all; E.Z = (c32*)zbuf; E.twM = (const c32*)twM; E.row_scale = row_scale;
     E.Wx = Wx; E.dWx = dWx; E.w = w; E.kidx = kidx;
     E.M = M; E.N = N; E.na = na; E.A = exA; E.B = exB; E.n1pad = (int)n1; E.sig = sig; E.n_rows = n_exact;
+    E.G2 = D_POINTS / exA;
     E.h = (2.0 * 3.141592653589793) / (double)M; E.inv_dt = 1.0f / (float)dt; E.gamma = sp.gamma;
     auto slot_of = [](int L) { return L == 128 ? 0 : L == 256 ? 1 : L == 512 ? 2 : L == 1024 ? 3 : 4; };
     int rc = 0;
