@@ -101,7 +101,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='signals per GPU per step')
+    ap.add_argument('--batch', type=int, default=16, help='signals per GPU per step')
     ap.add_argument('--n', type=int, default=160000)
     ap.add_argument('--na', type=int, default=300)
     ap.add_argument('--no-cpu', action='store_true')

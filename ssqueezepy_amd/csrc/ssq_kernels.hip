@@ -242,12 +242,18 @@ struct FoldLower<0, TM, T, term_t> {
     static __device__ __forceinline__ void run(int, term_t, term_t, T&, T&, unsigned long long&) {}
 };
 
-template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS>
-__global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
+// RL = row-lanes per column (16 or 8): a wavefront covers WC = 64/RL columns and the
+// 16-column tile takes 16/WC wavefronts. With RL = 8 two columns share a 16-lane DPP
+// row; their keys are made distinct so that a shift across the boundary never matches.
+// Fold work per column falls with RL (RL-1 distances per RL rows) and so does the
+// number of resident wavefronts (LDS per wavefront grows with WC).
+template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS, int RL>
+__global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_kernel(
     const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
     T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na64, int64_t n64,
     int32_t* __restrict__ kmap) {
-    constexpr int RL = 16, WC = 4;                 // row-lanes, columns per wavefront
+    constexpr int WC = 64 / RL;                    // columns per wavefront
+    constexpr int NTH = 64 * (16 / WC);            // threads per workgroup
     using TM = Term<T, CST64>;
     using term_t = typename TM::type;
     using w_t = typename TM::wtype;
@@ -256,7 +262,8 @@ __global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     T* tile = reinterpret_cast<T*>(lds_raw);       // [4 waves][na][4][2], cells skewed
     T* slab = tile + (size_t)wave * na * WC * 2;
-    const int cl = lane >> 4, rl = lane & 15;
+    const int cl = lane / RL, rl = lane % RL;
+    const int colkey = (RL < 16) ? ((cl & (16 / RL - 1)) << 20) : 0;   // column tag inside a DPP row
 
     // XCD-aware tile order (workgroup b runs on XCD b % 8: used for speed only):
     // consecutive 16-column tiles are issued to the same XCD back to back
@@ -308,12 +315,12 @@ __global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
             if (k >= 0) {
                 tr = TM::make(zc[u], wt[u]);
                 ti = TM::make(zd[u], wt[u]);
-                cell = slab + 2 * (k * WC + ((cl + k) & 3));
+                cell = slab + 2 * (k * WC + ((cl + k) & (WC - 1)));
                 ore = cell[0]; oim = cell[1];
             }
             request(u, i + RL * U);                 // refill the slot
             unsigned long long higher = 0;
-            FoldLower<15, TM, T, term_t>::run(k, tr, ti, ore, oim, higher);
+            FoldLower<RL - 1, TM, T, term_t>::run(k >= 0 ? (k | colkey) : -1, tr, ti, ore, oim, higher);
             ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
             const bool last = !((higher >> lane) & 1ull);
             if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
@@ -326,12 +333,12 @@ __global__ __launch_bounds__(256, WPS) void accumulate_tile16_kernel(
     {
         const int cc = threadIdx.x & 15, rr = threadIdx.x >> 4;
         const int jj = tile_id * 16 + cc;
-        const T* ws = tile + (size_t)(cc >> 2) * na * WC * 2;        // owning wave's slab
-        const int c4 = cc & 3;
+        const T* ws = tile + (size_t)(cc / WC) * na * WC * 2;        // owning wave's slab
+        const int c4 = cc % WC;
         if (jj < n) {
 #pragma unroll 4
-            for (int k = rr; k < na; k += 16) {
-                const T* cell = ws + 2 * (k * WC + ((c4 + k) & 3));
+            for (int k = rr; k < na; k += NTH / 16) {
+                const T* cell = ws + 2 * (k * WC + ((c4 + k) & (WC - 1)));
                 size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)jj);
                 Tb[2 * q] = cell[0];
                 Tb[2 * q + 1] = cell[1];
@@ -499,11 +506,19 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
             static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
             if (variant != 2) {        // default: 16 row-lanes x 4 waves per tile
                 constexpr int U = sizeof(T) == 4 ? 8 : 4;
-                auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 4>;
+                if (variant == 3) {    // 8 row-lanes x 8 columns per wavefront, 2 wavefronts per tile
+                    auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 2, 8>;
+                    SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kern, grid, dim3(128), lds, stream, (const T*)Wx, src, (const T*)Sfs,
+                                       (T*)Tx, cst, sp, na, n, kmap);
+                } else {
+                auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 4, 16>;
                 SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
                                    (T*)Tx, cst, sp, na, n, kmap);
+                }
             } else {                   // SSQ_ACC_VARIANT=2: one wave per tile, quads (tuning aid)
                 constexpr int U = sizeof(T) == 4 ? 16 : 8;
                 auto kern = accumulate_quad_kernel<T, BINSRC, STFT, CST64, U>;
