@@ -175,10 +175,11 @@ struct EmitRow {
     float2* W; float2* D; float* w; unsigned short* k;
     float rs; bool scale; double gamma; int64_t omax;
     float m2hi, m2lo;          // |Wx|^2 screens of mag_gt (ssq_point_math.inl)
+    int fx, fa;                // flipud as (k ^ fx) + fa: (-1, omax + 1) or (0, 0)
 };
 __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w, unsigned short* kidx,
                                                  const float* row_scale, int sig, int ksig, int row,
-                                                 int64_t na, int64_t N, double gamma) {
+                                                 int64_t na, int64_t N, double gamma, int flipud) {
     EmitRow e;
     const int64_t base = ((int64_t)sig * na + row) * N;
     e.W = reinterpret_cast<float2*>(Wx) + base;
@@ -190,6 +191,7 @@ __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w
     e.gamma = gamma; e.omax = na - 1;
     const float g2 = (float)(gamma * gamma);
     e.m2hi = g2 * 1.000004f; e.m2lo = g2 * 0.999996f;
+    e.fx = flipud ? -1 : 0; e.fa = flipud ? (int)na : 0;
     return e;
 }
 // Stores one point. Returns true when its bin could not be decided by the float32
@@ -202,19 +204,20 @@ __device__ __forceinline__ EmitRow make_emit_row(float* Wx, float* dWx, float* w
 template <bool LEAN, int GRID>
 __device__ __forceinline__ bool emit_point(const EmitRow& e, int j, c32 W, c32 D, const SsqParams& sp) {
     float c = W.x, d = W.y, a = D.x, b = D.y;
-    c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs;        // rs == 1 (exact) when unscaled
-    e.W[j] = make_float2(c, d);
-    if constexpr (LEAN) {
+    if constexpr (LEAN) {                    // lean kernels run without row scaling
+        e.W[(unsigned)j] = make_float2(c, d);
         const float m2 = c * c + d * d, num = b * c - a * d;
         const bool above = m2 > e.m2hi, below = m2 < e.m2lo;
         // hardware reciprocal: relative error of w under 3e-7 (see bin_of_point)
         const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
         bool ok;
         const int kb = bin_screen_cwt<GRID>(w32, sp, (int)e.omax, ok);
-        const int kf = sp.flipud ? (int)e.omax - kb : kb;
-        e.k[j] = (unsigned short)(above ? kf : 0xFFFF);   // overwritten by the exact path if undecided
+        const int kf = (kb ^ e.fx) + e.fa;
+        e.k[(unsigned)j] = (unsigned short)(above ? kf : 0xFFFF);   // overwritten by the exact path if undecided
         return !(below | (above & ok));
     } else {
+        c = c * e.rs; d = d * e.rs; a = a * e.rs; b = b * e.rs;        // rs == 1 (exact) when unscaled
+        e.W[j] = make_float2(c, d);
         if (e.D) e.D[j] = make_float2(a, b);
         if (e.w) {
             float wv;
@@ -373,9 +376,11 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
 
     // ---- epilogue: unpad, store, phase transform, bin map
     constexpr int NB = PPT / RL, STR = L / RL;
-    const EmitRow er = make_emit_row(A.Wx, A.dWx, A.w, A.kidx, A.row_scale, sig, (int)blockIdx.y, row, A.na, A.N, A.gamma);
-    const int m = (int)cl.m, hiv = (int)(cl.m + cl.V), N = (int)A.N;
+    const EmitRow er = make_emit_row(A.Wx, A.dWx, A.w, A.kidx, A.row_scale, sig, (int)blockIdx.y, row, A.na, A.N, A.gamma, sp.flipud);
+    const int m = (int)cl.m, N = (int)A.N;
     const int jbase = blk * (int)cl.V - m + c0;
+    // valid outputs of the block: samples [m, m + V) that fall inside the signal
+    const unsigned span = (unsigned)max(0, min((int)cl.V, N - blk * (int)cl.V));
     unsigned pend = 0;                              // slots whose bin needs the exact map
     auto emit_all = [&](auto grid_tag) {
         constexpr int GRID = decltype(grid_tag)::value;
@@ -384,9 +389,9 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
-                const int tb = (u + k * STR) * Rp + c0 + g;        // sample index inside the block
-                const int j = jbase + (u + k * STR) * Rp + g;       // output column
-                if (tb < m || tb >= hiv || j >= N) continue;
+                const int dcol = (u + k * STR) * Rp + g + (c0 - m);   // sample index inside the block - margin
+                if ((unsigned)dcol >= span) continue;               // margin or past the signal's end
+                const int j = dcol + blk * (int)cl.V;               // output column
                 if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], zd[it * RL + k], sp))
                     pend |= 1u << (it * RL + k);
             }
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     lds_ifft<L, G, R1, R2, R3>(zw, buf, E.ftw, tid);
     lds_ifft<L, G, R1, R2, R3>(zd, buf, E.ftw, tid);
     constexpr int NB = PPT / RL, STR = L / RL;
-    const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig + (int)blockIdx.z, (int)blockIdx.z, row, E.na, E.N, E.gamma);
+    const EmitRow er = make_emit_row(E.Wx, E.dWx, E.w, E.kidx, E.row_scale, E.sig + (int)blockIdx.z, (int)blockIdx.z, row, E.na, E.N, E.gamma, sp.flipud);
     const int N = (int)E.N;
     unsigned pend = 0;
     auto emit_all = [&](auto grid_tag) {
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
             for (int k = 0; k < RL; ++k) {
                 const int n = (c0 + g) + E.B * (u + k * STR);
                 const int j = n - E.n1pad;
-                if (j < 0 || j >= N) continue;
+                if ((unsigned)j >= (unsigned)N) continue;
                 if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], zd[it * RL + k], sp))
                     pend |= 1u << (it * RL + k);
             }
@@ -590,7 +595,7 @@ template <int L, int G, int R1, int R2, int R3>
 static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
     const dim3 grid((unsigned)A.n_items, (unsigned)nsig);
-    if (A.kidx && !A.dWx && !A.w)
+    if (A.kidx && !A.dWx && !A.w && !A.row_scale)
         hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, true>), grid, dim3(NT), 0, stream, A, sp);
     else
         hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, false>), grid, dim3(NT), 0, stream, A, sp);
@@ -731,7 +736,7 @@ static int launch_exact1(const ExactArgs& E, int n_rows, int nsig, hipStream_t s
 template <int L, int G, int R1, int R2, int R3>
 static int launch_exact2(const ExactArgs& E, const SsqParams& sp, int n_rows, int nsig, hipStream_t stream) {
     const dim3 grid((unsigned)(E.B / G), (unsigned)n_rows, (unsigned)nsig);
-    if (E.kidx && !E.dWx && !E.w)
+    if (E.kidx && !E.dWx && !E.w && !E.row_scale)
         hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3, true>), grid, dim3(NT), 0, stream, E, sp);
     else
         hipLaunchKernelGGL((exact_pass2_kernel<L, G, R1, R2, R3, false>), grid, dim3(NT), 0, stream, E, sp);

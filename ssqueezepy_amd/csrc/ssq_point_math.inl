@@ -152,7 +152,7 @@ template <int GRID>
 __device__ __forceinline__ int bin_screen_cwt(float w, const SsqParams& sp, int omax, bool& ok) {
     constexpr float REL = 5e-7f, LERR = 1.4428f * 5e-7f;
     float t, g = sp.guard;
-    bool valid = (w > 1e-30f) & (w < 1e30f);
+    bool valid = true;
     int kofs = 0;
     bool seg1 = false;
     if (GRID == SSQ_GRID_LIN) {
@@ -165,21 +165,24 @@ __device__ __forceinline__ int bin_screen_cwt(float w, const SsqParams& sp, int 
             g = g + LERR * sp.pf[1];
         } else {
             const float dv = wl - sp.pf[1];
-            valid &= !(fabsf(dv) < 2e-5f + LERR);      // on the segment boundary
+            valid = !(fabsf(dv) < 2e-5f + LERR);       // on the segment boundary
             seg1 = dv > 0.f;
             t = seg1 ? dv * sp.pf[3] : (wl - sp.pf[0]) * sp.pf[2];
             g = g + LERR * (seg1 ? sp.pf[3] : sp.pf[2]);
             kofs = seg1 ? (int)sp.pf[4] : 0;
         }
     }
+    // w = 0, inf, NaN or out of float range make t (and with it g) infinite or NaN, and
+    // |t| >= 1e6 alone pushes g past 1/4: one comparison covers every "cannot decide"
     g = g + fabsf(t) * 4e-7f;
-    valid &= (fabsf(t) < 1e9f) & (g < 0.25f);
-    const bool zero = !seg1 & (t < g);                 // exact map: 0 for t <= 0 and 0 < t < 1/2
-    const bool near = fabsf((t - floorf(t)) - 0.5f) < g;
+    valid &= g < 0.25f;
+    const float rt = rintf(t);
+    const bool zero = !seg1 & (t < g);     // exact map: 0 for t <= 0 and for 0 < t < 1/2
+    const bool near = (0.5f - fabsf(t - rt)) < g;      // within g of a rounding boundary
     ok = valid & (zero | !near);
-    int k = (int)rintf(t) + kofs;
-    k = k > omax ? omax : (k < 0 ? 0 : k);
-    return zero ? 0 : k;
+    // t < g < 1/4 rounds to <= 0, so the clamp already yields 0 in the `zero` case
+    const int k = (int)rt + kofs;
+    return min(max(k, 0), omax);
 }
 
 // the two halves of the float32 `bin_of_point` below, for kernels that keep the
