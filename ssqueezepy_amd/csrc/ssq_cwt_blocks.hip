@@ -488,7 +488,8 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
         }
     }
     constexpr int NBL = PPT / RL, STRL = L / RL;
-    const int G2 = E.G2;
+    const int G2 = E.G2, lg2 = __ffs(G2) - 1;
+    constexpr int LG = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5;
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {
         c32 (&v)[PPT] = tr ? zd : zw;
@@ -509,9 +510,10 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
 #pragma unroll
         for (int it = 0; it < PPT; ++it) {
             // consecutive lanes: n2 % G2 fastest, then this workgroup's k1 -> G*G2-element runs
-            const int idx = tid + it * NT, n2i = idx % G2, g = (idx / G2) % G, n2t = idx / (G2 * G);
-            const int n2 = n2t * G2 + n2i;
-            Zt[(int64_t)n2t * E.A * G2 + (c0 + g) * G2 + n2i] = buf[g * (L + 1) + n2];
+            // (G2 and G are powers of two: shifts, not divisions)
+            const int idx = tid + it * NT, n2i = idx & (G2 - 1), g = (idx >> lg2) & (G - 1);
+            const int n2t = idx >> (lg2 + LG), n2 = (n2t << lg2) + n2i;
+            Zt[((int64_t)n2t * E.A + (c0 + g)) * G2 + n2i] = buf[g * (L + 1) + n2];
         }
     }
 }
