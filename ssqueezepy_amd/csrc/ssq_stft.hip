@@ -8,9 +8,16 @@
 //   frames --rocFFT R2C, batch = n_hops, output stride n_hops--> Sx[f][c], dSx[f][c]
 //        (the strided store writes the (rows, n_hops) layout directly: no transpose)
 //   Sx, dSx --accumulate_tile_kernel (STFT form)--> Tx
+// float32 with a power-of-two n_fft in [128, 2048] takes the fused kernel instead:
+// framing, both windows and both transforms in ONE launch for the whole batch -- the
+// two real frames a = frame*window, b = frame*diff_window ride one complex LDS FFT as
+// a + ib and are separated by Hermitian symmetry (stft_fused_kernel below).
 // Compiled with -ffp-contract=off (see ssq_kernels.hip).
 #include "ssq_common.h"
 #include "ssq_fft.h"
+#include "ssq_ldsfft.h"
+#include <vector>
+#include <cmath>
 #include <algorithm>
 #include <rocfft/rocfft.h>
 
@@ -33,6 +40,78 @@ __global__ __launch_bounds__(256) void frame_window_kernel(
         frames[t] = v * window[r];
         if (dframes) dframes[t] = v * diff_window[r];
     }
+}
+
+// ---- fused framing + window + FFT (float32, n_fft = L a power of two) -----------------
+// One workgroup = G = 4096/L consecutive frames of one signal. The forward transform is
+// taken as conj(IFFT(conj(.))) with the inverse LDS FFT of ssq_ldsfft.h: input
+// a - ib, output Z' with FFT(a + ib) = conj(Z'). With A = FFT(a), B = FFT(b) Hermitian,
+//   A[f] = (Z[f] + conj(Z[L-f])) / 2,   B[f] = (Z[f] - conj(Z[L-f])) / (2i),  f <= L/2.
+struct StftFusedArgs {
+    const float* xp; const float* window; const float* diff_window; const c32* ftw;
+    float2* Sx; float2* dSx;            // dSx null: no derivative
+    int64_t padlen, n_hops, rows;
+    int hop, s20, s21, modulated;
+};
+
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A) {
+    __shared__ c32 buf[D_POINTS];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x, c0 = blockIdx.x * G;
+    const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
+    const bool deriv = A.dSx != nullptr;
+    c32 z[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+            const int c = c0 + g;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int r = u + k * STR;                    // sample of the frame
+                // modulated: the frame is rotated by ceil(n_fft/2) (utils/stft_utils.py:76-82)
+                const int s = !A.modulated ? r : (r < A.s20 ? A.s21 + r : r - A.s20);
+                float a = 0.f, b = 0.f;
+                if (c < A.n_hops) {
+                    const float v = xp[(int64_t)A.hop * c + s];
+                    a = v * A.window[r];
+                    if (deriv) b = v * A.diff_window[r];
+                }
+                z[it * R1 + k] = {a, -b};
+            }
+        }
+    }
+    lds_ifft<L, G, R1, R2, R3>(z, buf, A.ftw, tid);
+    __syncthreads();                                  // last pass' LDS reads are done
+    {
+        constexpr int NB = PPT / RL, STR = L / RL;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < RL; ++k) buf[(u + k * STR) * G + g] = z[it * RL + k];
+        }
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.y * A.rows * A.n_hops;
+    for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
+        const int f = i / G, g = i % G, c = c0 + g;
+        if (c >= A.n_hops) continue;
+        const c32 P = buf[f * G + g], Q = buf[((L - f) & (L - 1)) * G + g];
+        const int64_t q = base + (int64_t)f * A.n_hops + c;
+        A.Sx[q] = make_float2(0.5f * (P.x + Q.x), 0.5f * (Q.y - P.y));
+        if (deriv) A.dSx[q] = make_float2(-0.5f * (P.y + Q.y), 0.5f * (Q.x - P.x));
+    }
+}
+
+template <int L, int G, int R1, int R2, int R3>
+static int launch_stft_fused(const StftFusedArgs& A, int64_t batch, hipStream_t stream) {
+    dim3 grid((unsigned)((A.n_hops + G - 1) / G), (unsigned)batch);
+    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, A);
+    SSQ_LAUNCH_CHECK();
+    return 0;
 }
 
 // R2C with transposed (strided) output: transform c writes bin f at out[f*n_hops + c]
@@ -87,6 +166,7 @@ struct ssq_stft_plan {
     void* window = nullptr; void* diff_window = nullptr;
     void* xp = nullptr; void* frames = nullptr; void* dframes = nullptr; void* dSx_ws = nullptr;
     StridedR2C fft;
+    bool fused = false; void* ftw = nullptr;      // fused float32 path (power-of-two n_fft)
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;
 };
 
@@ -127,6 +207,17 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
 #undef TRYA
     rc = pl->fft.create(d.dtype, (size_t)d.n_fft, (size_t)pl->n_hops);
     if (rc) { ssq_stft_plan_destroy(pl); return rc; }
+    const bool pow2 = (d.n_fft & (d.n_fft - 1)) == 0;
+    if (d.dtype == SSQ_F32 && pow2 && d.n_fft >= 128 && d.n_fft <= 2048 && !getenv("SSQ_STFT_GENERIC")) {
+        std::vector<float> tw((size_t)2 * d.n_fft);
+        for (int64_t q = 0; q < d.n_fft; ++q) {
+            double ang = 2.0 * 3.14159265358979323846 * (double)q / (double)d.n_fft;
+            tw[2 * q] = (float)cos(ang); tw[2 * q + 1] = (float)sin(ang);
+        }
+        if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
+        SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        pl->fused = true;
+    }
     pl->d.window = nullptr; pl->d.diff_window = nullptr;
     *out = pl;
     return 0;
@@ -136,7 +227,7 @@ void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
     if (!pl) return;
     pl->fft.destroy();
     void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
-                    pl->cst, pl->Sfs};
+                    pl->cst, pl->Sfs, pl->ftw};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -178,7 +269,25 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     if (rc) return rc;
     const int64_t s20 = (n_fft + 1) / 2, s21 = (n_fft % 2 == 1) ? s20 - 1 : s20;
     T* dS = dSx ? (T*)dSx : (T*)pl->dSx_ws;
-    for (int64_t b = 0; b < batch; ++b) {
+    if constexpr (sizeof(T) == 4) {
+        if (pl->fused) {
+            StftFusedArgs A;
+            A.xp = (const float*)pl->xp; A.window = (const float*)pl->window;
+            A.diff_window = (const float*)pl->diff_window; A.ftw = (const c32*)pl->ftw;
+            A.Sx = (float2*)Sx; A.dSx = deriv ? (float2*)dS : nullptr;
+            A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
+            A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated;
+            switch (n_fft) {
+                case 128: rc = launch_stft_fused<128, 32, 16, 8, 1>(A, batch, stream); break;
+                case 256: rc = launch_stft_fused<256, 16, 16, 16, 1>(A, batch, stream); break;
+                case 512: rc = launch_stft_fused<512, 8, 8, 8, 8>(A, batch, stream); break;
+                case 1024: rc = launch_stft_fused<1024, 4, 16, 8, 8>(A, batch, stream); break;
+                default: rc = launch_stft_fused<2048, 2, 16, 16, 8>(A, batch, stream); break;
+            }
+            if (rc) return rc;
+        }
+    }
+    for (int64_t b = 0; b < (pl->fused ? 0 : batch); ++b) {
         const T* xp = (const T*)pl->xp + (size_t)b * pl->padlen;
         int64_t total = n_fft * n_hops;
         unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
