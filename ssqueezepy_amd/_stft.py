@@ -97,6 +97,37 @@ def _check_NOLA(window, hop_len, dtype=None, imprecision_strict=False):
              "Lower `hop_len`, choose wider `window`, or use `dtype='float64'`.")
 
 
+_WINDOW_CACHE = {}
+
+
+def _window_design(window, win_len, n_fft, hop_len, dtype):
+    """`get_window(derivative=True)` + `_check_NOLA` memoised per configuration: the
+    DPSS design and the overlap-add checks cost far more host time than the device
+    transform itself (the analogue of the reference's wavelet cache)."""
+    wkey = (window.tobytes(), window.dtype.str) if isinstance(window, np.ndarray) else window
+    key = (wkey, int(win_len), int(n_fft), int(hop_len), dtype)
+    hit = _WINDOW_CACHE.get(key)
+    if hit is None:
+        msgs = []
+        import logging
+
+        class _Collect(logging.Handler):
+            def emit(self, record):
+                msgs.append(record.getMessage())
+        w, dw = get_window(window, win_len, n_fft, derivative=True, dtype=dtype)
+        root, h = logging.getLogger(), _Collect()
+        root.addHandler(h)
+        try:
+            _check_NOLA(w, hop_len, dtype)
+        finally:
+            root.removeHandler(h)
+        if len(_WINDOW_CACHE) >= 32:
+            _WINDOW_CACHE.pop(next(iter(_WINDOW_CACHE)))
+        hit = _WINDOW_CACHE[key] = (w, dw, tuple(msgs))
+        return hit[0], hit[1], ()       # first call: _check_NOLA has already warned
+    return hit
+
+
 class StftPlan():
     """Host handle of a device STFT plan for one
     ``(N, n_fft, hop_len, window, padtype, modulated, dtype)`` configuration."""
@@ -215,9 +246,10 @@ def _stft_setup(x, window, n_fft, win_len, hop_len, fs, t, padtype, modulated,
     if dtype is None:
         dtype = defaults('stft')['dtype']
     dtype = str(np.dtype(dtype))
-    window, diff_window = get_window(window, win_len, n_fft, derivative=True,
-                                     dtype=dtype)
-    _check_NOLA(window, hop_len, dtype)
+    window, diff_window, nola_msgs = _window_design(window, win_len, n_fft, hop_len,
+                                                    dtype)
+    for msg in nola_msgs:            # the reference warns on every call
+        logging.warning(msg)
     xd = algos.to_device(x, _TDT[dtype])
     B = xd.shape[0] if xd.ndim == 2 else 1
     plan = get_stft_plan(N, n_fft, hop_len, window, diff_window, fs, padtype,
