@@ -8,6 +8,7 @@
 device (`ssq_cwt_execute`), which writes only the arrays that are returned.
 """
 import numpy as np
+from types import FunctionType
 import torch
 
 from . import algos
@@ -15,7 +16,7 @@ from .configs import EPS32, EPS64
 from ._cwt import get_cwt_plan, _process_gmw_wavelet, _zero_nonfinite_inplace, _TDT
 from .padding import PADTYPES
 from .scales import process_scales, infer_scaletype, _process_fs_and_t
-from .ssqueezing import (_check_ssqueezing_args, _compute_associated_frequencies,
+from .ssqueezing import (_check_ssqueezing_args, _compute_associated_frequencies, GRID_LIN,
                          ssq_grid_params, ssq_const)
 from .wavelets import Wavelet
 
@@ -97,8 +98,8 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
         w: phase transform (if `get_w`);  dWx: time derivative (if `get_dWx`)
 
     `Tx`, `Wx`, `w`, `dWx` are torch GPU tensors (`astensor=True`) or NumPy arrays.
-    Supported on the device path: `difftype='trig'`, `squeezing='sum'`, `order=0`;
-    other values raise, as the reference's GPU mode does for `difftype`.
+    Supported on the device path: `difftype='trig'`, `order=0` (other values raise, as
+    the reference's GPU mode does for `difftype`); every `squeezing` mode.
     """
     if x.ndim == 2 and get_w:
         raise NotImplementedError("`get_w=True` unsupported with batched input.")
@@ -109,9 +110,6 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
         raise ValueError("`x` must be 1D or 2D (got x.ndim == %s)" % x.ndim)
     difforder = _check_ssqueezing_args(squeezing, maprange, wavelet, difftype,
                                        difforder, get_w, transform='cwt')
-    if squeezing != 'sum':
-        raise NotImplementedError("only `squeezing='sum'` is fused on the device; "
-                                  "use `cwt` + `ssqueeze` for other modes")
     if isinstance(order, (tuple, list, range)) or order > 0:
         raise NotImplementedError("`order > 0` (higher-order GMWs) is not part of "
                                   "the accelerated path")
@@ -145,8 +143,28 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
     B = xd.shape[0] if xd.ndim == 2 else 1
     plan = get_cwt_plan(wavelet, scales_dt, N, padtype, dt, True, B, cache=use_cache)
     plan.set_ssq(grid, params, const, flipud, gamma)
-    out = plan.execute(xd, want_dWx=get_dWx, want_Tx=True, want_w=get_w)
-    Tx, Wx, w, dWx = out['Tx'], out['Wx'], out.get('w'), out.get('dWx')
+    if squeezing == 'sum':
+        out = plan.execute(xd, want_dWx=get_dWx, want_Tx=True, want_w=get_w)
+        Tx, Wx, w, dWx = out['Tx'], out['Wx'], out.get('w'), out.get('dWx')
+    else:
+        # 'lebesgue' / 'abs' / callable replace the summed quantity (and, as in the
+        # reference, the `Wx` the fused phase transform sees: ssqueezing.py:197-202);
+        # the transform stays fused, the reassignment runs as its own launch
+        out = plan.execute(xd, want_dWx=True, want_Tx=False, want_w=get_w)
+        Wx, w = out['Wx'], out.get('w')
+        if isinstance(squeezing, FunctionType):
+            Wq = squeezing(Wx)
+        elif squeezing == 'lebesgue':
+            Wq = algos.ones_like(Wx) / len(Wx)
+        else:
+            Wq = algos.cabs(Wx)
+        logscale = grid != GRID_LIN
+        if get_w:
+            Tx = algos.indexed_sum_onfly(Wq, w, ssq_freqs, const, logscale, flipud)
+        else:
+            Tx = algos.ssqueeze_fast(Wq, out['dWx'], ssq_freqs, const, logscale,
+                                     flipud, gamma)
+        dWx = out['dWx'] if get_dWx else None
 
     # `scales` go high -> low, so frequencies are returned high -> low
     ssq_freqs = ssq_freqs[::-1]

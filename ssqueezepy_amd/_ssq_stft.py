@@ -6,6 +6,7 @@
 transform and the reassignment run as one device plan execution.
 """
 import numpy as np
+from types import FunctionType
 import torch
 
 from . import algos
@@ -32,8 +33,6 @@ def ssq_stft(x, window=None, n_fft=None, win_len=None, hop_len=1, fs=None, t=Non
     if x.ndim == 2 and get_w:
         raise NotImplementedError("`get_w=True` unsupported with batched input.")
     _check_ssqueezing_args(squeezing)
-    if squeezing != 'sum':
-        raise NotImplementedError("only `squeezing='sum'` is fused on the device")
     if (isinstance(ssq_freqs, np.ndarray) and
             infer_scaletype(ssq_freqs)[0] != 'linear'):
         raise ValueError("`ssq_freqs` must be linearly distributed "
@@ -50,8 +49,24 @@ def ssq_stft(x, window=None, n_fft=None, win_len=None, hop_len=1, fs=None, t=Non
     const = (ssq_freqs[1] - ssq_freqs[0])
     grid, params = ssq_grid_params(ssq_freqs, False)
     plan.set_ssq(Sfs, grid, params, const, flipud, gamma)
-    out = plan.execute(xd, want_dSx=get_dWx, want_Tx=True, want_w=get_w)
-    Tx, Sx, w, dSx = out['Tx'], out['Sx'], out.get('w'), out.get('dSx')
+    if squeezing == 'sum':
+        out = plan.execute(xd, want_dSx=get_dWx, want_Tx=True, want_w=get_w)
+        Tx, Sx, w, dSx = out['Tx'], out['Sx'], out.get('w'), out.get('dSx')
+    else:                       # see ssq_cwt: the reassignment runs as its own launch
+        out = plan.execute(xd, want_dSx=True, want_Tx=False, want_w=get_w)
+        Sx, w = out['Sx'], out.get('w')
+        if isinstance(squeezing, FunctionType):
+            Sq = squeezing(Sx)
+        elif squeezing == 'lebesgue':
+            Sq = algos.ones_like(Sx) / len(Sx)
+        else:
+            Sq = algos.cabs(Sx)
+        if get_w:
+            Tx = algos.indexed_sum_onfly(Sq, w, ssq_freqs, const, False, flipud)
+        else:
+            Tx = algos.ssqueeze_fast(Sq, out['dSx'], ssq_freqs, const, False, flipud,
+                                     gamma, Sfs=Sfs)
+        dSx = out['dSx'] if get_dWx else None
     if flipud:
         ssq_freqs = ssq_freqs[::-1]
     if not astensor:

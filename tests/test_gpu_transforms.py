@@ -352,6 +352,12 @@ def test_ssqueeze_squeezing_modes_and_stft_config3(S, orc):
               _np(torch.abs(Wx)).astype(Wn.dtype))
         ref = orc.ssqueeze(Wm, dWn, 'log', r['params'], r['const'], r['gamma'], True, typing=NUMBA)
         assert np.array_equal(_np(T2), ref), mode
+        # the same mode through ssq_cwt itself (returned Wx stays the transform)
+        T3, W3, *_ = S.ssq_cwt(x, wav, scales='log', nv=8, squeezing=mode)
+        assert torch.equal(T3, T2) and torch.equal(W3, Wx), mode
+    T4, *_ = S.ssq_cwt(x, wav, scales='log', nv=8, squeezing=lambda W: 2 * W)
+    ref = orc.ssqueeze(2 * Wn, dWn, 'log', r['params'], r['const'], r['gamma'], True, typing=NUMBA)
+    assert np.array_equal(_np(T4), ref)
     # config 3
     N = 160000
     x = two_chirps(N, seed=3)
@@ -365,6 +371,12 @@ def test_ssqueeze_squeezing_modes_and_stft_config3(S, orc):
     ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], ro['gamma'], False, Sfs=Sfs,
                        typing=NUMBA)
     assert np.array_equal(Tx, ref)
+    Ta, Sa, *_ = S.ssq_stft(x, n_fft=1024, hop_len=256, dtype='float32', squeezing='abs',
+                            astensor=False)
+    ref = orc.ssqueeze(np.abs(Sx).astype(Sx.dtype), dSx, 'linear', p, Sfs[1] - Sfs[0],
+                       ro['gamma'], False, Sfs=Sfs, typing=NUMBA)
+    assert np.array_equal(Sa, Sx)
+    assert (np.abs(Ta - ref) > 1e-6 * np.abs(ref).max()).mean() < 1e-4   # |.| last-bit ties
 
 
 def test_float64_long_signal_properties(S):
