@@ -123,6 +123,33 @@ int ssq_buffer(int dtype, const void* x, void* out, int64_t batch, int64_t n_x,
 int ssq_pad_signal(int dtype, const void* x, void* out, int64_t batch, int64_t n,
                    int64_t n1, int64_t n2, int padtype, void* stream);
 
+/* ------------------------------------------------------------------ inverses
+ * Column reductions of arrays that already live on the device; sums run in the
+ * reference's order (ascending row, the array's precision), results are bit-identical
+ * to the NumPy expressions they replace.
+ *
+ * out (batch, n) <- sum_i Re(Z[b, i, :]) [/ divisor[i]].   replaces
+ *   `(Wx.real / norm(scales)).sum(axis=-2)` of _icwt_1int (_cwt.py:472-476) and
+ *   `Tx.real.sum(axis=0)` of issq_cwt / issq_stft (_ssq_cwt.py:369-371, _ssq_stft.py:191).
+ * `divisor`: real (na,) in the data dtype, or NULL. */
+int ssq_colsum(int dtype, const void* Z, const void* divisor, void* out, int64_t batch,
+               int64_t na, int64_t n, void* stream);
+
+/* Component inversion around curves: out (ncomp + 1, n) float64; row k < ncomp sums
+ * Re(Z[lo[k][j] .. hi[k][j], j]) in double, row ncomp sums the rows no band covers in
+ * the data dtype. lo/hi: int32 (ncomp, n), inclusive, empty when lo > hi.
+ * replaces _invert_components (_ssq_cwt.py:381-403). */
+int ssq_band_colsum(int dtype, const void* Z, const int32_t* lo, const int32_t* hi,
+                    int64_t ncomp, double* out, int64_t na, int64_t n, void* stream);
+
+/* Inverse STFT: x (N) <- Sx (n_fft/2 + 1, n_hops) complex. irfft of every column
+ * (rocFFT), fftshift of the frame if `modulated`, overlap-add with win_a = window^a,
+ * division by the overlap-added win_a1 = window^(a+1), trim of n_fft/2 leading samples.
+ * replaces the body of istft (_stft.py:238-256: irfft, unbuffer, window_norm). */
+int ssq_istft(int dtype, const void* Sx, const void* win_a, const void* win_a1, void* x,
+              int64_t n_fft, int64_t n_hops, int64_t hop_len, int64_t N, int modulated,
+              void* stream);
+
 /* ----------------------------------------------------------------- CWT plan
  * Replaces the body of cwt() (_cwt.py:255-306: pad -> fft -> Psih*xh -> ifft
  * [-> *1j*xi/dt -> ifft] -> unpad) and, when ssq parameters are set, the

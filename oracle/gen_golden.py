@@ -275,8 +275,71 @@ def gen_stft():
         save('stft_' + dtype, **d)
 
 
+def gen_inverse():
+    """Inverses (reference: icwt _cwt.py:323-497, issq_cwt _ssq_cwt.py:313-378,
+    istft _stft.py:184-256, issq_stft _ssq_stft.py:139-198) on the reference's own
+    forward outputs, plus the admissibility constants they rely on."""
+    from ssqueezepy import icwt, issq_cwt, istft, issq_stft
+    from ssqueezepy.utils import adm_ssq, adm_cwt
+    d = {}
+    for name, spec in (('gmw', 'gmw'), ('gmw_l2', ('gmw', {'norm': 'energy'})),
+                       ('morlet', 'morlet'), ('bump', 'bump')):
+        d['adm_ssq/' + name] = np.float64(adm_ssq(spec))
+        d['adm_cwt/' + name] = np.float64(adm_cwt(spec))
+    for dtype in ('float32', 'float64'):
+        N = 400
+        x = two_chirps(N, seed=21)
+        d[f'x/{dtype}'] = x
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        for st in ('log', 'log-piecewise', 'linear'):
+            nv = 8 if st != 'linear' else None
+            Tx, Wx, sf, sc = ssq_cwt(x, wav, scales=st, nv=nv)
+            pre = f'{dtype}/{st}'
+            d['Tx/' + pre], d['Wx/' + pre], d['scales/' + pre] = Tx, Wx, sc
+            d['icwt/' + pre] = icwt(Wx, wav, scales=sc, nv=nv, x_mean=x.mean())
+            d['issq/' + pre] = issq_cwt(Tx, wav)
+        # L2 norm, double integral, component inversion
+        wav2 = Wavelet(('gmw', {'dtype': dtype, 'norm': 'energy'}))
+        Wx, sc = cwt(x, wav2, scales='log', nv=8, l1_norm=False)
+        d[f'Wx/{dtype}/l2'], d[f'scales/{dtype}/l2'] = Wx, sc
+        d[f'icwt/{dtype}/l2'] = icwt(Wx, wav2, scales=sc, nv=8, l1_norm=False)
+        Tx = d[f'Tx/{dtype}/log']
+        na = len(Tx)
+        rng = np.random.default_rng(5)
+        cc = np.stack([np.clip(na // 3 + rng.integers(-3, 4, N), 0, na - 1),
+                       np.clip(2 * na // 3 + rng.integers(-3, 4, N), 0, na - 1)], 1)
+        cc[100:140, 1] = -1                     # "no curve" marker
+        cw = np.stack([np.full(N, 4), np.full(N, 6)], 1)
+        d[f'cc/{dtype}'], d[f'cw/{dtype}'] = cc, cw
+        d[f'issq_comp/{dtype}'] = issq_cwt(Tx, wav, cc, cw)
+        xb = np.vstack([two_chirps(300, seed=s) for s in (31, 32)])
+        Txb, Wxb, _, scb = ssq_cwt(xb, wav, scales='log', nv=8)
+        d[f'xb/{dtype}'], d[f'Wxb/{dtype}'], d[f'scb/{dtype}'] = xb, Wxb, scb
+        d[f'icwt_b/{dtype}'] = icwt(Wxb, wav, scales=scb, nv=8)
+        # STFT side
+        for (N, n_fft, hop, win_len, win, mod, we) in (
+                (1024, 128, 16, None, None, True, 1), (1000, 100, 10, 80, 'hann', True, 1),
+                (777, 64, 8, None, None, False, 0), (300, 64, 1, None, None, True, 2)):
+            x = two_chirps(N, seed=N + 5)
+            pre = f'{dtype}/{N}/{n_fft}/{hop}'
+            Sx = stft(x, win, n_fft=n_fft, win_len=win_len, hop_len=hop, modulated=mod,
+                      dtype=dtype)
+            d['xs/' + pre], d['Sx/' + pre] = x, Sx
+            d['istft/' + pre] = istft(Sx, win, n_fft=n_fft, win_len=win_len, hop_len=hop,
+                                      N=N, modulated=mod, win_exp=we)
+        x = two_chirps(300, seed=905)
+        Tx, Sx, *_ = ssq_stft(x, n_fft=64, hop_len=1, dtype=dtype)
+        d[f'Txs/{dtype}'] = Tx
+        d[f'issq_stft/{dtype}'] = issq_stft(Tx, n_fft=64, hop_len=1)
+        ccs = np.clip(12 + rng.integers(-2, 3, (Tx.shape[1], 1)), 0, 32)
+        cws = np.full((Tx.shape[1], 1), 3)
+        d[f'ccs/{dtype}'], d[f'cws/{dtype}'] = ccs, cws
+        d[f'issq_stft_comp/{dtype}'] = issq_stft(Tx, cc=ccs, cw=cws, n_fft=64, hop_len=1)
+    save('inverse', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

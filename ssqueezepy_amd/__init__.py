@@ -1,9 +1,9 @@
 # -*- coding: utf-8 -*-
 """ssqueezepy_amd -- MI355X-native synchrosqueezed CWT / STFT engine.
 
-Drop-in for the forward-transform path of ssqueezepy (`cwt`, `stft`, `ssq_cwt`,
-`ssq_stft`, `ssqueeze`, `phase_cwt`, `phase_stft`, `Wavelet` and the scale-design
-utilities): same Python API, computed by hand-written HIP kernels (gfx950) behind a
+Drop-in for the transform path of ssqueezepy (`cwt`, `stft`, `ssq_cwt`, `ssq_stft`,
+`ssqueeze`, `phase_cwt`, `phase_stft`, their inverses `icwt`, `issq_cwt`, `istft`,
+`issq_stft`, `Wavelet` and the scale-design utilities): same Python API, computed by hand-written HIP kernels (gfx950) behind a
 C ABI (include/ssq_hip.h, libssq_hip.so). The design step (scales, filter bank,
 frequency grid, windows) is host NumPy and value-exact with the reference; all
 O(na * N) work is on the GPU and there is no CPU fallback.
@@ -14,7 +14,7 @@ from .configs import EPS32, EPS64
 from .padding import p2up, padsignal
 from .wavelets import Wavelet, center_frequency
 from .scales import (process_scales, make_scales, cwt_scalebounds, infer_scaletype,
-                     logscale_transition_idx)
+                     logscale_transition_idx, adm_ssq, adm_cwt)
 
 
 def __getattr__(name):
@@ -27,6 +27,8 @@ def __getattr__(name):
         'ssqueeze_fast': 'algos', 'indexed_sum_onfly': 'algos', 'buffer': 'algos',
         'replace_under_abs': 'algos', 'phase_cwt_gpu': 'algos',
         'phase_stft_gpu': 'algos',
+        'icwt': '_inverse', 'issq_cwt': '_inverse', 'istft': '_inverse',
+        'issq_stft': '_inverse',
     }
     if name in _lazy:
         import importlib

@@ -77,6 +77,12 @@ _PROTOS = {
                            c_int64, c_int, c_void_p]),
     'ssq_pad_signal': (c_int, [c_int, c_void_p, c_void_p, c_int64, c_int64,
                                c_int64, c_int64, c_int, c_void_p]),
+    'ssq_colsum': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                           c_int64, c_void_p]),
+    'ssq_band_colsum': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_void_p, c_int64, c_int64, c_void_p]),
+    'ssq_istft': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                          c_int64, c_int64, c_int64, c_int, c_void_p]),
     'ssq_cwt_plan_create': (c_int, [POINTER(c_void_p), POINTER(CwtDesc)]),
     'ssq_cwt_plan_destroy': (None, [c_void_p]),
     'ssq_cwt_plan_set_ssq': (c_int, [c_void_p, c_int, POINTER(c_double), c_void_p,

@@ -226,3 +226,56 @@ def pad_signal_gpu(x, n1, n2, padtype='reflect'):
     check(lib.ssq_pad_signal(_CDT[x.dtype], _ptr(x), _ptr(out), B, n, n1, n2,
                              _lib.PAD[padtype], stream()))
     return out[0] if x.ndim == 1 else out
+
+
+# ------------------------------------------------------------------ inverses
+def colsum_real(Z, divisor=None):
+    """``sum_i Re(Z[..., i, :]) [/ divisor[i]]`` over the scale / frequency axis, rows in
+    ascending order in `Z`'s own precision (bit-identical to NumPy's
+    ``(Z.real / d).sum(axis=-2)``). `Z`: (na, n) or (B, na, n) complex."""
+    lib = _lib.load()
+    Z = to_device(Z)
+    B, na, n = _shape3(Z)
+    rdt = _real_of(Z.dtype)
+    d = None if divisor is None else to_device(np.ascontiguousarray(
+        np.asarray(divisor).reshape(-1)), rdt)
+    if d is not None and d.numel() != na:
+        raise ValueError("`divisor` must have one entry per row (%d != %d)"
+                         % (d.numel(), na))
+    out = torch.empty(Z.shape[:-2] + (n,), dtype=rdt, device=Z.device)
+    check(lib.ssq_colsum(_CDT[Z.dtype], _ptr(Z), _ptr(d) if d is not None else None,
+                         _ptr(out), B, na, n, stream()))
+    return out
+
+
+def band_colsum(Z, lo, hi):
+    """Per-component sums of ``Re(Z)`` over the row bands ``lo[k, j] .. hi[k, j]`` of every
+    column (float64), plus the sum of the rows no band covers as the last row.
+    `Z`: (na, n) complex; `lo`, `hi`: (K, n) integer arrays, inclusive."""
+    lib = _lib.load()
+    Z = to_device(Z)
+    if Z.ndim != 2:
+        raise ValueError("component inversion takes a single (na, n) transform")
+    na, n = Z.shape
+    lo = torch.as_tensor(np.ascontiguousarray(lo, dtype=np.int32), device=Z.device)
+    hi = torch.as_tensor(np.ascontiguousarray(hi, dtype=np.int32), device=Z.device)
+    K = lo.shape[0]
+    out = torch.empty((K + 1, n), dtype=torch.float64, device=Z.device)
+    check(lib.ssq_band_colsum(_CDT[Z.dtype], _ptr(Z), _ptr(lo), _ptr(hi), K, _ptr(out),
+                              na, n, stream()))
+    return out
+
+
+def istft_gpu(Sx, win_a, win_a1, n_fft, hop_len, N, modulated=True):
+    """irfft of every column of `Sx` + overlap-add with `win_a`, divided by the
+    overlap-added `win_a1`, trimmed to `N` samples (`ssq_istft`, include/ssq_hip.h)."""
+    lib = _lib.load()
+    Sx = to_device(Sx)
+    rdt = _real_of(Sx.dtype)
+    rows, n_hops = Sx.shape
+    wa, wa1 = to_device(win_a, rdt), to_device(win_a1, rdt)
+    x = torch.empty(int(N), dtype=rdt, device=Sx.device)
+    check(lib.ssq_istft(_CDT[Sx.dtype], _ptr(Sx), _ptr(wa), _ptr(wa1), _ptr(x),
+                        int(n_fft), int(n_hops), int(hop_len), int(N),
+                        int(bool(modulated)), stream()))
+    return x

@@ -22,7 +22,7 @@ from .wavelets import (Wavelet, center_frequency, find_maximum,
 pi = np.pi
 WARN = lambda msg: logging.warning("WARNING: %s" % msg)
 
-__all__ = ['process_scales', 'infer_scaletype', 'make_scales',
+__all__ = ['adm_ssq', 'adm_cwt', 'integrate_analytic', 'process_scales', 'infer_scaletype', 'make_scales',
            'logscale_transition_idx', 'nv_from_scales', 'cwt_scalebounds',
            'find_min_scale', 'find_max_scale', 'find_max_scale_alt',
            'find_downsampling_scale']
@@ -329,3 +329,80 @@ def process_scales(scales, N, wavelet=None, nv=None, get_params=False,
     scales = make_scales(N, lo, hi, nv=nv, scaletype=scaletype, wavelet=wavelet)
     return (scales if not get_params else
             (scales, scaletype, len(scales), nv))
+
+
+# ------------------------------------------------------- admissibility constants
+def integrate_analytic(int_fn, nowarn=False):
+    """Integral over (0, inf) of a function that vanishes for negative arguments, has one
+    hump and decays to the right (an analytic wavelet divided by `w`): trapezoid rule on
+    a logarithmic grid for (1e-15, 0.1) plus a uniform grid from 0.1 up to the first
+    candidate limit (1, 20, 80, 160; 1e4, 1e4, 4e4, 8e4 points) that contains the hump
+    and at least 1000*m points of it below 1e-15 -- the quadrature the reference defines
+    (utils/cwt_utils.py:583-627), so the constants agree to the last digits."""
+    from scipy import integrate
+    t0 = np.logspace(-15, -1, 1000)
+    near_zero = integrate.trapezoid(int_fn(t0), t0)
+    arr = t = None
+    cut = 0
+    for m, lim in zip((1, 1, 4, 8), (1, 20, 80, 160)):
+        n = 10000 * m
+        t = np.linspace(lim, .1, n, endpoint=False)[::-1].copy()
+        arr = int_fn(t)
+        peak = int(np.argmax(arr))
+        small = np.nonzero(np.abs(arr[peak:]) < 1e-15)[0]
+        cut = peak + (int(small[0]) if len(small) else len(arr) - peak - 1)
+        if (len(t) - cut > 1000 * m) and np.sum(np.abs(arr)) > 1e-5:
+            break
+    else:
+        if near_zero < 1e-5:
+            raise Exception("Could not find converging or non-negligibly-valued "
+                            "bounds of integration for `int_fn`")
+        elif not nowarn:
+            WARN("Integrated only from 1e-15 to 0.1 in logspace")
+    return integrate.trapezoid(arr[:cut], t[:cut]) + near_zero
+
+
+def _wavelet_fn(wavelet):
+    from .wavelets import Wavelet
+    return Wavelet._init_if_not_isinstance(wavelet).fn
+
+
+_ADM_CACHE = {}
+
+
+def _adm_cached(kind, wavelet, compute):
+    # the quadrature costs ~0.1 ms of host time; the constants depend only on the
+    # wavelet's family and parameters
+    from .wavelets import Wavelet
+    w = wavelet if isinstance(wavelet, Wavelet) else None
+    key = None
+    if isinstance(wavelet, str):
+        key = (kind, wavelet)
+    elif w is not None and w.family is not None:
+        key = (kind, w.family, tuple(sorted((k, str(v)) for k, v in w.config.items())))
+    if key is not None and key in _ADM_CACHE:
+        return _ADM_CACHE[key]
+    val = compute()
+    if key is not None:
+        _ADM_CACHE[key] = val
+    return val
+
+
+def adm_ssq(wavelet):
+    """Synchrosqueezing admissibility constant ``int_0^inf conj(psih(w)) / w dw``
+    (reference: utils/cwt_utils.py:28-47)."""
+    def compute():
+        fn = _wavelet_fn(wavelet)
+        c = integrate_analytic(lambda w: np.conj(_to_numpy(fn(w))) / w)
+        return c.real if abs(c.imag) < 1e-15 else c
+    return _adm_cached('ssq', wavelet, compute)
+
+
+def adm_cwt(wavelet):
+    """CWT admissibility constant ``int_0^inf |psih(w)|^2 / w dw``
+    (reference: utils/cwt_utils.py:50-64)."""
+    def compute():
+        fn = _wavelet_fn(wavelet)
+        c = integrate_analytic(lambda w: np.conj(_to_numpy(fn(w))) * _to_numpy(fn(w)) / w)
+        return c.real if abs(c.imag) < 1e-15 else c
+    return _adm_cached('cwt', wavelet, compute)

@@ -103,3 +103,14 @@ def test_pad_geometry_and_modes():
     assert np.array_equal(padsignal(x, 'wrap')[-n2:], [1, 2, 3, 4])
     assert np.array_equal(padsignal(x, 'zero')[-n2:], [0] * 4)
     assert len(padsignal(x, 'reflect', padlength=12)) == 12
+
+
+def test_admissibility_constants():
+    """adm_ssq / adm_cwt (utils/cwt_utils.py:28-64): same quadrature, same digits."""
+    from conftest import golden
+    from ssqueezepy_amd.scales import adm_ssq, adm_cwt
+    g = golden('inverse')
+    for name, spec in (('gmw', 'gmw'), ('gmw_l2', ('gmw', {'norm': 'energy'})),
+                       ('morlet', 'morlet'), ('bump', 'bump')):
+        assert adm_ssq(spec) == float(g['adm_ssq/' + name]), name
+        assert adm_cwt(spec) == float(g['adm_cwt/' + name]), name

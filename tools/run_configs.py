@@ -25,7 +25,7 @@ def timeit(fn, n):
 
 
 def main():
-    which = sys.argv[1:] or ['c1', 'c3', 'c5']
+    which = sys.argv[1:] or ['c1', 'c3', 'c5', 'inv']
     dev = torch.device('cuda')
     if 'c1' in which:
         N, na = 10000, 300
@@ -65,6 +65,27 @@ def main():
                           "GBps_alg": bytes_alg / ms / 1e6,
                           "setup_s": time.time() - t0}))
         assert err < 1e-11, err
+
+    if 'inv' in which:
+        # inverses at config-2 size: one streaming pass over the (300, 160000) array
+        N, na = 160000, 300
+        wav = S.Wavelet()
+        scales = S.process_scales('log', N, wav, nv=32)[:na]
+        x = torch.as_tensor(two_chirps(N, 0), dtype=torch.float32, device=dev)
+        Tx, Wx, *_ = S.ssq_cwt(x, wav, scales=scales)
+        from ssqueezepy_amd import algos
+        ms, _ = timeit(lambda: algos.colsum_real(Tx), 20)
+        print(json.dumps({"config": "colsum kernel (icwt / issq_cwt core) 300x160000 c64",
+                          "ms": ms, "GBps": na * N * 8 / ms / 1e6}))
+        ms, xr = timeit(lambda: S.issq_cwt(Tx, wav), 10)
+        print(json.dumps({"config": "issq_cwt N=160k 300 scales f32 (incl. host design)",
+                          "ms": ms}))
+        ms, xr = timeit(lambda: S.icwt(Wx, wav, scales=scales, nv=32), 10)
+        print(json.dumps({"config": "icwt N=160k 300 scales f32 (incl. host design)",
+                          "ms": ms}))
+        Sx = S.stft(x, n_fft=1024, hop_len=256, dtype='float32')
+        ms, xr = timeit(lambda: S.istft(Sx, n_fft=1024, hop_len=256, N=N), 10)
+        print(json.dumps({"config": "istft N=160k n_fft=1024 hop=256 f32", "ms": ms}))
 
 
 if __name__ == '__main__':
