@@ -50,6 +50,7 @@ struct SsqParams {
     int    grid;
     int    flipud;
     int    cst_f64;
+    int    cst_uniform;   // all per-row weights equal (scalar `const`): kernels read one value
     // float32 screening of the bin map (ssq_point_math.inl: bin_screen_f32): the bin
     // is first estimated in float32; only points whose estimate lies within `guard`
     // bins of a rounding boundary are re-evaluated with the exact double sequence.

@@ -253,6 +253,14 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
     pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
     pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
+    {   // the weights come from the host here: note when they are one scalar repeated
+        const bool wide = cst_f64 || pl->d.dtype == SSQ_F64;
+        bool uni = true;
+        for (int64_t i = 1; i < pl->d.na && uni; ++i)
+            uni = wide ? ((const double*)cst)[i] == ((const double*)cst)[0]
+                       : ((const float*)cst)[i] == ((const float*)cst)[0];
+        pl->sp.cst_uniform = uni ? 1 : 0;
+    }
     finalize_params(pl->sp);
     size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
     if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->d.na * 8));

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
     T zc[U], zd[U];
     w_t wt[U];
     SideVal<T, BINSRC> sv[U];
+    const bool uni = sp.cst_uniform != 0;          // scalar weight: one load per kernel
+    const w_t w0 = ((const w_t*)cst)[0];
     auto request = [&](int u, int i) {
         zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
         if (col_ok && i < na) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
             zc[u] = Wb[2 * (size_t)q];
             zd[u] = Wb[2 * (size_t)q + 1];
             sv[u].load(sb, q, i, j, na);
-            wt[u] = ((const w_t*)cst)[i];
+            wt[u] = uni ? w0 : ((const w_t*)cst)[i];
         }
     };
 #pragma unroll
@@ -388,6 +390,8 @@ __global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
     T zc[U], zd[U];
     w_t wt[U];
     SideVal<T, BINSRC> sv[U];
+    const bool uni = sp.cst_uniform != 0;          // scalar weight: one load per kernel
+    const w_t w0 = ((const w_t*)cst)[0];
     auto request = [&](int u, int i) {
         zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
         if (col_ok && i < na) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
             zc[u] = Wb[2 * (size_t)q];
             zd[u] = Wb[2 * (size_t)q + 1];
             sv[u].load(sb, q, i, j, na);
-            wt[u] = ((const w_t*)cst)[i];
+            wt[u] = uni ? w0 : ((const w_t*)cst)[i];
         }
     };
 #pragma unroll
@@ -758,6 +762,7 @@ static int fill_params(SsqParams& sp, int grid, const double* params, int flipud
     SSQ_REQUIRE(params, "grid params must not be null");
     for (int t = 0; t < 5; ++t) sp.p[t] = params[t];
     sp.grid = grid; sp.flipud = flipud ? 1 : 0; sp.gamma = gamma; sp.cst_f64 = cst_f64 ? 1 : 0;
+    sp.cst_uniform = 0;                   // weights are a device array here: not inspected
     finalize_params(sp);
     return 0;
 }

@@ -239,6 +239,14 @@ int ssq_stft_plan_set_ssq(ssq_stft_plan* pl, const void* Sfs, int grid, const do
     for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
     pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
     pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
+    {
+        const bool wide = cst_f64 || pl->d.dtype == SSQ_F64;
+        bool uni = true;
+        for (int64_t i = 1; i < pl->rows && uni; ++i)
+            uni = wide ? ((const double*)cst)[i] == ((const double*)cst)[0]
+                       : ((const float*)cst)[i] == ((const float*)cst)[0];
+        pl->sp.cst_uniform = uni ? 1 : 0;
+    }
     finalize_params(pl->sp);
     const int rs = pl->rsize();
     if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->rows * 8));
