@@ -289,15 +289,18 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
     SideVal<T, BINSRC> sv[U];
     const bool uni = sp.cst_uniform != 0;          // scalar weight: one load per kernel
     const w_t w0 = ((const w_t*)cst)[0];
+    // Loads are unconditional (row and column clamped into the array, the point is
+    // discarded at its use when it lies outside): with a branch around them the compiler
+    // loses count of the loads in flight and drains them all (s_waitcnt vmcnt(0)) before
+    // every use, which turns the rolling prefetch into one batch at a time.
+    const int jc = col_ok ? j : n - 1;
     auto request = [&](int u, int i) {
-        zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
-        if (col_ok && i < na) {
-            unsigned q = (unsigned)i * (unsigned)n + (unsigned)j;
-            zc[u] = Wb[2 * (size_t)q];
-            zd[u] = Wb[2 * (size_t)q + 1];
-            sv[u].load(sb, q, i, j, na);
-            wt[u] = uni ? w0 : ((const w_t*)cst)[i];
-        }
+        const int ic = i < na ? i : na - 1;
+        const unsigned q = (unsigned)ic * (unsigned)n + (unsigned)jc;
+        zc[u] = Wb[2 * (size_t)q];
+        zd[u] = Wb[2 * (size_t)q + 1];
+        sv[u].load(sb, q, ic, jc, na);
+        if (!uni) wt[u] = ((const w_t*)cst)[ic];
     };
 #pragma unroll
     for (int u = 0; u < U; ++u) request(u, u * RL + rl);
@@ -315,8 +318,9 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
             T ore = T(0), oim = T(0);
             T* cell = slab;
             if (k >= 0) {
-                tr = TM::make(zc[u], wt[u]);
-                ti = TM::make(zd[u], wt[u]);
+                const w_t wsel = uni ? w0 : wt[u];
+                tr = TM::make(zc[u], wsel);
+                ti = TM::make(zd[u], wsel);
                 cell = slab + 2 * (k * WC + ((cl + k) & (WC - 1)));
                 ore = cell[0]; oim = cell[1];
             }
@@ -392,15 +396,18 @@ __global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
     SideVal<T, BINSRC> sv[U];
     const bool uni = sp.cst_uniform != 0;          // scalar weight: one load per kernel
     const w_t w0 = ((const w_t*)cst)[0];
+    // Loads are unconditional (row and column clamped into the array, the point is
+    // discarded at its use when it lies outside): with a branch around them the compiler
+    // loses count of the loads in flight and drains them all (s_waitcnt vmcnt(0)) before
+    // every use, which turns the rolling prefetch into one batch at a time.
+    const int jc = col_ok ? j : n - 1;
     auto request = [&](int u, int i) {
-        zc[u] = T(0); zd[u] = T(0); wt[u] = w_t(0);
-        if (col_ok && i < na) {
-            unsigned q = (unsigned)i * (unsigned)n + (unsigned)j;
-            zc[u] = Wb[2 * (size_t)q];
-            zd[u] = Wb[2 * (size_t)q + 1];
-            sv[u].load(sb, q, i, j, na);
-            wt[u] = uni ? w0 : ((const w_t*)cst)[i];
-        }
+        const int ic = i < na ? i : na - 1;
+        const unsigned q = (unsigned)ic * (unsigned)n + (unsigned)jc;
+        zc[u] = Wb[2 * (size_t)q];
+        zd[u] = Wb[2 * (size_t)q + 1];
+        sv[u].load(sb, q, ic, jc, na);
+        if (!uni) wt[u] = ((const w_t*)cst)[ic];
     };
 #pragma unroll
     for (int u = 0; u < U; ++u) request(u, u * RL + rl);
@@ -418,8 +425,9 @@ __global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
             T ore = T(0), oim = T(0);
             T* cell = tile;
             if (k >= 0) {
-                tr = TM::make(zc[u], wt[u]);
-                ti = TM::make(zd[u], wt[u]);
+                const w_t wsel = uni ? w0 : wt[u];
+                tr = TM::make(zc[u], wsel);
+                ti = TM::make(zd[u], wsel);
                 cell = tile + 2 * (k * TC + ((c + k) & 15));
                 ore = cell[0]; oim = cell[1];
             }
@@ -509,7 +517,11 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
             dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
             static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
             if (variant != 2) {        // default: 16 row-lanes x 4 waves per tile
-                constexpr int U = sizeof(T) == 4 ? 8 : 4;
+                // Row batches in flight per lane. Measured (config 2, float32): U = 2: 257 us,
+                // 3: 263, 4: 259, 8: 278 -- with 16 wavefronts per CU the latency is covered
+                // by the other wavefronts, and a deeper prefetch spreads each wavefront's
+                // requests over more DRAM pages.
+                constexpr int U = sizeof(T) == 4 ? 2 : 4;
                 if (variant == 3) {    // 8 row-lanes x 8 columns per wavefront, 2 wavefronts per tile
                     auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 2, 8>;
                     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
