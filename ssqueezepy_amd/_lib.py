@@ -11,7 +11,8 @@ from ctypes import (c_int, c_int32, c_int64, c_double, c_void_p, c_char_p, POINT
                     Structure)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libssq_hip.so')
+# SSQ_HIP_LIB: load a library built elsewhere (e.g. an A/B build) instead of the in-tree one
+LIB_PATH = os.environ.get('SSQ_HIP_LIB') or os.path.join(HERE, 'libssq_hip.so')
 
 F32, F64 = 0, 1
 GRID_LOG, GRID_LOG_PIECEWISE, GRID_LIN = 0, 1, 2
