@@ -105,3 +105,43 @@ def test_stft_odd_sizes_and_windows(S, orc, dtype):
     Tf = S.ssq_stft(x, n_fft=64, hop_len=8, dtype=dtype, flipud=True, astensor=False)
     Tn = S.ssq_stft(x, n_fft=64, hop_len=8, dtype=dtype, astensor=False)
     assert np.array_equal(Tf[0], Tn[0][::-1]) and np.array_equal(Tf[2], Tn[2][::-1])
+
+
+@pytest.mark.parametrize('n_fft', [128, 256, 512, 1024, 2048])
+def test_fused_stft_every_size(S, orc, n_fft):
+    """The fused framing + window + packed-pair FFT kernel (float32, power-of-two n_fft)
+    for each of its five FFT configurations: against the oracle (reference tolerance 1e-5),
+    against this engine's rocFFT path (env switch), modulated and not, batched, hops that
+    leave a partial last workgroup; Tx exact against the oracle reassignment of the
+    device's own Sx, dSx."""
+    import os, subprocess, sys, json
+    from ssqueezepy_amd import _stft
+    N = 6000 + n_fft
+    for hop, mod in ((n_fft // 4, True), (37, False)):
+        x = two_chirps(N, seed=n_fft + hop)
+        _stft._PLAN_CACHE.clear()
+        Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, modulated=mod,
+                                          dtype='float32', get_dWx=True, astensor=False)
+        ro = oracle_ssq_stft(orc, x, 'float32', n_fft=n_fft, hop_len=hop, modulated=mod)
+        assert Sx.shape == ro['Sx'].shape
+        assert relmax(Sx, ro['Sx']) <= 1e-5 and relmax(dSx, ro['dSx']) <= 1e-5, (hop, mod)
+        from ssqueezepy_amd.ssqueezing import ssq_grid_params
+        _, p = ssq_grid_params(Sfs, False)
+        ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], ro['gamma'], False,
+                           Sfs=Sfs, typing=0)
+        assert np.array_equal(Tx, ref), (hop, mod)
+        xb = np.stack([x, x[::-1].copy(), 0.5 * x])
+        Txb, Sxb, *_ = S.ssq_stft(xb, n_fft=n_fft, hop_len=hop, modulated=mod,
+                                  dtype='float32', astensor=False)
+        assert np.array_equal(Sxb[0], Sx) and np.array_equal(Txb[0], Tx)
+        # the generic (rocFFT) path of this engine on the same input
+        os.environ['SSQ_STFT_GENERIC'] = '1'
+        try:
+            _stft._PLAN_CACHE.clear()
+            Sx2, dSx2 = S.stft(x, n_fft=n_fft, hop_len=hop, modulated=mod, derivative=True,
+                               dtype='float32', astensor=False)
+        finally:
+            del os.environ['SSQ_STFT_GENERIC']
+            _stft._PLAN_CACHE.clear()
+        assert relmax(Sx2, ro['Sx']) <= 1e-5 and relmax(Sx, Sx2) <= 1e-5
+        assert relmax(dSx, dSx2) <= 1e-5
