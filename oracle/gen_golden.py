@@ -338,8 +338,36 @@ def gen_inverse():
     save('inverse', **d)
 
 
+def gen_hiorder():
+    """Higher-order generalized Morse wavelets (_gmw.py:268-394) and the transforms
+    that use them: cwt(order=...) -> cwt_higher_order (_cwt.py:517-610), ssq_cwt(order=...)
+    (_ssq_cwt.py:227-241)."""
+    d = {}
+    w = np.linspace(-1, 12, 527)
+    for dtype in ('float32', 'float64'):
+        for k in (1, 2, 3):
+            wav = Wavelet(('gmw', {'order': k, 'dtype': dtype}))
+            d[f'psih_l1/{dtype}/{k}'] = wav.fn(w.astype(dtype))
+        N = 400
+        x = two_chirps(N, seed=41)
+        d[f'x/{dtype}'] = x
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        Wx, sc, dWx = cwt(x, wav, scales='log', nv=8, order=1, derivative=True)
+        d[f'Wx1/{dtype}'], d[f'sc/{dtype}'], d[f'dWx1/{dtype}'] = Wx, sc, dWx
+        Wx, sc = cwt(x, wav, scales='log', nv=8, order=(0, 2), average=True)
+        d[f'Wx02/{dtype}'] = Wx
+        Tx, Wx, sf, sc = ssq_cwt(x, wav, scales='log', nv=8, order=2)
+        d[f'Tx2/{dtype}'], d[f'WxT2/{dtype}'], d[f'sf/{dtype}'] = Tx, Wx, sf
+        Tx, Wx, sf, sc = ssq_cwt(x, wav, scales='log', nv=8, order=(0, 1, 2))
+        d[f'Tx012/{dtype}'], d[f'WxT012/{dtype}'] = Tx, Wx
+    for k in (1, 2):
+        wav = Wavelet(('gmw', {'order': k, 'norm': 'energy', 'dtype': 'float64'}))
+        d[f'psih_l2/float64/{k}'] = wav.fn(w.copy())
+    save('hiorder', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

@@ -21,7 +21,7 @@ def __getattr__(name):
     # the compute layer needs torch + the HIP library; import it lazily so that the
     # host-side design modules stay importable on a machine without a GPU
     _lazy = {
-        'cwt': '_cwt', 'ssq_cwt': '_ssq_cwt', 'phase_cwt': '_ssq_cwt',
+        'cwt': '_cwt', 'cwt_higher_order': '_cwt', 'ssq_cwt': '_ssq_cwt', 'phase_cwt': '_ssq_cwt',
         'stft': '_stft', 'get_window': '_stft', 'ssq_stft': '_ssq_stft',
         'phase_stft': '_ssq_stft', 'ssqueeze': 'ssqueezing',
         'ssqueeze_fast': 'algos', 'indexed_sum_onfly': 'algos', 'buffer': 'algos',

@@ -26,7 +26,7 @@ from .wavelets import Wavelet
 
 WARN = lambda msg: logging.warning("WARNING: %s" % msg)
 
-__all__ = ['cwt', 'CwtPlan', 'get_cwt_plan', 'clear_plan_cache']
+__all__ = ['cwt', 'cwt_higher_order', 'CwtPlan', 'get_cwt_plan', 'clear_plan_cache']
 
 _TDT = {'float32': torch.float32, 'float64': torch.float64}
 _CDT = {'float32': torch.complex64, 'float64': torch.complex128}
@@ -281,11 +281,14 @@ def cwt(x, wavelet='gmw', scales='log-piecewise', fs=None, t=None, nv=32,
     (``(B, na, N)`` for batched input), `scales` a NumPy vector in the wavelet
     dtype. `vectorized`, `patience` are accepted and ignored (the device path has
     one execution strategy); `cache_wavelet=False` bypasses the plan cache.
-    Higher-order GMWs (`order > 0`) are outside the accelerated path.
+    `order > 0` / a tuple of orders: see `cwt_higher_order`.
     """
     if isinstance(order, (tuple, list, range)) or order > 0:
-        raise NotImplementedError("`order > 0` (higher-order GMWs) is not part of "
-                                  "the accelerated path")
+        kw = dict(wavelet=wavelet, scales=scales, fs=fs, t=t, nv=nv, l1_norm=l1_norm,
+                  derivative=derivative, padtype=padtype, rpadded=rpadded,
+                  vectorized=vectorized, patience=patience, cache_wavelet=cache_wavelet)
+        return cwt_higher_order(x, order=order, average=average, astensor=astensor,
+                                **kw)
     if not hasattr(x, 'ndim'):
         raise TypeError("`x` must be a numpy array or torch Tensor "
                         "(got %s)" % type(x))
@@ -323,4 +326,57 @@ def cwt(x, wavelet='gmw', scales='log-piecewise', fs=None, t=None, nv=32,
     if not astensor:
         Wx = Wx.cpu().numpy()
         dWx = dWx.cpu().numpy() if dWx is not None else None
+    return (Wx, scales, dWx) if derivative else (Wx, scales)
+
+
+def cwt_higher_order(x, wavelet='gmw', order=1, average=None, astensor=True, **kw):
+    """`cwt` with generalized Morse wavelets of the given order(s): lower variance, more
+    noise-robust (Olhede & Walden 2002). `order`: int or tuple of ints; with a tuple and
+    `average` (default True for a tuple) the transforms (and derivatives) are averaged,
+    else returned as lists. `kw`: arguments of `cwt`; string `scales` are designed with
+    the order-0 wavelet and shared by all orders. Returns ``(Wx, scales[, dWx])``.
+    Reference: ``cwt_higher_order``, ssqueezepy/_cwt.py:517-610."""
+    if isinstance(order, (list, range)):
+        order = tuple(order)
+    if not isinstance(order, (list, tuple)):
+        order = [order]
+    if len(order) == 1 and average:
+        WARN("`average` ignored with single `order`")
+        average = False
+    wavelet = Wavelet._init_if_not_isinstance(wavelet)
+    if not wavelet.name.lower().startswith('gmw'):
+        raise ValueError("`wavelet` must be GMW for higher-order transforms "
+                         "(got %s)" % wavelet.name)
+    wavopts = wavelet.config.copy()
+    wavopts.pop('order')
+    wavelets = [Wavelet(('gmw', dict(order=k, **wavopts))) for k in order]
+    scales = kw.get('scales', 'log-piecewise')
+    if isinstance(scales, str):
+        wav = Wavelet(('gmw', dict(order=0, **wavopts)))
+        scales = process_scales(scales, x.shape[-1], wavelet=wav, nv=kw.get('nv', 32))
+        scales = np.asarray(scales, dtype=wav.dtype)
+    kw['scales'] = scales
+
+    derivative = kw.get('derivative', False)
+    Wx_all, dWx_all = [], []
+    for wav in wavelets:
+        out = cwt(x, wav, order=0, astensor=True, **kw)
+        Wx_all.append(out[0])
+        if derivative:
+            dWx_all.append(out[-1])
+    dWx = None
+    if average or (average is None and isinstance(order, tuple)):
+        Wx = torch.stack(Wx_all).mean(dim=0)
+        if derivative:
+            dWx = torch.stack(dWx_all).mean(dim=0)
+    elif len(Wx_all) == 1:
+        Wx = Wx_all[0]
+        if derivative:
+            dWx = dWx_all[0]
+    else:
+        Wx, dWx = Wx_all, (dWx_all if derivative else None)
+    if not astensor:
+        tonp = lambda g: ([t.cpu().numpy() for t in g] if isinstance(g, list)
+                          else (g.cpu().numpy() if g is not None else None))
+        Wx, dWx = tonp(Wx), tonp(dWx)
     return (Wx, scales, dWx) if derivative else (Wx, scales)

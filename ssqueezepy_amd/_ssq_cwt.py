@@ -98,8 +98,8 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
         w: phase transform (if `get_w`);  dWx: time derivative (if `get_dWx`)
 
     `Tx`, `Wx`, `w`, `dWx` are torch GPU tensors (`astensor=True`) or NumPy arrays.
-    Supported on the device path: `difftype='trig'`, `order=0` (other values raise, as
-    the reference's GPU mode does for `difftype`); every `squeezing` mode.
+    Supported on the device path: `difftype='trig'` (other values raise, as in the
+    reference's GPU mode); every `squeezing` mode; `order` > 0 / tuple (higher-order GMWs).
     """
     if x.ndim == 2 and get_w:
         raise NotImplementedError("`get_w=True` unsupported with batched input.")
@@ -110,9 +110,6 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
         raise ValueError("`x` must be 1D or 2D (got x.ndim == %s)" % x.ndim)
     difforder = _check_ssqueezing_args(squeezing, maprange, wavelet, difftype,
                                        difforder, get_w, transform='cwt')
-    if isinstance(order, (tuple, list, range)) or order > 0:
-        raise NotImplementedError("`order > 0` (higher-order GMWs) is not part of "
-                                  "the accelerated path")
     if padtype is not None and padtype not in PADTYPES:
         raise ValueError("`padtype` must be one of: %s (got %s)"
                          % (', '.join(PADTYPES), padtype))
@@ -141,9 +138,36 @@ def ssq_cwt(x, wavelet='gmw', scales='log-piecewise', nv=None, fs=None, t=None,
     use_cache = True if cache_wavelet is None else bool(cache_wavelet)
     xd = algos.to_device(x, _TDT[dtype])
     B = xd.shape[0] if xd.ndim == 2 else 1
-    plan = get_cwt_plan(wavelet, scales_dt, N, padtype, dt, True, B, cache=use_cache)
-    plan.set_ssq(grid, params, const, flipud, gamma)
-    if squeezing == 'sum':
+    hi_order = isinstance(order, (tuple, list, range)) or order > 0
+    if not hi_order:
+        plan = get_cwt_plan(wavelet, scales_dt, N, padtype, dt, True, B, cache=use_cache)
+        plan.set_ssq(grid, params, const, flipud, gamma)
+    if hi_order:
+        # higher-order GMWs: the (averaged) transform and its derivative, then the
+        # reassignment as its own launch (_ssq_cwt.py:227-241; the reference
+        # differentiates the averaged padded transform, which is the average of the
+        # derivatives)
+        from ._cwt import cwt as _cwt_fn
+        Wx, _, dWx_h = _cwt_fn(xd, wavelet, scales=scales_dt, fs=fs, nv=nv, l1_norm=True,
+                               derivative=True, padtype=padtype, astensor=True,
+                               cache_wavelet=cache_wavelet, nan_checks=False, order=order,
+                               average=isinstance(order, (tuple, list, range)))
+        out = {'Wx': Wx, 'dWx': dWx_h}
+        w = algos.phase_cwt_gpu(Wx, dWx_h, gamma) if get_w else None
+        Wq = Wx
+        if isinstance(squeezing, FunctionType):
+            Wq = squeezing(Wx)
+        elif squeezing == 'lebesgue':
+            Wq = algos.ones_like(Wx) / len(Wx)
+        elif squeezing == 'abs':
+            Wq = algos.cabs(Wx)
+        logscale = grid != GRID_LIN
+        if get_w:
+            Tx = algos.indexed_sum_onfly(Wq, w, ssq_freqs, const, logscale, flipud)
+        else:
+            Tx = algos.ssqueeze_fast(Wq, dWx_h, ssq_freqs, const, logscale, flipud, gamma)
+        dWx = dWx_h if get_dWx else None
+    elif squeezing == 'sum':
         out = plan.execute(xd, want_dWx=get_dWx, want_Tx=True, want_w=get_w)
         Tx, Wx, w, dWx = out['Tx'], out['Wx'], out.get('w'), out.get('dWx')
     else:

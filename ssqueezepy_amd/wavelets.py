@@ -76,15 +76,17 @@ def _make_gmw(gamma=None, beta=None, norm=None, order=None, centered_scale=None,
         raise ValueError("`beta` must be positive (got %s)" % beta)
     if norm not in ('bandpass', 'energy'):
         raise ValueError("`norm` must be 'energy' or 'bandpass' (got %s)" % norm)
-    if cfg['order'] != 0:
-        raise NotImplementedError("higher-order GMWs (order > 0) are outside the "
-                                  "accelerated hot path")
+    order = int(cfg['order'])
+    if order < 0:
+        raise ValueError("`order` must be >= 0 (got %s)" % order)
     dt = str(np.dtype(cfg['dtype']))
     if norm == 'energy' and dt == 'float32':
         raise ValueError("`norm='energy'` w/ `dtype='float32'` is unsupported; "
                          "use 'float64' instead.")
     wc_py = morsefreq(gamma, beta)
     centered = bool(cfg['centered_scale'])
+    if order > 0:
+        return _make_gmw_k(gamma, beta, order, norm, wc_py, centered, dt), cfg
 
     if norm == 'bandpass':
         g, b, wc, wcl = _as0d(gamma, beta, wc_py, np.log(wc_py), dtype=dt)
@@ -111,6 +113,49 @@ def _make_gmw(gamma=None, beta=None, norm=None, order=None, centered_scale=None,
         w *= keep
         return np.sqrt(2. * pi * g * 2.**r / rg) * w**b * np.exp(-w**g) * keep
     return gmw_l2, cfg
+
+
+def _gmw_k_constants(gamma, beta, k, norm, dt):
+    """Coefficients of the order-k generalized Morse wavelet: generalized Laguerre
+    polynomial L_k^(c)(2 w^gamma), c = (2 beta + 1)/gamma - 1, times the normalisation
+    (Olhede & Walden 2002; ssqueezepy/_gmw.py:366-394)."""
+    from scipy.special import gammaln
+    r = (2 * beta + 1) / gamma
+    c = r - 1
+    if norm == 'bandpass':
+        coeff = np.sqrt(np.exp(gammaln(r) + gammaln(k + 1) - gammaln(k + r)))
+    else:
+        coeff = np.sqrt(2 * pi * gamma * (2**r) * np.exp(gammaln(k + 1) - gammaln(k + r)))
+    L = np.zeros(k + 1, dtype=dt)
+    for m in range(k + 1):
+        fact = np.exp(gammaln(k + c + 1) - gammaln(c + m + 1) - gammaln(k - m + 1))
+        L[m] = (-1)**m * fact / _gamma_fn(m + 1)
+    kc = L * coeff
+    if norm == 'bandpass':
+        kc *= 2
+    return kc.astype(dt)
+
+
+def _make_gmw_k(gamma, beta, k, norm, wc_py, centered, dt):
+    """Order-k GMW in the frequency domain (ssqueezepy/_gmw.py:268-365): the order-0
+    envelope times the Laguerre polynomial in ``2 w**gamma``."""
+    kc = _gmw_k_constants(gamma, beta, k, norm, dt)
+    g, b, wc = _as0d(gamma, beta, wc_py, dtype=dt)
+
+    def gmw_k(w):
+        w = np.atleast_1d(np.asarray(w * wc if centered else w, dtype=dt))
+        if not w.flags.writeable or w.base is not None:
+            w = w.copy()
+        keep = (w >= 0)
+        w *= keep                           # zero negative w to avoid nans
+        C = np.zeros(w.shape, dtype=w.dtype)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            for m in range(len(kc)):
+                C += kc[m] * (2 * w**g)**m
+            if norm == 'bandpass':
+                return C * np.exp(- b * np.log(wc) + wc**g + b * np.log(w) - w**g) * keep
+            return C * np.exp(b * np.log(w) - w**g) * keep
+    return gmw_k
 
 
 def _make_morlet(mu=None, dtype=None):

@@ -114,3 +114,19 @@ def test_admissibility_constants():
                        ('morlet', 'morlet'), ('bump', 'bump')):
         assert adm_ssq(spec) == float(g['adm_ssq/' + name]), name
         assert adm_cwt(spec) == float(g['adm_cwt/' + name]), name
+
+
+def test_higher_order_gmw_samples():
+    """Order-k generalized Morse wavelets (_gmw.py:268-394): value-exact samples."""
+    from conftest import golden
+    from ssqueezepy_amd.wavelets import Wavelet
+    g = golden('hiorder')
+    w = np.linspace(-1, 12, 527)
+    for dtype in ('float32', 'float64'):
+        for k in (1, 2, 3):
+            wav = Wavelet(('gmw', {'order': k, 'dtype': dtype}))
+            assert np.array_equal(wav.fn(w.astype(dtype)), g[f'psih_l1/{dtype}/{k}'],
+                                  equal_nan=True), (dtype, k)
+    for k in (1, 2):
+        wav = Wavelet(('gmw', {'order': k, 'norm': 'energy', 'dtype': 'float64'}))
+        assert np.array_equal(wav.fn(w.copy()), g[f'psih_l2/float64/{k}'], equal_nan=True)

@@ -396,3 +396,35 @@ def test_float64_long_signal_properties(S):
     Wy, _ = S.cwt(y, wav, scales=scales)
     Wxy, _ = S.cwt(x - 2 * y, wav, scales=scales)
     assert ((Wxy - (Wx - 2 * Wy)).abs().max() / Wxy.abs().max()).item() < 1e-13
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_higher_order_gmw_vs_reference(S, orc, dtype):
+    """cwt / ssq_cwt with higher-order generalized Morse wavelets (order > 0, tuples with
+    averaging) against the reference's outputs (tests/golden/hiorder.npz; wavelet samples
+    are checked value-exact in test_design_vs_golden.py)."""
+    g = golden('hiorder')
+    tol = 1e-5 if dtype == 'float32' else 1e-11
+    x = g[f'x/{dtype}']
+    wav = S.Wavelet(('gmw', {'dtype': dtype}))
+    Wx, sc, dWx = S.cwt(x, wav, scales='log', nv=8, order=1, derivative=True, astensor=False)
+    assert np.array_equal(np.asarray(sc).reshape(-1), g[f'sc/{dtype}'].reshape(-1))
+    assert relmax(Wx, g[f'Wx1/{dtype}']) <= tol and relmax(dWx, g[f'dWx1/{dtype}']) <= tol
+    Wa, _ = S.cwt(x, wav, scales='log', nv=8, order=(0, 2), average=True, astensor=False)
+    assert relmax(Wa, g[f'Wx02/{dtype}']) <= tol
+    Wl, _ = S.cwt(x, wav, scales='log', nv=8, order=(0, 2), average=False, astensor=False)
+    assert isinstance(Wl, list) and len(Wl) == 2
+    assert relmax(0.5 * (Wl[0] + Wl[1]), g[f'Wx02/{dtype}']) <= tol
+    for order, key in ((2, '2'), ((0, 1, 2), '012')):
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=8, order=order,
+                                        get_dWx=True, astensor=False)
+        assert np.array_equal(sf, g[f'sf/{dtype}'])
+        assert relmax(Wx, g[f'WxT{key}/{dtype}']) <= tol
+        # reassignment: exact w.r.t. the oracle on the device's own (Wx, dWx); against the
+        # reference's Tx through the assignment-invariant column sums
+        r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=8)
+        check_Tx(orc, Tx, Wx, dWx, r, dtype)
+        ref = g[f'Tx{key}/{dtype}']
+        assert np.abs(Tx.sum(0) - ref.sum(0)).max() <= 20 * tol * np.abs(ref.sum(0)).max()
+    with pytest.raises(ValueError):
+        S.cwt(x, 'morlet', order=1)
