@@ -35,7 +35,7 @@ import scipy.fft as sfft
 
 __all__ = ['plan_blocks']
 
-POINTS_PER_WG = 4096          # D = L' * G complex points per workgroup
+POINTS_PER_WG = {'float32': 4096, 'float64': 2048}   # D = L' * G complex points per workgroup
 L_MIN, L_MAX = 128, 2048
 P_MIN = 4096
 
@@ -44,9 +44,14 @@ def _is_pow2(v):
     return v >= 1 and (v & (v - 1)) == 0
 
 
-def _margins(vals, off, lo, M, tol, chunk=32):
+def _margins(vals, off, lo, M, tol, chunk=32, denoise=False):
     """Per row: smallest m such that the impulse response's L1 mass outside
-    [-m, m] (circularly, on the M-point grid) is <= tol * total. Double precision."""
+    [-m, m] (circularly, on the M-point grid) is <= tol * total. Double precision.
+    `denoise`: subtract 4x the median magnitude of the far half of the response (the
+    rounding-noise floor of the double-precision FFT, ~1e-17 of the peak per sample but
+    ~1e-13 of the L1 norm once summed over M samples; capped at 64 eps of the peak) before
+    accumulating -- needed to resolve tails at the 1e-14 level a float64 transform asks
+    for."""
     na = len(lo)
     lens = np.diff(off)
     out = np.empty(na, np.int64)
@@ -60,6 +65,12 @@ def _margins(vals, off, lo, M, tol, chunk=32):
         f = h[:, :half + 1].copy()
         f[:, 1:half] += h[:, :half:-1]
         tot = f.sum(1)
+        if denoise:
+            # the far half is rounding noise for a compact response, but real signal for a
+            # long one: never subtract more than 64 eps of the peak
+            floor = np.minimum(4 * np.median(f[:, half // 2:], axis=1, keepdims=True),
+                               64 * np.finfo(np.float64).eps * f.max(1, keepdims=True))
+            f = np.maximum(f - floor, 0)
         cs = np.cumsum(f[:, ::-1], axis=1)[:, ::-1]      # cs[s] = sum_{s' >= s}
         for r, i in enumerate(rows):
             ok = np.nonzero(cs[r] <= tol * tot[r])[0]
@@ -67,7 +78,7 @@ def _margins(vals, off, lo, M, tol, chunk=32):
     return out
 
 
-def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
+def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
     """Plan the block decomposition.
 
     vals/off/lo: banded bank on the M-grid (`_bank.banded_bank`). `vals64`: the
@@ -84,14 +95,22 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
       items    dict L' -> (n_items, 4) int32: row, block, c0, class
       generic_rows  int32 indices of rows left on the exact path
     """
-    if not _is_pow2(M) or M < P_MIN or str(np.dtype(dtype)) != 'float32':
+    dtype = str(np.dtype(dtype))
+    if not _is_pow2(M) or M < P_MIN or dtype not in POINTS_PER_WG:
         return None
+    f64 = dtype == 'float64'
+    if tail_tol is None:
+        # truncated-tail budget relative to the row's L1 norm: far below the rounding
+        # error of the transform itself (6e-8 / 1e-16)
+        tail_tol = 1e-14 if f64 else 1e-9
+    points = POINTS_PER_WG[dtype]
+    rdt, cdt = (np.float64, np.complex128) if f64 else (np.float32, np.complex64)
     na = len(lo)
     lens = np.diff(off)
     half = M // 2
     if np.any(lo + lens > half + 1):
         return None                                   # negative-frequency content
-    margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol)
+    margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol, denoise=f64)
 
     # block classes: P = 4096, 8192, ..., M/2 (margin P/8, valid 3P/4) and the
     # "global" class P = M (one block, no margin needed: the circular convolution
@@ -123,7 +142,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
                 Lp *= 2
             if Lp > L_MAX:
                 break                      # band too wide for an LDS FFT: exact path
-            G = POINTS_PER_WG // Lp
+            G = points // Lp
             if P // Lp < G:
                 continue                   # fewer columns than a workgroup handles
             cls_of[i] = c
@@ -132,7 +151,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
             # xi at the band's bins, exactly the M-grid values the reference uses
             # (k * 2pi/M formed in double, stored in float32: wavelets.py:473-484)
             px.append((np.arange(k_lo, k_lo + KP) * S * (2 * np.pi / M)
-                       ).astype(np.float32))
+                       ).astype(rdt))
             rows[i] = (c, k_lo, KP, Lp, G, pb_off)
             pb_off += KP
             break
@@ -152,7 +171,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
         classes[remap[c]] = (P, m, V, nb)
         q = np.arange(P)
         w = np.exp(2j * np.pi * q / P)
-        ctw.append(w.astype(np.complex64))
+        ctw.append(w.astype(cdt))
         ctw_off.append(ctw_off[-1] + P)
     for i in range(na):
         if rows[i, 0] >= 0:
@@ -162,7 +181,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
     o = 0
     Lp = L_MIN
     while Lp <= L_MAX:
-        ftw.append(np.exp(2j * np.pi * np.arange(Lp) / Lp).astype(np.complex64))
+        ftw.append(np.exp(2j * np.pi * np.arange(Lp) / Lp).astype(cdt))
         ftw_off[Lp] = o
         o += Lp
         Lp *= 2
@@ -184,7 +203,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=1e-9):
     return dict(classes=classes, rows=rows,
                 pbank=(np.concatenate(pb) if pb else np.zeros(1, vals.dtype)
                        ).astype(vals.dtype),
-                pxi=(np.concatenate(px) if px else np.zeros(1, np.float32)),
+                pxi=(np.concatenate(px) if px else np.zeros(1, rdt)),
                 ctw=np.concatenate(ctw), ctw_off=np.array(ctw_off, np.int64),
                 ftw=np.concatenate(ftw), ftw_off=ftw_off, items=items,
                 generic_rows=generic_rows, margins=margins)

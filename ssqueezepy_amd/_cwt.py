@@ -80,10 +80,10 @@ class CwtPlan():
         configuration admits it (float32, padded power-of-two length, analytic
         bank); see _blocks.py. Impulse-response margins are measured on the
         wavelet evaluated in float64 when it is a built-in family."""
-        if self.dtype != 'float32' or self.padtype is None:
+        if self.padtype is None or os.environ.get('SSQ_CWT_ALGO') == 'generic':
             return
         vals64 = None
-        if wavelet.family is not None:
+        if self.dtype == 'float32' and wavelet.family is not None:
             cfg = {k: v for k, v in wavelet.config.items() if k != 'dtype'}
             try:
                 twin = Wavelet((wavelet.family, dict(cfg, dtype='float64')))
@@ -102,11 +102,13 @@ class CwtPlan():
         # left pad, so that block sample t maps to output t - n1 (see kernel)
         cls[cls[:, 0] == self.M, 1] = self.n1
         rows = np.ascontiguousarray(bp['rows'], dtype=np.int32)
-        pbank = np.ascontiguousarray(bp['pbank'], dtype=np.float32)
-        pxi = np.ascontiguousarray(bp['pxi'], dtype=np.float32)
-        ctw = np.ascontiguousarray(bp['ctw'], dtype=np.complex64)
+        rdt, cdt = (('float32', 'complex64') if self.dtype == 'float32' else
+                    ('float64', 'complex128'))
+        pbank = np.ascontiguousarray(bp['pbank'], dtype=rdt)
+        pxi = np.ascontiguousarray(bp['pxi'], dtype=rdt)
+        ctw = np.ascontiguousarray(bp['ctw'], dtype=cdt)
         ctw_off = np.ascontiguousarray(bp['ctw_off'], dtype=np.int64)
-        ftw = np.ascontiguousarray(bp['ftw'], dtype=np.complex64)
+        ftw = np.ascontiguousarray(bp['ftw'], dtype=cdt)
         gen = np.ascontiguousarray(bp['generic_rows'], dtype=np.int32)
         keep = [cls, rows, pbank, pxi, ctw, ctw_off, ftw, gen]
         d = CwtBlocksDesc()

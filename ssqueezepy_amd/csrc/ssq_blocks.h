@@ -25,20 +25,20 @@ struct BlockClassDev {
 
 struct BlockPlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0, max_batch = 1;
+    int dtype = SSQ_F32;             // tables, spectra and kernels in this precision
     int group = 1;                   // signals per launch (kernels take them as a grid dimension)
     int nc = 0;
     std::vector<BlockClassDev> hcls;
     BlockClassDev* classes = nullptr;
     BlockRowDev* rows = nullptr;
-    float* pbank = nullptr;
-    float* pxi = nullptr;
+    void* pbank = nullptr;           // real (dtype)
+    void* pxi = nullptr;             // real (dtype)
     void* ctw = nullptr; void* ftw = nullptr;
     void* items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t n_items[5] = {0, 0, 0, 0, 0};
     int64_t ftw_off[5] = {0, 0, 0, 0, 0};
-    float* blocks = nullptr;         // gathered signal blocks of one class
-    struct c32_ { float x, y; };
-    c32_* xb = nullptr;              // block spectra of every class
+    void* blocks = nullptr;          // gathered signal blocks of one class (real)
+    void* xb = nullptr;              // block spectra of every class (complex)
     std::vector<FftPlan> ffts;
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take
@@ -54,14 +54,17 @@ struct BlockPlan {
     int run_exact(int sig, int nsig, const void* xh_all, float* Wx, float* dWx, float* w, unsigned short* kidx,
                   const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
 
-    int create(const ssq_cwt_blocks_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na,
+    int create(const ssq_cwt_blocks_desc& d, int dtype, int64_t M, int64_t N, int64_t n1, int64_t na,
                int64_t max_batch, int64_t& bytes);
     void destroy();
     // block spectra of all classes for the padded batch xp (max_batch x M)
-    int spectra(const float* xp, int64_t batch, hipStream_t stream);
+    int spectra(const void* xp, int64_t batch, hipStream_t stream);
     // all block rows of signals sig .. sig+nsig-1; kidx holds nsig maps
     int run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
             const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
+    // the same for a float64 plan (2048 points per 128-thread workgroup)
+    int run64(int sig, int nsig, double* Wx, double* dWx, double* w, unsigned short* kidx,
+              const double* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
 };
 
 }  // namespace ssq

@@ -272,7 +272,6 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
 int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
     SSQ_REQUIRE(pl && bd, "ssq_cwt_plan_set_blocks: null pointer");
     SSQ_REQUIRE(!pl->executed && !pl->blk, "block tables must be set once, before the first execute");
-    SSQ_REQUIRE(pl->d.dtype == SSQ_F32, "the block path is float32 only");
     SSQ_REQUIRE(pl->d.padtype != SSQ_PAD_NONE, "the block path needs a padded (power-of-two) length");
     SSQ_REQUIRE((pl->d.m & (pl->d.m - 1)) == 0, "the block path needs a power-of-two padded length");
     SSQ_REQUIRE(bd->n_classes >= 1 && bd->n_generic >= 0 && bd->n_generic <= pl->d.na, "bad block tables");
@@ -282,13 +281,13 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
     }
     auto* b = new BlockPlan();
     b->group = pl->group;
-    int rc = b->create(*bd, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->d.max_batch, pl->bytes);
+    int rc = b->create(*bd, pl->d.dtype, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->d.max_batch, pl->bytes);
     if (rc) { b->destroy(); delete b; return rc; }
     pl->blk = b;
     pl->n_gen = bd->n_generic;
     if (pl->n_gen)
         SSQ_CHECK_HIP(hipMemcpy(pl->gen_rows, bd->generic_rows, (size_t)pl->n_gen * 4, hipMemcpyHostToDevice));
-    if (pl->n_gen) {
+    if (pl->n_gen && pl->d.dtype == SSQ_F32) {      // four-step exact kernels: float32 only
         std::vector<int32_t> hg(bd->generic_rows, bd->generic_rows + bd->n_generic);
         rc = b->setup_exact((const float*)pl->bank, pl->band_off, pl->band_lo, pl->gen_rows,
                             pl->h_band_off, pl->h_band_lo, hg, pl->bytes);
@@ -362,10 +361,8 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     const bool use_blocks = pl->blk && !rpadded;
     const int64_t n_gen = use_blocks ? pl->n_gen : na;
     if (use_blocks) {
-        if constexpr (sizeof(T) == 4) {
-            int rc = pl->blk->spectra((const float*)pl->xp, batch, stream);
-            if (rc) return rc;
-        }
+        int rc = pl->blk->spectra(pl->xp, batch, stream);
+        if (rc) return rc;
     }
     mark(1);
     int64_t slot = 0;                                   // timing slot = launch group
@@ -377,6 +374,10 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
             if constexpr (sizeof(T) == 4) {
                 int rc = pl->blk->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)w, kidx,
                                       (const float*)pl->row_scale, d.dt, pl->sp, stream);
+                if (rc) return rc;
+            } else {
+                int rc = pl->blk->run64((int)b0, ng, (double*)Wx, (double*)dWx, (double*)w, kidx,
+                                        (const double*)pl->row_scale, d.dt, pl->sp, stream);
                 if (rc) return rc;
             }
         }

@@ -280,6 +280,149 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     }
 }
 
+// ======================================================================= float64 block rows
+// The same block decomposition in double precision: 2048 points per 128-thread workgroup
+// (32 KiB of LDS, 16 points per thread), twiddles and spectra in double, the exact
+// (double) bin map for every point. No lean variant, no LDS band staging.
+struct BlockArgs64 {
+    const int4* items; const BlockRowDev* rows; const BlockClassDev* classes;
+    const double* pbank; const double* pxi;
+    const c64* ctw; const c64* ftw; const c64* xb;
+    const double* row_scale;
+    double* Wx; double* dWx; double* w; unsigned short* kidx;
+    int64_t M, N, na, n_items;
+    double inv_dt, gamma;
+    int sig;
+};
+
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(FftGeom<double>::NT) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
+    constexpr int NT64 = FftGeom<double>::NT;
+    __shared__ c64 buf[FftGeom<double>::D];
+    __shared__ c64 spow[R1 * G];
+    __shared__ c64 wrapf[G];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x;
+    const int4 item = A.items[blockIdx.x];
+    const int row = item.x, blk = item.y, c0 = item.z;
+    const BlockRowDev r = A.rows[row];
+    const BlockClassDev cl = A.classes[item.w];
+    const int P = (int)cl.P, Rp = P / L;
+    const int sig = A.sig + (int)blockIdx.y;
+    const c64* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * (cl.P / 2 + 1);
+    const c64* ctw = A.ctw + cl.ctw_off;
+    const double* psi = A.pbank + r.pb_off;
+    const double* pxi = A.pxi + r.pb_off;
+    const double invP = 1.0 / (double)P;
+    {
+        constexpr int STR = L / R1;
+        for (int i = tid; i < R1 * G; i += NT64) {
+            const unsigned t = (unsigned)(i / G), col = (unsigned)(c0 + i % G);
+            spow[i] = ctw[(t * (unsigned)STR * col) & (unsigned)(P - 1)];
+        }
+        if (tid < G) {
+            const unsigned col = (unsigned)(c0 + tid);
+            wrapf[tid] = ctw[(0u - (unsigned)L * col) & (unsigned)(P - 1)];
+        }
+    }
+    __syncthreads();
+    c64 zw[PPT], zd[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT64, g = idx % G, u = idx / G;
+            const unsigned col = (unsigned)(c0 + g);
+            const int off0 = (u - r.klo) & (L - 1);
+            const c64 cw0 = ctw[((unsigned)(r.klo + off0) * col) & (unsigned)(P - 1)];
+            const c64 wf = wrapf[g];
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int offu = off0 + k * STR, off = offu & (L - 1);
+                const bool in = off < r.KP;
+                const int oc = in ? off : 0;                 // unconditional, clamped loads
+                const double p = psi[oc] * invP;
+                const c64 X = xb[r.klo + oc];
+                const double mm = pxi[oc] * A.inv_dt;
+                c64 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
+                if (offu >= L) cw = cmul(cw, wf);
+                const c64 bz = {p * X.x, p * X.y};
+                const c64 zz = cmul(bz, cw);
+                c64 z = {0.0, 0.0}, dz = {0.0, 0.0};
+                if (in) { z = zz; dz = {-(zz.y * mm), zz.x * mm}; }
+                zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
+            }
+        }
+    }
+    lds_ifft<L, G, R1, R2, R3>(zw, buf, A.ftw, tid);
+    lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
+
+    constexpr int NB = PPT / RL, STR = L / RL;
+    const int64_t base = ((int64_t)sig * A.na + row) * A.N;
+    double2* Wo = reinterpret_cast<double2*>(A.Wx) + base;
+    double2* Do = A.dWx ? reinterpret_cast<double2*>(A.dWx) + base : nullptr;
+    double* wo = A.w ? A.w + base : nullptr;
+    unsigned short* ko = A.kidx ? A.kidx + ((int64_t)blockIdx.y * A.na + row) * A.N : nullptr;
+    const double rs = A.row_scale ? A.row_scale[row] : 1.0;
+    const int64_t omax = A.na - 1;
+    const int m = (int)cl.m, N = (int)A.N;
+    const unsigned span = (unsigned)max(0, min((int)cl.V, N - blk * (int)cl.V));
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int idx = tid + it * NT64, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int dcol = (u + k * STR) * Rp + g + (c0 - m);
+            if ((unsigned)dcol >= span) continue;
+            const int j = dcol + blk * (int)cl.V;
+            const c64 W = zw[it * RL + k], D = zd[it * RL + k];
+            const double c = W.x * rs, d = W.y * rs, a = D.x * rs, b = D.y * rs;
+            Wo[j] = make_double2(c, d);
+            if (Do) Do[j] = make_double2(a, b);
+            if (wo) wo[j] = mag_lt(c, d, A.gamma) ? (double)INFINITY : fabs(phase_ratio(a, b, c, d));
+            if (ko) {
+                unsigned short kk = 0xFFFFu;
+                if (mag_gt(c, d, A.gamma)) {
+                    const int64_t kb = bin_of_point(a, b, c, d, false, 0.0, sp, omax);
+                    kk = (unsigned short)(sp.flipud ? omax - kb : kb);
+                }
+                ko[j] = kk;
+            }
+        }
+    }
+}
+
+template <int L, int G, int R1, int R2, int R3>
+static int launch_zoom64(const BlockArgs64& A, const SsqParams& sp, int nsig, hipStream_t stream) {
+    if (A.n_items == 0) return 0;
+    hipLaunchKernelGGL((blockzoom_f64_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items, (unsigned)nsig),
+                       dim3(FftGeom<double>::NT), 0, stream, A, sp);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+int BlockPlan::run64(int sig, int nsig, double* Wx, double* dWx, double* w, unsigned short* kidx,
+                     const double* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
+    BlockArgs64 A;
+    A.rows = rows; A.classes = classes; A.pbank = (const double*)pbank; A.pxi = (const double*)pxi;
+    A.ctw = (const c64*)ctw; A.xb = (const c64*)xb; A.row_scale = row_scale;
+    A.Wx = Wx; A.dWx = dWx; A.w = w; A.kidx = kidx;
+    A.M = M; A.N = N; A.na = na;
+    A.inv_dt = 1.0 / dt; A.gamma = sp.gamma; A.sig = sig;
+    int rc = 0;
+#define ZOOM64(slot, L, G, R1, R2, R3)                                                            \
+    A.items = (const int4*)items[slot]; A.n_items = n_items[slot];                                 \
+    A.ftw = (const c64*)ftw + ftw_off[slot];                                                       \
+    if ((rc = launch_zoom64<L, G, R1, R2, R3>(A, sp, nsig, stream))) return rc;
+    ZOOM64(0, 128, 16, 16, 8, 1)
+    ZOOM64(1, 256, 8, 16, 16, 1)
+    ZOOM64(2, 512, 4, 8, 8, 8)
+    ZOOM64(3, 1024, 2, 16, 8, 8)
+    ZOOM64(4, 2048, 1, 16, 16, 8)
+#undef ZOOM64
+    return 0;
+}
+
 // ======================================================================= exact rows
 // Rows whose impulse response is not compact (pass-band cut by the Nyquist frequency)
 // get the reference's full-length transform, as a four-step FFT over M = A x B with
@@ -442,8 +585,9 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
 }
 
 // gather overlapping blocks of the (periodic) padded signal for one class
-__global__ __launch_bounds__(256) void gather_blocks_kernel(const float* __restrict__ xp,
-                                                            float* __restrict__ blocks, int64_t M,
+template <typename T>
+__global__ __launch_bounds__(256) void gather_blocks_kernel(const T* __restrict__ xp,
+                                                            T* __restrict__ blocks, int64_t M,
                                                             int64_t n1, int64_t P, int64_t m,
                                                             int64_t V, int64_t nb, int64_t total) {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
@@ -467,9 +611,10 @@ static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStr
     return 0;
 }
 
-int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_,
-                      int64_t max_batch_, int64_t& bytes) {
-    M = M_; N = N_; n1 = n1_; na = na_; max_batch = max_batch_;
+int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int64_t N_, int64_t n1_,
+                      int64_t na_, int64_t max_batch_, int64_t& bytes) {
+    M = M_; N = N_; n1 = n1_; na = na_; max_batch = max_batch_; dtype = dtype_;
+    const size_t rs = dtype == SSQ_F32 ? 4 : 8;
     nc = d.n_classes;
     hcls.resize(nc);
     int64_t xb_total = 0, blk_max = 0;
@@ -492,20 +637,20 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int64_t M_, int64_t N_, int6
     if ((rc = up((void**)&classes, hcls.data(), sizeof(BlockClassDev) * nc))) return rc;
     static_assert(sizeof(BlockRowDev) == 6 * sizeof(int32_t), "row table layout");
     if ((rc = up((void**)&rows, d.rows, sizeof(BlockRowDev) * na))) return rc;
-    if ((rc = up((void**)&pbank, d.pbank, sizeof(float) * d.n_pbank))) return rc;
-    if ((rc = up((void**)&pxi, d.pxi, sizeof(float) * d.n_pbank))) return rc;
-    if ((rc = up((void**)&ctw, d.ctw, 8 * (size_t)d.ctw_off[nc]))) return rc;
-    if ((rc = up((void**)&ftw, d.ftw, 8 * (size_t)d.n_ftw))) return rc;
+    if ((rc = up((void**)&pbank, d.pbank, rs * d.n_pbank))) return rc;
+    if ((rc = up((void**)&pxi, d.pxi, rs * d.n_pbank))) return rc;
+    if ((rc = up((void**)&ctw, d.ctw, 2 * rs * (size_t)d.ctw_off[nc]))) return rc;
+    if ((rc = up((void**)&ftw, d.ftw, 2 * rs * (size_t)d.n_ftw))) return rc;
     for (int s = 0; s < 5; ++s) {
         n_items[s] = d.n_items[s];
         ftw_off[s] = d.ftw_off[s];
         if ((rc = up((void**)&items[s], d.items[s], sizeof(int4) * (size_t)d.n_items[s]))) return rc;
     }
-    SSQ_CHECK_HIP(hipMalloc((void**)&xb, 8 * (size_t)xb_total)); bytes += 8 * xb_total;
-    SSQ_CHECK_HIP(hipMalloc((void**)&blocks, 4 * (size_t)blk_max)); bytes += 4 * blk_max;
+    SSQ_CHECK_HIP(hipMalloc((void**)&xb, 2 * rs * (size_t)xb_total)); bytes += 2 * rs * xb_total;
+    SSQ_CHECK_HIP(hipMalloc((void**)&blocks, rs * (size_t)blk_max)); bytes += rs * blk_max;
     ffts.resize(nc);
     for (int c = 0; c < nc; ++c) {
-        rc = ffts[c].create(0, SSQ_F32, (size_t)hcls[c].P, (size_t)(max_batch * hcls[c].nb), 1.0);
+        rc = ffts[c].create(0, dtype, (size_t)hcls[c].P, (size_t)(max_batch * hcls[c].nb), 1.0);
         if (rc) return rc;
         bytes += (int64_t)ffts[c].work_bytes;
     }
@@ -520,16 +665,20 @@ void BlockPlan::destroy() {
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
-int BlockPlan::spectra(const float* xp, int64_t batch, hipStream_t stream) {
+int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream) {
     for (int c = 0; c < nc; ++c) {
         const BlockClassDev& k = hcls[c];
         int64_t total = max_batch * k.nb * k.P;
         (void)batch;
         unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(gather_blocks_kernel, dim3(g), dim3(256), 0, stream, xp, blocks, M, n1, k.P,
-                           k.m, k.V, k.nb, total);
+        if (dtype == SSQ_F32)
+            hipLaunchKernelGGL(gather_blocks_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)xp,
+                               (float*)blocks, M, n1, k.P, k.m, k.V, k.nb, total);
+        else
+            hipLaunchKernelGGL(gather_blocks_kernel<double>, dim3(g), dim3(256), 0, stream, (const double*)xp,
+                               (double*)blocks, M, n1, k.P, k.m, k.V, k.nb, total);
         SSQ_LAUNCH_CHECK();
-        int rc = ffts[c].execute(blocks, xb + k.xb_off, stream);
+        int rc = ffts[c].execute(blocks, (char*)xb + (size_t)k.xb_off * (dtype == SSQ_F32 ? 8 : 16), stream);
         if (rc) return rc;
     }
     return 0;
@@ -538,7 +687,8 @@ int BlockPlan::spectra(const float* xp, int64_t batch, hipStream_t stream) {
 int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
                    const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
     BlockArgs A;
-    A.rows = rows; A.classes = classes; A.pbank = pbank; A.pxi = pxi; A.ctw = (const c32*)ctw;
+    A.rows = rows; A.classes = classes; A.pbank = (const float*)pbank; A.pxi = (const float*)pxi;
+    A.ctw = (const c32*)ctw;
     A.xb = (const c32*)xb; A.row_scale = row_scale;
     A.Wx = Wx; A.dWx = dWx; A.w = w; A.kidx = kidx;
     A.M = M; A.N = N; A.na = na;
