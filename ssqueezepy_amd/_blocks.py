@@ -44,37 +44,87 @@ def _is_pow2(v):
     return v >= 1 and (v & (v - 1)) == 0
 
 
+def _tail_margin(f, tol, denoise):
+    """Smallest s with sum_{s' >= s} f[s'] <= tol * sum(f) for every row of the folded
+    magnitude response `f` (rows, half + 1); -1 where no such s exists."""
+    half = f.shape[1] - 1
+    tot = f.sum(1)
+    if denoise:
+        # the far half is rounding noise for a compact response, but real signal for a
+        # long one: never subtract more than 64 eps of the peak
+        floor = np.minimum(4 * np.median(f[:, half // 2:], axis=1, keepdims=True),
+                           64 * np.finfo(np.float64).eps * f.max(1, keepdims=True))
+        f = np.maximum(f - floor, 0)
+    cs = np.cumsum(f[:, ::-1], axis=1)[:, ::-1]          # cs[s] = sum_{s' >= s}
+    out = np.full(len(f), -1, np.int64)
+    for r in range(len(f)):
+        ok = np.nonzero(cs[r] <= tol * tot[r])[0]
+        if len(ok):
+            out[r] = ok[0]
+    return out
+
+
 def _margins(vals, off, lo, M, tol, chunk=32, denoise=False):
     """Per row: smallest m such that the impulse response's L1 mass outside
     [-m, m] (circularly, on the M-point grid) is <= tol * total. Double precision.
+
     `denoise`: subtract 4x the median magnitude of the far half of the response (the
     rounding-noise floor of the double-precision FFT, ~1e-17 of the peak per sample but
     ~1e-13 of the L1 norm once summed over M samples; capped at 64 eps of the peak) before
     accumulating -- needed to resolve tails at the 1e-14 level a float64 transform asks
-    for."""
+    for.
+
+    Cost control (the plain way is an M-point FFT per row: 10+ s of host time at
+    M = 2^21). The response of a row is measured on the shortest grid that represents it:
+      * narrow band (ends at bin hi): the response sampled every 2^d-th point is the
+        (M >> d)-point inverse FFT of the same band -- grid 8x the band, >= 8192 points;
+      * wide band, short response: the band sampled every s-th bin is the response
+        periodised with period M / s -- start at 16384 points and double until the
+        margin is below 1/8 of the period (a compact response is then unaffected);
+      * a band that reaches the Nyquist bin is cut there by the reference, its response
+        decays like 1/t: such rows go to the exact path without being measured."""
     na = len(lo)
     lens = np.diff(off)
-    out = np.empty(na, np.int64)
-    half = M // 2
-    for i0 in range(0, na, chunk):
-        rows = range(i0, min(na, i0 + chunk))
-        D = np.zeros((len(rows), M), np.complex128)
-        for r, i in enumerate(rows):
-            D[r, lo[i]:lo[i] + lens[i]] = vals[off[i]:off[i + 1]]
-        h = np.abs(sfft.ifft(D, axis=-1, workers=-1))
-        f = h[:, :half + 1].copy()
-        f[:, 1:half] += h[:, :half:-1]
-        tot = f.sum(1)
-        if denoise:
-            # the far half is rounding noise for a compact response, but real signal for a
-            # long one: never subtract more than 64 eps of the peak
-            floor = np.minimum(4 * np.median(f[:, half // 2:], axis=1, keepdims=True),
-                               64 * np.finfo(np.float64).eps * f.max(1, keepdims=True))
-            f = np.maximum(f - floor, 0)
-        cs = np.cumsum(f[:, ::-1], axis=1)[:, ::-1]      # cs[s] = sum_{s' >= s}
-        for r, i in enumerate(rows):
-            ok = np.nonzero(cs[r] <= tol * tot[r])[0]
-            out[i] = ok[0] if len(ok) else half
+    out = np.full(na, M // 2, np.int64)
+    todo = {}                                  # (kind, grid length) -> rows
+    for i in range(na):
+        hi = int(lo[i] + lens[i])
+        if lens[i] == 0 or hi >= M // 2 + 1:
+            continue                           # empty, or cut at Nyquist: exact path
+        d = 0
+        while (M >> (d + 1)) >= 8192 and 8 * hi <= (M >> (d + 1)):
+            d += 1
+        if d:
+            todo.setdefault(('time', M >> d), []).append(i)
+        else:
+            todo.setdefault(('freq', min(M, 16384)), []).append(i)
+    while todo:
+        (kind, Md), sel = todo.popitem()
+        half, step = Md // 2, M // Md
+        ch = max(1, chunk * max(1, (1 << 18) // Md))
+        for c0 in range(0, len(sel), ch):
+            rows = sel[c0:c0 + ch]
+            D = np.zeros((len(rows), Md), np.complex128)
+            for r, i in enumerate(rows):
+                band = vals[off[i]:off[i + 1]]
+                if kind == 'time':
+                    D[r, lo[i]:lo[i] + lens[i]] = band
+                else:                          # every `step`-th bin of the M-grid
+                    k0 = -(-int(lo[i]) // step)
+                    sub = band[k0 * step - int(lo[i])::step]
+                    D[r, k0:k0 + len(sub)] = sub
+            h = np.abs(sfft.ifft(D, axis=-1, workers=-1))
+            f = h[:, :half + 1].copy()
+            f[:, 1:half] += h[:, :half:-1]
+            m = _tail_margin(f, tol, denoise)
+            for r, i in enumerate(rows):
+                if kind == 'time':
+                    d = int(np.log2(step))
+                    out[i] = min(M // 2, ((int(m[r]) + 1) << d)) if m[r] >= 0 else M // 2
+                elif m[r] >= 0 and (8 * m[r] <= Md or Md == M):
+                    out[i] = min(M // 2, int(m[r]) + 4)     # periodisation folds a few samples
+                elif Md < M:                   # response not compact on this period: retry longer
+                    todo.setdefault(('freq', Md * 2), []).append(i)
     return out
 
 
