@@ -195,8 +195,8 @@ int  ssq_cwt_plan_set_ssq(ssq_cwt_plan* plan, int grid, const double* params,
 int  ssq_cwt_execute(ssq_cwt_plan* plan, const void* x, int64_t batch, void* Wx,
                      void* dWx, void* Tx, void* w, int rpadded, void* stream);
 
-/* Optional fast path ("overlap-save zoom" iFFT, float32, power-of-two m, analytic
- * bank): tables planned on the host (ssqueezepy_amd/_blocks.py documents the
+/* Optional fast path ("overlap-save zoom" iFFT, float32 or float64, power-of-two m,
+ * analytic bank): tables planned on the host (ssqueezepy_amd/_blocks.py documents the
  * decomposition; all pointers are host arrays, copied). Rows with class -1 in `rows`
  * -- listed in `generic_rows` -- keep using the exact full-length path.
  * Must be called before the first execute. No reference counterpart: the reference
@@ -206,12 +206,12 @@ typedef struct {
     int            n_classes;
     const int64_t* classes;      /* n_classes x 4: P, margin, valid, blocks/signal  */
     const int32_t* rows;         /* na x 6: class, kappa_lo, K_P, L', G, pbank_off  */
-    const float*   pbank;        /* P-grid band values of the block rows            */
-    const float*   pxi;          /* xi at the same bins (same indexing as pbank)    */
+    const void*    pbank;        /* P-grid band values of the block rows (plan dtype) */
+    const void*    pxi;          /* xi at the same bins (same indexing, plan dtype)   */
     int64_t        n_pbank;
-    const void*    ctw;          /* complex64 column twiddles exp(2i pi q/P)        */
+    const void*    ctw;          /* complex column twiddles exp(2i pi q/P) (plan dtype) */
     const int64_t* ctw_off;      /* n_classes + 1                                   */
-    const void*    ftw;          /* complex64 FFT twiddles exp(2i pi q/L')          */
+    const void*    ftw;          /* complex FFT twiddles exp(2i pi q/L') (plan dtype) */
     int64_t        n_ftw;
     int64_t        ftw_off[5];   /* per L' = 128, 256, 512, 1024, 2048              */
     const int32_t* items[5];     /* per L': n_items x 4: row, block, c0, class      */

@@ -138,7 +138,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
       classes  (nc, 4) int64: P, m (margin), V (valid), nb (blocks per signal)
       rows     (na, 6) int32: class (-1 = exact path), kappa_lo, K_P, L', G, pbank_off
       pbank    concatenated P-grid band values of the block rows (bank dtype)
-      pxi      xi (radian frequency) at the same bins, float32
+      pxi      xi (radian frequency) at the same bins, in the transform's dtype
       ctw      per class: exp(2i*pi*q/P), q in [0, P)   (complex, concatenated)
       ctw_off  (nc + 1) int64 offsets into ctw
       ftw      per L': exp(2i*pi*q/L'), concatenated for L' = 128..2048
@@ -199,7 +199,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
             sel = (np.arange(k_lo, k_lo + KP) * S - int(lo[i])) + int(off[i])
             pb.append(vals[sel])
             # xi at the band's bins, exactly the M-grid values the reference uses
-            # (k * 2pi/M formed in double, stored in float32: wavelets.py:473-484)
+            # (k * 2pi/M formed in double, stored in the wavelet dtype: wavelets.py:473-484)
             px.append((np.arange(k_lo, k_lo + KP) * S * (2 * np.pi / M)
                        ).astype(rdt))
             rows[i] = (c, k_lo, KP, Lp, G, pb_off)

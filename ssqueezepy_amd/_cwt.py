@@ -77,7 +77,7 @@ class CwtPlan():
 
     def _try_blocks(self, wavelet, vals, off, lo):
         """Plan and install the block ("overlap-save zoom") fast path when the
-        configuration admits it (float32, padded power-of-two length, analytic
+        configuration admits it (padded power-of-two length, analytic
         bank); see _blocks.py. Impulse-response margins are measured on the
         wavelet evaluated in float64 when it is a built-in family."""
         if self.padtype is None or os.environ.get('SSQ_CWT_ALGO') == 'generic':
