@@ -215,8 +215,11 @@ def main():
             # it moves Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point
             acc_bytes = na * N * 18
             line["stages_us_per_transform"] = stages
+            grp = min(plan.group, B)
             line["dominant_kernel"] = {
                 "name": "ssq::accumulate_tile16_kernel", "us": stages["reassignment_us"],
+                "signals_per_launch": grp,
+                "us_per_launch": stages["reassignment_us"] * grp,
                 "bytes_moved": acc_bytes,
                 "GBps": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9,
                 "frac_of_hbm_peak": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}

@@ -229,6 +229,10 @@ int  ssq_cwt_plan_set_blocks(ssq_cwt_plan* plan, const ssq_cwt_blocks_desc* desc
  * `enable` = 1 / 0 switches timing on / off and resets the accumulators, -1 only reads. */
 int  ssq_cwt_plan_timing(ssq_cwt_plan* plan, int enable, double* stage_ms, int64_t* signals);
 
+/* signals a plan processes per kernel launch (its launch group; the batch is walked in
+ * groups of this size) */
+int  ssq_cwt_plan_group(const ssq_cwt_plan* plan);
+
 /* bytes of device memory held by the plan (bank + workspace) */
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);
 /* name of the compute path the plan selected ("rocfft", "zoom+rocfft", ...) */

@@ -149,6 +149,11 @@ class CwtPlan():
     def device_bytes(self):
         return int(self.lib.ssq_cwt_plan_bytes(self._h))
 
+    @property
+    def group(self):
+        """signals per kernel launch (the batch is walked in groups of this size)"""
+        return int(self.lib.ssq_cwt_plan_group(self._h))
+
     def timing(self, enable=-1):
         """Per-stage HIP-event timing (see `ssq_cwt_plan_timing`): returns
         ``(stage_ms[4], n_signals)`` accumulated so far; `enable` 1/0 switches it on/off

@@ -92,6 +92,7 @@ _PROTOS = {
                                 c_void_p, c_void_p, c_int, c_void_p]),
     'ssq_cwt_plan_set_blocks': (c_int, [c_void_p, POINTER(CwtBlocksDesc)]),
     'ssq_cwt_plan_timing': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
+    'ssq_cwt_plan_group': (c_int, [c_void_p]),
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),

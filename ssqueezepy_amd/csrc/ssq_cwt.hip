@@ -309,6 +309,7 @@ int ssq_cwt_plan_timing(ssq_cwt_plan* pl, int enable, double* stage_ms, int64_t*
     return 0;
 }
 
+int ssq_cwt_plan_group(const ssq_cwt_plan* pl) { return pl ? pl->group : 0; }
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* pl) { return pl ? pl->bytes : 0; }
 const char* ssq_cwt_plan_algo(const ssq_cwt_plan* pl) { return pl ? pl->algo.c_str() : ""; }
 
