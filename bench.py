@@ -112,10 +112,18 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    # validation aids (a 1-GPU box cannot host two RCCL ranks): SSQ_BENCH_BACKEND=gloo with
+    # SSQ_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 to exercise the N > 1 code path
+    backend = os.environ.get('SSQ_BENCH_BACKEND', 'nccl')
+    if os.environ.get('SSQ_BENCH_ONE_DEVICE'):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 

@@ -32,12 +32,15 @@ def shard_signals(x, world_size, rank):
     return x[lo:hi]
 
 
-def signal_summary(Tx, Wx):
-    """Per-signal checksums (2 floats each): sum |Tx|, sum |Wx| -- cheap,
-    order-insensitive fingerprints of the device-resident results."""
+def signal_summary(Tx, Wx, cols=4096):
+    """Per-signal checksums (2 floats each): sum |Tx|, sum |Wx| over the first `cols`
+    time samples (None = all) -- cheap, order-insensitive fingerprints of the
+    device-resident results (a full pass would move more bytes than a transform)."""
     import torch
     if Tx.ndim == 2:
         Tx, Wx = Tx[None], Wx[None]
+    if cols is not None:
+        Tx, Wx = Tx[..., :cols], Wx[..., :cols]
     return torch.stack([Tx.abs().sum(dim=(1, 2)).double(),
                         Wx.abs().sum(dim=(1, 2)).double()], dim=1)
 
@@ -52,8 +55,12 @@ def gather_summaries(local, n_signals, group=None):
     cap = -(-int(n_signals) // world)                     # max block size
     buf = torch.zeros((cap, k), dtype=local.dtype, device=local.device)
     buf[:local.shape[0]] = local.reshape(-1, k)
+    dev = buf.device
+    if buf.is_cuda and dist.get_backend(group) == 'gloo':
+        buf = buf.cpu()                                   # gloo gathers host tensors
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
+    out = [o.to(dev) for o in out]
     rows = []
     for r in range(world):
         lo, hi = shard_bounds(n_signals, world, r)
