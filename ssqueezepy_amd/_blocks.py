@@ -162,15 +162,19 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
         return None                                   # negative-frequency content
     margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol, denoise=f64)
 
-    # block classes: P = 4096, 8192, ..., M/2 (margin P/8, valid 3P/4) and the
-    # "global" class P = M (one block, no margin needed: the circular convolution
-    # over the padded signal *is* the reference's definition)
-    Ps = []
+    # block classes (P, margin): P = 4096, 8192, ..., M/2 with margin P/8 (valid 3P/4),
+    # and the "global" class P = M (one block, no margin needed: the circular convolution
+    # over the padded signal *is* the reference's definition). A row takes the shortest
+    # block whose margin covers its response, so its margin lies in (P/16, P/8] -- except
+    # at the smallest block length, where short responses would waste most of a P/8
+    # margin: P_MIN also comes with margins P/32 and P/16 (valid 15/16 and 7/8 of P; each
+    # class costs a gather + FFT of the signal's blocks, so a P/64 class does not pay).
+    cands = []
     P = P_MIN
     while P < M:
-        Ps.append(P)
+        cands += [(P, den) for den in ((32, 16, 8) if P == P_MIN else (8,))]
         P *= 2
-    Ps.append(M)
+    cands.append((M, 1))
     cls_of = np.full(na, -1, np.int64)
     rows = np.zeros((na, 6), np.int32)
     rows[:, 0] = -1
@@ -178,8 +182,8 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
     for i in range(na):
         if lens[i] == 0:
             continue
-        for c, P in enumerate(Ps):
-            if P < M and 8 * margins[i] > P:
+        for c, (P, mden) in enumerate(cands):
+            if P < M and mden * margins[i] > P:
                 continue
             S = M // P
             k_lo = -(-int(lo[i]) // S)                       # ceil(lo / S)
@@ -212,11 +216,12 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
     classes = np.zeros((len(used), 4), np.int64)
     ctw, ctw_off = [], [0]
     for c in used:
-        P = Ps[c]
+        P, mden = cands[c]
         if P == M:
             m, V, nb, t0 = 0, M, 1, 0
         else:
-            m, V = P // 8, 3 * P // 4
+            m = P // mden
+            V = P - 2 * m
             nb = -(-N // V)
         classes[remap[c]] = (P, m, V, nb)
         q = np.arange(P)
