@@ -21,6 +21,7 @@ struct BlockClassDev {
     int64_t P, m, V, nb;    // block length, margin, valid length, blocks per signal
     int64_t ctw_off;        // offset of the class' column twiddles
     int64_t xb_off;         // offset of the class' block spectra
+    int64_t blk_off;        // offset of the class' gathered blocks
 };
 
 struct BlockPlan {
@@ -39,7 +40,8 @@ struct BlockPlan {
     int64_t ftw_off[5] = {0, 0, 0, 0, 0};
     void* blocks = nullptr;          // gathered signal blocks of one class (real)
     void* xb = nullptr;              // block spectra of every class (complex)
-    std::vector<FftPlan> ffts;
+    std::vector<FftPlan> ffts;       // one per run of classes with the same block length
+    std::vector<int> fft_first;      // first class of each run
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take
     bool exact_ok = false;

@@ -584,18 +584,23 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     }
 }
 
-// gather overlapping blocks of the (periodic) padded signal for one class
+// gather the overlapping blocks of the (periodic) padded signals, all classes in one
+// launch (blockIdx.y = class)
 template <typename T>
 __global__ __launch_bounds__(256) void gather_blocks_kernel(const T* __restrict__ xp,
-                                                            T* __restrict__ blocks, int64_t M,
-                                                            int64_t n1, int64_t P, int64_t m,
-                                                            int64_t V, int64_t nb, int64_t total) {
+                                                            T* __restrict__ blocks,
+                                                            const BlockClassDev* __restrict__ classes,
+                                                            int64_t M, int64_t n1, int64_t batch) {
+    const BlockClassDev k = classes[blockIdx.y];
+    const int64_t total = batch * k.nb * k.P;
+    const int64_t lead = (k.P == M) ? 0 : n1 - k.m;       // the single-block class starts at 0
+    T* out = blocks + k.blk_off;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t p = t % P, bb = t / P, b = bb % nb, s = bb / nb;
-        int64_t src = (n1 - m + b * V + p) % M;
+        int64_t p = t % k.P, bb = t / k.P, b = bb % k.nb, s = bb / k.nb;
+        int64_t src = (lead + b * k.V + p) % M;
         if (src < 0) src += M;
-        blocks[t] = xp[s * M + src];
+        out[t] = xp[s * M + src];
     }
 }
 
@@ -625,7 +630,8 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
         k.ctw_off = d.ctw_off[c];
         k.xb_off = xb_total;
         xb_total += max_batch * k.nb * (k.P / 2 + 1);
-        blk_max = std::max<int64_t>(blk_max, max_batch * k.nb * k.P);
+        k.blk_off = blk_max;
+        blk_max += max_batch * k.nb * k.P;
     }
     auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
         SSQ_CHECK_HIP(hipMalloc(dst, nbytes ? nbytes : 1));
@@ -648,11 +654,18 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
     }
     SSQ_CHECK_HIP(hipMalloc((void**)&xb, 2 * rs * (size_t)xb_total)); bytes += 2 * rs * xb_total;
     SSQ_CHECK_HIP(hipMalloc((void**)&blocks, rs * (size_t)blk_max)); bytes += rs * blk_max;
-    ffts.resize(nc);
-    for (int c = 0; c < nc; ++c) {
-        rc = ffts[c].create(0, dtype, (size_t)hcls[c].P, (size_t)(max_batch * hcls[c].nb), 1.0);
+    // classes of equal block length are contiguous in `blocks` and `xb`: one batched
+    // real-to-complex transform per length
+    for (int c = 0; c < nc;) {
+        int e = c;
+        int64_t nblocks = 0;
+        while (e < nc && hcls[e].P == hcls[c].P) nblocks += max_batch * hcls[e++].nb;
+        FftPlan fp;
+        rc = fp.create(0, dtype, (size_t)hcls[c].P, (size_t)nblocks, 1.0);
         if (rc) return rc;
-        bytes += (int64_t)ffts[c].work_bytes;
+        bytes += (int64_t)fp.work_bytes;
+        ffts.push_back(fp); fft_first.push_back(c);
+        c = e;
     }
     n_generic = d.n_generic;
     return 0;
@@ -666,19 +679,22 @@ void BlockPlan::destroy() {
 }
 
 int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream) {
-    for (int c = 0; c < nc; ++c) {
-        const BlockClassDev& k = hcls[c];
-        int64_t total = max_batch * k.nb * k.P;
-        (void)batch;
-        unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
-        if (dtype == SSQ_F32)
-            hipLaunchKernelGGL(gather_blocks_kernel<float>, dim3(g), dim3(256), 0, stream, (const float*)xp,
-                               (float*)blocks, M, n1, k.P, k.m, k.V, k.nb, total);
-        else
-            hipLaunchKernelGGL(gather_blocks_kernel<double>, dim3(g), dim3(256), 0, stream, (const double*)xp,
-                               (double*)blocks, M, n1, k.P, k.m, k.V, k.nb, total);
-        SSQ_LAUNCH_CHECK();
-        int rc = ffts[c].execute(blocks, (char*)xb + (size_t)k.xb_off * (dtype == SSQ_F32 ? 8 : 16), stream);
+    (void)batch;                                   // planned batch: stale rows are ignored later
+    int64_t most = 0;
+    for (const auto& k : hcls) most = std::max<int64_t>(most, max_batch * k.nb * k.P);
+    dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 2048), (unsigned)nc);
+    if (dtype == SSQ_F32)
+        hipLaunchKernelGGL(gather_blocks_kernel<float>, grid, dim3(256), 0, stream, (const float*)xp,
+                           (float*)blocks, classes, M, n1, max_batch);
+    else
+        hipLaunchKernelGGL(gather_blocks_kernel<double>, grid, dim3(256), 0, stream, (const double*)xp,
+                           (double*)blocks, classes, M, n1, max_batch);
+    SSQ_LAUNCH_CHECK();
+    const size_t rs = dtype == SSQ_F32 ? 4 : 8;
+    for (size_t f = 0; f < ffts.size(); ++f) {
+        const BlockClassDev& k = hcls[fft_first[f]];
+        int rc = ffts[f].execute((char*)blocks + (size_t)k.blk_off * rs,
+                                 (char*)xb + (size_t)k.xb_off * 2 * rs, stream);
         if (rc) return rc;
     }
     return 0;
