@@ -1,0 +1,93 @@
+# -*- coding: utf-8 -*-
+"""Host-side planning of the block ("overlap-save zoom") CWT path (ssqueezepy_amd/_blocks.py):
+structural invariants of the tables the kernels trust, and the margin measurement on
+adaptive grids against the plain full-length measurement. CPU only."""
+import numpy as np
+import pytest
+import scipy.fft as sfft
+
+from ssqueezepy_amd.wavelets import Wavelet
+from ssqueezepy_amd.scales import process_scales
+from ssqueezepy_amd._bank import banded_bank
+from ssqueezepy_amd.padding import pad_geometry
+from ssqueezepy_amd import _blocks
+
+
+def _bank(N, nv, dtype, wavelet='gmw'):
+    wav = Wavelet((wavelet, {'dtype': dtype}))
+    scales = np.asarray(process_scales('log', N, wav, nv=nv), dtype=dtype).reshape(-1)
+    M, n1, _ = pad_geometry(N)
+    tol = 1e-3 * np.finfo(dtype).eps
+    vals, off, lo = banded_bank(wav, scales, M, tol=tol)
+    v64 = None
+    if dtype == 'float32':
+        tw = Wavelet((wavelet, {'dtype': 'float64'}))
+        v64, o64, l64 = banded_bank(tw, scales.astype('float64'), M, tol=tol)
+        assert np.array_equal(o64, off) and np.array_equal(l64, lo)
+    return vals, off, lo, M, n1, v64
+
+
+@pytest.mark.parametrize('N,nv,dtype', [(6000, 8, 'float32'), (20000, 16, 'float32'),
+                                        (50000, 4, 'float64'), (4097, 8, 'float64')])
+def test_plan_invariants(N, nv, dtype):
+    vals, off, lo, M, n1, v64 = _bank(N, nv, dtype)
+    bp = _blocks.plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=v64)
+    assert bp is not None
+    points = _blocks.POINTS_PER_WG[dtype]
+    cls, rows = bp['classes'], bp['rows']
+    lens = np.diff(off)
+    for P, m, V, nb in cls:
+        assert P & (P - 1) == 0 and _blocks.P_MIN <= P <= M
+        if P == M:
+            assert (m, V, nb) == (0, M, 1)
+        else:
+            assert V == P - 2 * m and m >= P // 32 and nb == -(-N // V)
+    n_items = 0
+    for i, (c, klo, KP, Lp, G, pboff) in enumerate(rows):
+        if c < 0:
+            assert i in bp['generic_rows']
+            continue
+        P, m, V, nb = cls[c]
+        S = M // P
+        assert Lp * G == points and KP <= Lp and Lp <= _blocks.L_MAX and P // Lp >= G
+        # the P-grid band covers every P-grid bin inside the row's M-grid band
+        assert klo * S >= lo[i] and (klo + KP - 1) * S <= lo[i] + lens[i] - 1
+        assert (klo - 1) * S < lo[i] and (klo + KP) * S > lo[i] + lens[i] - 1
+        # the margin covers the measured response (the single-block class needs none)
+        assert P == M or bp['margins'][i] <= m
+        # band values are the M-grid bank sampled every S-th bin
+        sel = np.arange(klo, klo + KP) * S - lo[i] + off[i]
+        assert np.array_equal(bp['pbank'][pboff:pboff + KP], vals[sel])
+        n_items += nb * (P // Lp) // G
+    assert n_items == sum(len(v) for v in bp['items'].values())
+    for Lp, it in bp['items'].items():
+        r = rows[it[:, 0]]
+        assert np.all(r[:, 3] == Lp) and np.all(it[:, 3] == r[:, 0])
+        assert np.all(it[:, 2] % r[:, 4] == 0)
+    assert len(bp['generic_rows']) + np.count_nonzero(rows[:, 0] >= 0) == len(rows)
+
+
+def _margins_plain(vals, off, lo, M, tol):
+    na, lens, half = len(lo), np.diff(off), M // 2
+    out = np.empty(na, np.int64)
+    for i in range(na):
+        D = np.zeros(M, np.complex128)
+        D[lo[i]:lo[i] + lens[i]] = vals[off[i]:off[i + 1]]
+        h = np.abs(sfft.ifft(D))
+        f = h[:half + 1].copy()
+        f[1:half] += h[:half:-1]
+        cs = np.cumsum(f[::-1])[::-1]
+        ok = np.nonzero(cs <= tol * f.sum())[0]
+        out[i] = ok[0] if len(ok) else half
+    return out
+
+
+def test_adaptive_margins_match_the_full_length_measurement():
+    vals, off, lo, M, n1, v64 = _bank(20000, 16, 'float32')
+    fast = _blocks._margins(v64, off, lo, M, 1e-9)
+    plain = _margins_plain(v64, off, lo, M, 1e-9)
+    nyq = (lo + np.diff(off)) >= M // 2 + 1          # sent to the exact path unmeasured
+    assert np.all(fast[nyq] == M // 2)
+    d = (fast - plain)[~nyq]
+    # never short by more than the slack the classes have anyway, never long by > 2 %
+    assert d.min() >= -2 and np.all(d <= 0.02 * plain[~nyq] + 8)
