@@ -64,6 +64,13 @@ def _compute_associated_frequencies(scales, N, wavelet, ssq_scaletype, maprange,
     (fm, fM) for 'log', two exponential pieces joined at the scale-rate change
     for 'log-piecewise', linear otherwise."""
     fm, fM = _ssq_freqrange(maprange, dt, N, wavelet, scales, was_padded)
+    if not (np.isfinite(fm) and np.isfinite(fM) and fm > 0 and fM > 0):
+        # e.g. a compactly supported wavelet sampled at a scale where none of its
+        # support lands on the grid: no peak to map (the reference fails here too, with
+        # "cannot convert float NaN to integer")
+        raise ValueError("could not determine the frequency range of the transform "
+                         "(wavelet has no peak on the grid at the extreme scales); "
+                         "pass `ssq_freqs` / `maprange` explicitly or adjust `scales`")
     na = len(scales)
     if ssq_scaletype == 'log':
         return fm * np.power(fM / fm, np.arange(na) / (na - 1))

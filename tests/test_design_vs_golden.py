@@ -130,3 +130,18 @@ def test_higher_order_gmw_samples():
     for k in (1, 2):
         wav = Wavelet(('gmw', {'order': k, 'norm': 'energy', 'dtype': 'float64'}))
         assert np.array_equal(wav.fn(w.copy()), g[f'psih_l2/float64/{k}'], equal_nan=True)
+
+
+def test_degenerate_frequency_range_raises():
+    """A compactly supported wavelet whose support misses the grid at the extreme scales
+    has no peak frequency to map (the reference crashes with "cannot convert float NaN to
+    integer"): a clear ValueError instead of a NaN frequency grid."""
+    import pytest
+    from ssqueezepy_amd.wavelets import Wavelet
+    from ssqueezepy_amd.scales import process_scales
+    from ssqueezepy_amd.ssqueezing import _compute_associated_frequencies
+    wav = Wavelet(('bump', {'dtype': 'float32'}))
+    N = 9492
+    scales, st, _, nv = process_scales('log', N, wav, nv=4, get_params=True)
+    with pytest.raises(ValueError):
+        _compute_associated_frequencies(scales, N, wav, st, 'peak', True, 1., 'cwt')

@@ -1,0 +1,72 @@
+# -*- coding: utf-8 -*-
+"""Randomised parity sweep (design aid): ssq_cwt / ssq_stft on the device against the CPU
+oracle pipeline for random lengths, voices, wavelets, pad types, dtypes and batch sizes.
+    python tools/fuzz_parity.py [n_cases] [seed]
+Prints one line per case; exits non-zero on the first mismatch."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import ssqueezepy_amd as S
+from oracle import oracle as orc
+from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
+from conftest import two_chirps
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def main(n_cases=30, seed=0):
+    rng = np.random.default_rng(seed)
+    orc.lib()
+    for case in range(n_cases):
+        dtype = rng.choice(['float32', 'float64'])
+        tol = 1e-5 if dtype == 'float32' else 1e-11
+        if rng.random() < 0.7:
+            N = int(rng.integers(200, 30000))
+            nv = int(rng.choice([4, 8, 16]))
+            fam = rng.choice(['gmw', 'morlet', 'bump'])
+            pad = rng.choice(['reflect', 'zero', 'symmetric', 'wrap', 'replicate'])
+            st = rng.choice(['log', 'log-piecewise'])
+            x = two_chirps(N, seed=case)
+            wav = S.Wavelet((fam, {'dtype': dtype}))
+            try:
+                Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=st, nv=nv, padtype=pad,
+                                                get_dWx=True, astensor=False)
+            except ValueError as e:           # degenerate design (the reference fails too)
+                print('cwt ', dtype, fam, st, pad, 'N=%d nv=%d' % (N, nv), 'SKIP:', str(e)[:60])
+                continue
+            r = oracle_ssq_cwt(orc, x, dtype, wavelet=fam, scales=st, nv=nv, padtype=pad)
+            eW, eD = relmax(Wx, r['Wx']), relmax(dWx, r['dWx'])
+            ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'],
+                               r['gamma'], True, typing=0)
+            ok = eW <= tol and eD <= tol and np.array_equal(Tx, ref) and \
+                np.array_equal(sf, r['ssq_freqs'])
+            print('cwt ', dtype, fam, st, pad, 'N=%d nv=%d na=%d' % (N, nv, len(sc)),
+                  'eW=%.1e eD=%.1e' % (eW, eD), 'OK' if ok else 'MISMATCH')
+        else:
+            N = int(rng.integers(300, 20000))
+            n_fft = int(rng.choice([64, 100, 128, 256, 512, 1000, 1024]))
+            n_fft = min(n_fft, N // 2)
+            hop = int(rng.integers(1, max(2, n_fft // 2)))
+            mod = bool(rng.random() < 0.7)
+            x = two_chirps(N, seed=case)
+            Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, modulated=mod,
+                                              dtype=dtype, get_dWx=True, astensor=False)
+            ro = oracle_ssq_stft(orc, x, dtype, n_fft=n_fft, hop_len=hop, modulated=mod)
+            eS, eD = relmax(Sx, ro['Sx']), relmax(dSx, ro['dSx'])
+            from ssqueezepy_amd.ssqueezing import ssq_grid_params
+            _, p = ssq_grid_params(Sfs, False)
+            ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], ro['gamma'], False,
+                               Sfs=Sfs, typing=0)
+            ok = eS <= tol and eD <= tol and np.array_equal(Tx, ref)
+            print('stft', dtype, 'N=%d n_fft=%d hop=%d mod=%d' % (N, n_fft, hop, mod),
+                  'eS=%.1e eD=%.1e' % (eS, eD), 'OK' if ok else 'MISMATCH')
+        if not ok:
+            sys.exit(1)
+    print('all %d cases OK' % n_cases)
+
+
+if __name__ == '__main__':
+    main(*(int(a) for a in sys.argv[1:3]))
