@@ -26,9 +26,11 @@ def main(n_cases=30, seed=0):
         if rng.random() < 0.7:
             N = int(rng.integers(200, 30000))
             nv = int(rng.choice([4, 8, 16]))
-            fam = rng.choice(['gmw', 'morlet', 'bump'])
+            fam = rng.choice(['gmw', 'morlet', 'bump', 'cmhat', 'hhhat'])
             pad = rng.choice(['reflect', 'zero', 'symmetric', 'wrap', 'replicate'])
-            st = rng.choice(['log', 'log-piecewise'])
+            st = rng.choice(['log', 'log-piecewise', 'linear'])
+            if st == 'linear':
+                N = int(rng.integers(200, 1500))       # one row per sample spacing: keep small
             x = two_chirps(N, seed=case)
             wav = S.Wavelet((fam, {'dtype': dtype}))
             try:
@@ -43,6 +45,13 @@ def main(n_cases=30, seed=0):
                                r['gamma'], True, typing=0)
             ok = eW <= tol and eD <= tol and np.array_equal(Tx, ref) and \
                 np.array_equal(sf, r['ssq_freqs'])
+            if ok and rng.random() < 0.4:             # batched == single, get_w == oracle phase
+                xb = np.stack([x, x[::-1].copy(), 2 * x])
+                Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales=st, nv=nv, padtype=pad, astensor=False)
+                ok = np.array_equal(Wb[0], Wx) and np.array_equal(Tb[0], Tx)
+                out = S.ssq_cwt(x, wav, scales=st, nv=nv, padtype=pad, get_w=True,
+                                astensor=False)
+                ok = ok and np.array_equal(out[4], orc.phase_cwt(out[1], dWx, r['gamma'], typing=0))
             print('cwt ', dtype, fam, st, pad, 'N=%d nv=%d na=%d' % (N, nv, len(sc)),
                   'eW=%.1e eD=%.1e' % (eW, eD), 'OK' if ok else 'MISMATCH')
         else:
