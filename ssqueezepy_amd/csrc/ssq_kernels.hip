@@ -176,19 +176,19 @@ __global__ __launch_bounds__(64) void accumulate_tile_kernel(
 // "load -> bin -> LDS read -> fold -> LDS write" of one column is serial by
 // definition (ascending-row summation order), so the kernel (a) makes the chain short
 // and (b) keeps many independent chains per SIMD:
-//   * a wavefront owns 4 adjacent columns x 16 row-lanes (lane = 16*col + rl); the 16
-//     rows of a step are combined in registers: every lane reads its target cell once,
-//     folds in -- in ascending row order, the reference's summation order, bit for bit
-//     -- the terms of the lower row-lanes of its column that hit the same cell (DPP
-//     row_shr moves within the 16-lane row), and only the highest lane of a cell writes
-//     it back: one LDS read + one LDS write per 16 rows, 19 steps for 300 rows;
-//   * a workgroup is 4 such wavefronts (16 columns, 128-byte row segments between
-//     them); its Tx tile (na x 16 cells) lives in LDS, 4 workgroups = 16 wavefronts per
-//     CU, and the wavefronts never synchronise with each other;
-//   * row batches are double-buffered in registers (U steps = 16*U rows in flight per
-//     column), including the per-row weights.
-//   * cells are stored skewed (cell (k, c) at 4*k + ((c + k) & 3) of the wave's slab)
-//     to spread the four columns of a wave over LDS banks.
+//   * a wavefront owns WC adjacent columns x RL row-lanes (RL = 8, WC = 8 for float32;
+//     RL = 16, WC = 4 for float64; lane = RL*col + rl); the RL rows of a step are combined
+//     in registers: every lane reads its target cell once, folds in -- in ascending row
+//     order, the reference's summation order, bit for bit -- the terms of the lower
+//     row-lanes of its column that hit the same cell (DPP row_shr moves), and only the
+//     highest lane of a cell writes it back: one LDS read + one LDS write per RL rows;
+//   * a workgroup is 16/WC such wavefronts (16 columns, 128-byte row segments between
+//     them in float32); its Tx tile (na x 16 cells) lives in LDS, 4 workgroups per CU, and
+//     the wavefronts never synchronise with each other;
+//   * a few row batches are kept in flight in registers per lane (rolling prefetch of
+//     depth U; loads unconditional so that the compiler can count them);
+//   * cells are stored skewed (cell (k, c) at WC*k + ((c + k) & (WC-1)) of the wave's
+//     slab) to spread the columns of a wave over LDS banks.
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int old, int v) {
     return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
 }
@@ -222,24 +222,39 @@ template <> struct Term<float, true> {
 // distance and (b) the "a higher row-lane hits my cell" mask: lane L+N matching at
 // distance N is lane L having a higher partner at distance N (row_shr never crosses a
 // 16-lane row, so mask >> N stays inside the column).
-template <int N, typename TM, typename T, typename term_t>
+// SC (scalar combine): the per-distance decision is one DPP move + one compare, the rest
+// scalar -- measured faster with 8 row-lanes (245 vs 263 us), slower with 16 (263 vs 257),
+// so each layout keeps the form that suits it.
+template <int N, bool SC, typename TM, typename T, typename term_t>
 struct FoldLower {
-    static __device__ __forceinline__ void run(int k, term_t tr, term_t ti, T& ore, T& oim,
-                                               unsigned long long& higher) {
-        const int ks = dpp_mov<0x110 + N>(-1, k);           // row_shr:N, -1 where no source
-        const bool m = (ks == k) & (k >= 0);
-        const unsigned long long mask = __ballot(m);
+    static __device__ __forceinline__ void run(int k, unsigned long long valid, term_t tr, term_t ti,
+                                               T& ore, T& oim, unsigned long long& higher) {
+        // row_shr:N with bound_ctrl: lanes without a source in their row read 0. Keys are
+        // bin + 1 (0 = "takes no part", `valid` = the wave mask of k != 0), so a lane that
+        // takes part never matches a missing source.
+        const int ks = __builtin_amdgcn_update_dpp(0, k, 0x110 + N, 0xF, 0xF, true);
+        bool m;
+        unsigned long long mask;
+        if constexpr (SC) {
+            const bool e = ks == k;
+            mask = __builtin_amdgcn_ballot_w64(e) & valid;
+            m = e & (k != 0);
+        } else {
+            m = (ks == k) & (k != 0);
+            mask = __ballot(m);
+        }
         if (mask) {                                         // wave-uniform
             higher |= mask >> N;
             term_t rs = dpp_mov<0x110 + N>(term_t(0), tr), is = dpp_mov<0x110 + N>(term_t(0), ti);
             if (m) { ore = TM::fold(ore, rs); oim = TM::fold(oim, is); }
         }
-        FoldLower<N - 1, TM, T, term_t>::run(k, tr, ti, ore, oim, higher);
+        FoldLower<N - 1, SC, TM, T, term_t>::run(k, valid, tr, ti, ore, oim, higher);
     }
 };
-template <typename TM, typename T, typename term_t>
-struct FoldLower<0, TM, T, term_t> {
-    static __device__ __forceinline__ void run(int, term_t, term_t, T&, T&, unsigned long long&) {}
+template <bool SC, typename TM, typename T, typename term_t>
+struct FoldLower<0, SC, TM, T, term_t> {
+    static __device__ __forceinline__ void run(int, unsigned long long, term_t, term_t, T&, T&,
+                                               unsigned long long&) {}
 };
 
 // RL = row-lanes per column (16 or 8): a wavefront covers WC = 64/RL columns and the
@@ -326,7 +341,9 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
             }
             request(u, i + RL * U);                 // refill the slot
             unsigned long long higher = 0;
-            FoldLower<RL - 1, TM, T, term_t>::run(k >= 0 ? (k | colkey) : -1, tr, ti, ore, oim, higher);
+            const int key = k >= 0 ? (k | colkey) + 1 : 0;
+            FoldLower<RL - 1, (RL < 16), TM, T, term_t>::run(key, __builtin_amdgcn_ballot_w64(key != 0), tr, ti,
+                                                             ore, oim, higher);
             ore = TM::fold(ore, tr); oim = TM::fold(oim, ti);
             const bool last = !((higher >> lane) & 1ull);
             if (k >= 0 && last) { cell[0] = ore; cell[1] = oim; }
@@ -516,14 +533,19 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
         if ((size_t)na * (size_t)n < ((size_t)1 << 31)) {      // 32-bit offsets inside
             dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
             static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
-            if (variant != 2) {        // default: 16 row-lanes x 4 waves per tile
-                // Row batches in flight per lane. Measured (config 2, float32): U = 2: 257 us,
-                // 3: 263, 4: 259, 8: 278 -- with 16 wavefronts per CU the latency is covered
-                // by the other wavefronts, and a deeper prefetch spreads each wavefront's
-                // requests over more DRAM pages.
-                constexpr int U = sizeof(T) == 4 ? 2 : 4;
-                if (variant == 3) {    // 8 row-lanes x 8 columns per wavefront, 2 wavefronts per tile
-                    auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U, 2, 8>;
+            if (variant != 2) {        // row-lane layouts (variant 2: one wavefront per tile, quads)
+                // Row batches in flight per lane. Measured (config 2, float32), 16 row-lanes:
+                // U = 2: 257 us, 3: 263, 4: 259, 8: 278; 8 row-lanes: U = 1: 314, 2: 246, 3: 240,
+                // 4: 243, 8: 267 -- the resident wavefronts cover most of the latency, and a
+                // deep prefetch spreads each wavefront's requests over more DRAM pages.
+                constexpr int U = sizeof(T) == 4 ? 2 : 4;       // 16 row-lanes
+                constexpr int U8 = 3;                           // 8 row-lanes
+                // default: float32 -> 8 row-lanes x 8 columns per wavefront, 2 wavefronts per tile
+                // (240 us at config 2 vs 250 with 16 row-lanes); float64 -> 16 row-lanes x 4 columns,
+                // 4 wavefronts (config 5: 22.7 vs 23.6 ms).
+                // SSQ_ACC_VARIANT = 1 / 3 force the 16- / 8-lane layout.
+                if (variant == 3 || (variant == 0 && sizeof(T) == 4)) {
+                    auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U8, 2, 8>;
                     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(kern, grid, dim3(128), lds, stream, (const T*)Wx, src, (const T*)Sfs,
