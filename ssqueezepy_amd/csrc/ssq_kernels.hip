@@ -262,13 +262,13 @@ struct FoldLower<0, SC, TM, T, term_t> {
 // row; their keys are made distinct so that a shift across the boundary never matches.
 // Fold work per column falls with RL (RL-1 distances per RL rows) and so does the
 // number of resident wavefronts (LDS per wavefront grows with WC).
-template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS, int RL>
-__global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_kernel(
+template <typename T, int BINSRC, bool STFT, bool CST64, int U, int WPS, int RL, int TC = 16>
+__global__ __launch_bounds__(64 * (TC / (64 / RL)), WPS) void accumulate_tile16_kernel(
     const T* __restrict__ Wx, const void* __restrict__ src, const T* __restrict__ Sfs,
     T* __restrict__ Tx, const void* __restrict__ cst, SsqParams sp, int64_t na64, int64_t n64,
     int32_t* __restrict__ kmap) {
     constexpr int WC = 64 / RL;                    // columns per wavefront
-    constexpr int NTH = 64 * (16 / WC);            // threads per workgroup
+    constexpr int NTH = 64 * (TC / WC);            // threads per workgroup
     using TM = Term<T, CST64>;
     using term_t = typename TM::type;
     using w_t = typename TM::wtype;
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
     // consecutive 16-column tiles are issued to the same XCD back to back
     const int per = gridDim.x >> 3;                // grid.x is a multiple of 8
     const int tile_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    if (tile_id * 16 >= n) return;
-    const int j = tile_id * 16 + wave * WC + cl;
+    if (tile_id * TC >= n) return;
+    const int j = tile_id * TC + wave * WC + cl;
     const bool col_ok = j < n;
     const int64_t omax = na - 1;
     const size_t boff = (size_t)blockIdx.y * (size_t)na * (size_t)n;
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(64 * (16 / (64 / RL)), WPS) void accumulate_tile16_
     // segment (a full 128-byte line in float32), 16 rows per pass
     __syncthreads();
     {
-        const int cc = threadIdx.x & 15, rr = threadIdx.x >> 4;
-        const int jj = tile_id * 16 + cc;
+        const int cc = threadIdx.x % TC, rr = threadIdx.x / TC;
+        const int jj = tile_id * TC + cc;
         const T* ws = tile + (size_t)(cc / WC) * na * WC * 2;        // owning wave's slab
         const int c4 = cc % WC;
         if (jj < n) {
 #pragma unroll 4
-            for (int k = rr; k < na; k += NTH / 16) {
+            for (int k = rr; k < na; k += NTH / TC) {
                 const T* cell = ws + 2 * (k * WC + ((c4 + k) & (WC - 1)));
                 size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)jj);
                 Tb[2 * q] = cell[0];
@@ -540,10 +540,24 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
                 // deep prefetch spreads each wavefront's requests over more DRAM pages.
                 constexpr int U = sizeof(T) == 4 ? 2 : 4;       // 16 row-lanes
                 constexpr int U8 = 3;                           // 8 row-lanes
-                // default: float32 -> 8 row-lanes x 8 columns per wavefront, 2 wavefronts per tile
-                // (240 us at config 2 vs 250 with 16 row-lanes); float64 -> 16 row-lanes x 4 columns,
-                // 4 wavefronts (config 5: 22.7 vs 23.6 ms).
+                // float32 with a tall tile (na * 32 cells over half the LDS): 8 row-lanes x 8 columns
+                // per wavefront, 2 wavefronts per 16-column tile (240 us at config 2 vs 250 with 16
+                // row-lanes); float64 -> 16 row-lanes x 4 columns, 4 wavefronts (config 5: 22.7 vs
+                // 23.6 ms).
                 // SSQ_ACC_VARIANT = 1 / 3 force the 16- / 8-lane layout.
+                if ((variant == 0 || variant == 9) && sizeof(T) == 4 &&
+                    (size_t)na * 32 * cell <= lds_cap / 2) {
+                    // float32 default: 32-column tiles of four 8-lane wavefronts (256-byte row
+                    // segments per workgroup, 2 workgroups per CU): 232 us at config 2 vs 240 with
+                    // 16-column tiles (64-column tiles, one workgroup per CU: 231)
+                    auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U8, 2, 8, 32>;
+                    const size_t lds32 = (size_t)na * 32 * cell;
+                    SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds32));
+                    dim3 grid32((unsigned)(((n + 31) / 32 + 7) / 8 * 8), (unsigned)batch);
+                    hipLaunchKernelGGL(kern, grid32, dim3(256), lds32, stream, (const T*)Wx, src, (const T*)Sfs,
+                                       (T*)Tx, cst, sp, na, n, kmap);
+                } else
                 if (variant == 3 || (variant == 0 && sizeof(T) == 4)) {
                     auto kern = accumulate_tile16_kernel<T, BINSRC, STFT, CST64, U8, 2, 8>;
                     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
