@@ -1,5 +1,6 @@
 // ssq_cwt_blocks.hip -- the CWT fast path: overlap-save "zoom" iFFT, LDS-resident,
-// fused with the unpad / phase-transform / bin-map epilogue.  gfx950, float32.
+// fused with the unpad / phase-transform / bin-map epilogue.  gfx950; float32 (tuned, with
+// a lean fused-ssq instantiation and four-step exact kernels) and float64.
 //
 // Math (see ssqueezepy_amd/_blocks.py for the derivation and the host planning):
 // a row whose impulse response fits +-m samples is evaluated block by block; block b
@@ -16,7 +17,8 @@
 // column index fastest -- so every LDS access of the Stockham passes is
 // conflict-free for G >= 16, and the final outputs (held in registers) go to HBM as
 // runs of G adjacent time samples (128-byte segments for G = 16). Per workgroup:
-// 32 KiB of LDS, so 4-5 workgroups per CU. HBM traffic: Wx (8 B/pt) + bin map
+// 32 KiB of LDS for the FFT + up to 17 KiB of staged band / twiddle powers; 140-160 VGPRs
+// -> 3 workgroups per CU. HBM traffic: Wx (8 B/pt) + bin map
 // (2 B/pt) written once; the inputs (band of X_b, psi, twiddles: a few KiB per
 // workgroup) come from L2. No intermediate array is ever written.
 //
