@@ -105,6 +105,9 @@ def main():
     ap.add_argument('--n', type=int, default=160000)
     ap.add_argument('--na', type=int, default=300)
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--gather-tx', action='store_true',
+                    help='N > 1: also time one step followed by an all_gather of the full Tx '
+                         '(reported separately; `value` never includes it)')
     args = ap.parse_args()
 
     import torch
@@ -168,6 +171,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, gpu_ms = t.tolist()
 
+    # optional: what a caller pays to collect every rank's Tx on every rank (SURVEY 8e:
+    # config 4's Tx is 24.6 GB per GPU, so the gather -- per-link xGMI bound -- not the
+    # transform, sets the rate). Outside the timed region of `value`.
+    gather_ms = None
+    if world > 1 and args.gather_tx:
+        Tx = step()[0]
+        big = torch.empty((world,) + tuple(Tx.shape), dtype=Tx.dtype, device=dev)
+        torch.cuda.synchronize(); dist.barrier()
+        t1 = time.perf_counter()
+        Tx = step()[0]
+        if backend == 'nccl':
+            dist.all_gather_into_tensor(big, Tx)
+        else:
+            parts = [torch.empty_like(Tx).cpu() for _ in range(world)]
+            dist.all_gather(parts, Tx.cpu())
+        torch.cuda.synchronize(); dist.barrier()
+        tg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather_ms = tg.item() * 1e3
+        del big
+
     # per-stage times of the same workload, HIP events inside the plan on the launch
     # stream (outside the timed region: the plan synchronises while it measures)
     stages = None
@@ -218,6 +242,11 @@ def main():
                          "bytes_alg_per_transform": bytes_alg,
                          "us_per_transform": t_transform * 1e6},
         }
+        if gather_ms is not None:
+            line["with_full_tx_gather"] = {
+                "ms_per_step": gather_ms,
+                "transforms_per_s": B * world / (gather_ms * 1e-3),
+                "gathered_bytes_per_rank": int((world - 1) * B * na * N * 8)}
         if stages:
             # the single largest kernel is the reassignment (one launch per transform);
             # it moves Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point
