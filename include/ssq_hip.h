@@ -142,6 +142,14 @@ int ssq_colsum(int dtype, const void* Z, const void* divisor, void* out, int64_t
 int ssq_band_colsum(int dtype, const void* Z, const int32_t* lo, const int32_t* hi,
                     int64_t ncomp, double* out, int64_t na, int64_t n, void* stream);
 
+/* Double-integral inverse CWT core: out (n_up) real <- Re ifft( sum_a fft(Wp[a]) * psih[a] ).
+ * `Wp` (na, n_up) complex: the padded transform, overwritten (used as FFT workspace);
+ * `psih` (na, n_up) real: wavelet samples already divided by the scale normalisation.
+ * replaces the loop of _icwt_2int (_cwt.py:448-469; its (-1)^k factor and ifftshift cancel
+ * for the even padded lengths it uses, and the sum over scales commutes with the iFFT). */
+int ssq_icwt2(int dtype, void* Wp, const void* psih, void* out, int64_t na, int64_t n_up,
+              void* stream);
+
 /* Inverse STFT: x (N) <- Sx (n_fft/2 + 1, n_hops) complex. irfft of every column
  * (rocFFT), fftshift of the frame if `modulated`, overlap-add with win_a = window^a,
  * division by the overlap-added win_a1 = window^(a+1), trim of n_fft/2 leading samples.

@@ -366,8 +366,26 @@ def gen_hiorder():
     save('hiorder', **d)
 
 
+def gen_icwt2():
+    """Double-integral inverse CWT, icwt(one_int=False) (_cwt.py:448-469), on the
+    reference's own forward transforms."""
+    from ssqueezepy import icwt
+    d = {}
+    N = 400
+    x = two_chirps(N, seed=21)
+    d['x'] = x
+    for dtype in ('float32', 'float64'):
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        for st, nv in (('log', 8), ('log-piecewise', 8), ('linear', None)):
+            Wx, sc = cwt(x, wav, scales=st, nv=nv)
+            d[f'Wx/{dtype}/{st}'], d[f'sc/{dtype}/{st}'] = Wx, sc
+            d[f'icwt2/{dtype}/{st}'] = icwt(Wx, wav, scales=sc, nv=nv, one_int=False,
+                                            x_len=N, x_mean=x.mean())
+    save('icwt2', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

@@ -91,12 +91,13 @@ def _icwt_norm(scaletype, l1_norm):
 
 def icwt(Wx, wavelet='gmw', scales='log-piecewise', nv=None, one_int=True, x_len=None,
          x_mean=0, padtype='reflect', rpadded=False, l1_norm=True):
-    """Inverse CWT by the one-integral formula (analytic wavelets): ``x = (2 / C_psi) *
-    ln(2**(1/nv)) * sum_a Re(Wx[a]) / norm(a)  + x_mean``; `scales`, `nv`, `l1_norm`,
-    `wavelet` as in the forward call. `Wx`: (na, N) or batched (B, na, N)."""
-    if not one_int:
-        raise NotImplementedError("the double-integral inverse (`one_int=False`) is not "
-                                  "part of the accelerated path")
+    """Inverse CWT. `one_int=True` (analytic wavelets): ``x = (2 / C_psi) * ln(2**(1/nv)) *
+    sum_a Re(Wx[a]) / norm(a) + x_mean``; `one_int=False`: every row is filtered again
+    with its wavelet before the sum (double integral, float64 result, single `Wx` only).
+    `scales`, `nv`, `l1_norm`, `wavelet`, `padtype` as in the forward call. `Wx`: (na, N) or
+    batched (B, na, N)."""
+    if not one_int and Wx.ndim == 3:
+        raise NotImplementedError("batched `Wx` requires `one_int=True`.")
     *_, na, n = Wx.shape
     x_len = x_len or n
     if not (isinstance(scales, np.ndarray) or _is_tensor(scales)) and nv is None:
@@ -122,6 +123,16 @@ def icwt(Wx, wavelet='gmw', scales='log-piecewise', nv=None, one_int=True, x_len
 
     Wd = algos.to_device(Wx)
     norm = _icwt_norm(scaletype, l1_norm)
+    if not one_int:
+        x = _icwt_2int(Wd, np.asarray(scales).reshape(-1), norm, wavelet, x_len, padtype,
+                       rpadded)
+        Cpsi = adm_cwt(wavelet)
+        if scaletype == 'log':
+            x = x * float((2 / Cpsi) * np.log(2 ** (1 / nv)))
+        else:
+            x = x * float((2 / Cpsi) * np.pi / 4)
+        x = x + float(x_mean)
+        return _finish(x, Wx)
     divisor = None
     if norm is not None:
         divisor = np.asarray(norm(np.asarray(scales).reshape(-1)))
@@ -136,6 +147,44 @@ def icwt(Wx, wavelet='gmw', scales='log-piecewise', nv=None, one_int=True, x_len
         x = _scale(x, (2 / Cpsi) * np.pi / 4)
     x = _add(x, x_mean)                       # the CWT does not capture the mean
     return _finish(x, Wx)
+
+
+def _icwt_2int(Wd, scales, norm, wavelet, x_len, padtype, rpadded):
+    """Double-integral iCWT (_cwt.py:448-469): every row is filtered again with its
+    wavelet and the rows are summed. The reference's (-1)^k factor and ifftshift cancel
+    (even padded length) and the sum over scales commutes with the inverse FFT, so the
+    device does one forward FFT per row, a multiply-accumulate over rows and one inverse
+    FFT (`ssq_icwt2`). Returns float64, as the reference does."""
+    from .padding import pad_geometry
+    from . import _lib
+    from ._lib import check
+    cdt = Wd.dtype
+    rdt = torch.float32 if cdt == torch.complex64 else torch.float64
+    if not rpadded:
+        n_up, n1, n2 = pad_geometry(Wd.shape[-1])
+        if cdt == torch.complex64:        # 8-byte elements: the pad kernel only moves them
+            Wp = algos.pad_signal_gpu(Wd.view(torch.float64), n1, n2, padtype).view(cdt)
+        else:
+            ri = torch.view_as_real(Wd).permute(2, 0, 1).contiguous()      # (2, na, N)
+            pr = algos.pad_signal_gpu(ri.reshape(-1, ri.shape[-1]), n1, n2, padtype)
+            pr = pr.reshape(2, Wd.shape[0], -1)
+            Wp = torch.complex(pr[0], pr[1])
+    else:
+        n_up = Wd.shape[-1]
+        n1 = (n_up - x_len) // 2
+        Wp = Wd.clone()
+    Wp = Wp.contiguous()
+    na = Wp.shape[0]
+    psih = np.asarray(wavelet(scale=scales.reshape(-1, 1), N=n_up))
+    if norm is not None:
+        psih = psih / np.asarray(norm(scales)).reshape(-1, 1)
+    psih_d = algos.to_device(np.ascontiguousarray(psih), rdt)
+    out = torch.empty(n_up, dtype=rdt, device=Wp.device)
+    lib = _lib.load()
+    check(lib.ssq_icwt2(_lib.F32 if rdt == torch.float32 else _lib.F64, Wp.data_ptr(),
+                        psih_d.data_ptr(), out.data_ptr(), int(na), int(n_up),
+                        algos.stream()))
+    return out[n1:n1 + x_len].double()
 
 
 # ------------------------------------------------------------ component inversion

@@ -82,6 +82,7 @@ _PROTOS = {
                            c_int64, c_void_p]),
     'ssq_band_colsum': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_void_p, c_int64, c_int64, c_void_p]),
+    'ssq_icwt2': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'ssq_istft': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                           c_int64, c_int64, c_int64, c_int, c_void_p]),
     'ssq_cwt_plan_create': (c_int, [POINTER(c_void_p), POINTER(CwtDesc)]),

@@ -124,6 +124,65 @@ __global__ __launch_bounds__(256) void istft_ola_kernel(const T* __restrict__ fr
     x[s] = acc;
 }
 
+// S[k] = sum_a F[a][k] * psih[a][k] (rows in order): the double-integral iCWT summed in
+// the frequency domain, so that one inverse transform serves all scales
+template <typename T>
+__global__ __launch_bounds__(256) void mulsum_rows_kernel(const T* __restrict__ F, const T* __restrict__ psih,
+                                                          T* __restrict__ S, int64_t na, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    T re = T(0), im = T(0);
+    for (int64_t a = 0; a < na; ++a) {
+        const T p = psih[a * n + k];
+        re = re + F[2 * (a * n + k)] * p;
+        im = im + F[2 * (a * n + k) + 1] * p;
+    }
+    S[2 * k] = re; S[2 * k + 1] = im;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void real_part_kernel(const T* __restrict__ S, T* __restrict__ out, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = S[2 * k];
+}
+
+static std::mutex g_icwt2_mu;
+static std::map<std::tuple<int, int64_t, int64_t>, std::pair<FftPlan, FftPlan>> g_icwt2_plans;
+
+template <typename T>
+static int icwt2_t(int dtype, void* Wp, const void* psih, void* out, int64_t na, int64_t n,
+                   hipStream_t stream) {
+    std::pair<FftPlan, FftPlan>* pp = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_icwt2_mu);
+        auto key = std::make_tuple(dtype, na, n);
+        auto it = g_icwt2_plans.find(key);
+        if (it == g_icwt2_plans.end()) {
+            std::pair<FftPlan, FftPlan> pr;
+            int rc = pr.first.create(2, dtype, (size_t)n, (size_t)na, 1.0);
+            if (rc) return rc;
+            rc = pr.second.create(1, dtype, (size_t)n, 1, 1.0 / (double)n);
+            if (rc) return rc;
+            it = g_icwt2_plans.emplace(key, pr).first;
+        }
+        pp = &it->second;
+    }
+    int rc = pp->first.execute(Wp, nullptr, stream);              // forward FFT of every row, in place
+    if (rc) return rc;
+    T* S = nullptr;
+    SSQ_CHECK_HIP(hipMallocAsync((void**)&S, (size_t)n * 2 * sizeof(T), stream));
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL((mulsum_rows_kernel<T>), grid, dim3(256), 0, stream, (const T*)Wp, (const T*)psih, S, na, n);
+    rc = (hipGetLastError() == hipSuccess) ? pp->second.execute(S, nullptr, stream) : -3;
+    if (!rc) {
+        hipLaunchKernelGGL((real_part_kernel<T>), grid, dim3(256), 0, stream, (const T*)S, (T*)out, n);
+        if (hipGetLastError() != hipSuccess) rc = -3;
+    }
+    if (rc == -3) set_error("icwt2 kernel launch failed");
+    (void)hipFreeAsync(S, stream);
+    return rc;
+}
+
 struct IstftFft {
     rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr; void* work = nullptr;
 };
@@ -228,6 +287,14 @@ int ssq_band_colsum(int dtype, const void* Z, const int32_t* lo, const int32_t* 
                            (int)ncomp, out, na, n);
     SSQ_LAUNCH_CHECK();
     return 0;
+}
+
+int ssq_icwt2(int dtype, void* Wp, const void* psih, void* out, int64_t na, int64_t n_up, void* stream) {
+    SSQ_REQUIRE(Wp && psih && out, "ssq_icwt2: null pointer");
+    SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "bad dtype %d", dtype);
+    SSQ_REQUIRE(na >= 1 && n_up >= 2, "icwt2: bad shape (%lld, %lld)", (long long)na, (long long)n_up);
+    if (dtype == SSQ_F32) return icwt2_t<float>(dtype, Wp, psih, out, na, n_up, as_stream(stream));
+    return icwt2_t<double>(dtype, Wp, psih, out, na, n_up, as_stream(stream));
 }
 
 int ssq_istft(int dtype, const void* Sx, const void* win_a, const void* win_a1, void* x, int64_t n_fft,
