@@ -23,6 +23,8 @@
 
 namespace ssq {
 
+#include "ssq_point_math.inl"
+
 template <typename T>
 __global__ __launch_bounds__(256) void frame_window_kernel(
     const T* __restrict__ xp, const T* __restrict__ window, const T* __restrict__ diff_window,
@@ -49,18 +51,20 @@ __global__ __launch_bounds__(256) void frame_window_kernel(
 //   A[f] = (Z[f] + conj(Z[L-f])) / 2,   B[f] = (Z[f] - conj(Z[L-f])) / (2i),  f <= L/2.
 struct StftFusedArgs {
     const float* xp; const float* window; const float* diff_window; const c32* ftw;
-    float2* Sx; float2* dSx;            // dSx null: no derivative
+    float2* Sx; float2* dSx;            // dSx null: derivative not stored
+    // fused ssq_stft: the bin of every point (2 bytes) instead of dSx (8 bytes)
+    unsigned short* kidx; const float* Sfs; double gamma;
     int64_t padlen, n_hops, rows;
     int hop, s20, s21, modulated;
 };
 
 template <int L, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A) {
+__global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     constexpr int RL = (R3 > 1) ? R3 : R2;
     const int tid = threadIdx.x, c0 = blockIdx.x * G;
     const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
-    const bool deriv = A.dSx != nullptr;
+    const bool deriv = A.dSx != nullptr || A.kidx != nullptr;
     c32 z[PPT];
     {
         constexpr int NB = PPT / R1, STR = L / R1;
@@ -101,15 +105,27 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A) {
         if (c >= A.n_hops) continue;
         const c32 P = buf[f * G + g], Q = buf[((L - f) & (L - 1)) * G + g];
         const int64_t q = base + (int64_t)f * A.n_hops + c;
-        A.Sx[q] = make_float2(0.5f * (P.x + Q.x), 0.5f * (Q.y - P.y));
-        if (deriv) A.dSx[q] = make_float2(-0.5f * (P.y + Q.y), 0.5f * (Q.x - P.x));
+        const float sr = 0.5f * (P.x + Q.x), si = 0.5f * (Q.y - P.y);
+        A.Sx[q] = make_float2(sr, si);
+        if (!deriv) continue;
+        const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
+        if (A.dSx) A.dSx[q] = make_float2(dr, di);
+        if (A.kidx) {            // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
+            const int64_t omax = A.rows - 1;
+            unsigned short kk = 0xFFFFu;
+            if (mag_gt(sr, si, A.gamma)) {
+                const int64_t kb = bin_of_point(dr, di, sr, si, true, A.Sfs[f], sp, omax);
+                kk = (unsigned short)(sp.flipud ? omax - kb : kb);
+            }
+            A.kidx[q] = kk;
+        }
     }
 }
 
 template <int L, int G, int R1, int R2, int R3>
-static int launch_stft_fused(const StftFusedArgs& A, int64_t batch, hipStream_t stream) {
+static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_t batch, hipStream_t stream) {
     dim3 grid((unsigned)((A.n_hops + G - 1) / G), (unsigned)batch);
-    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, A);
+    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, A, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
@@ -167,6 +183,7 @@ struct ssq_stft_plan {
     void* xp = nullptr; void* frames = nullptr; void* dframes = nullptr; void* dSx_ws = nullptr;
     StridedR2C fft;
     bool fused = false; void* ftw = nullptr;      // fused float32 path (power-of-two n_fft)
+    unsigned short* kidx = nullptr;               // bin map of the fused ssq_stft form
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;
 };
 
@@ -227,7 +244,7 @@ void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
     if (!pl) return;
     pl->fft.destroy();
     void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
-                    pl->cst, pl->Sfs, pl->ftw};
+                    pl->cst, pl->Sfs, pl->ftw, pl->kidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -277,20 +294,31 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     if (rc) return rc;
     const int64_t s20 = (n_fft + 1) / 2, s21 = (n_fft % 2 == 1) ? s20 - 1 : s20;
     T* dS = dSx ? (T*)dSx : (T*)pl->dSx_ws;
+    // fused ssq_stft form: Tx wanted, neither dSx nor w -> the kernel emits 2-byte bins
+    // instead of the 8-byte derivative (the reassignment then reads 10 instead of 16 B/pt)
+    bool use_kidx = false;
+    if constexpr (sizeof(T) == 4) {
+        if (pl->fused && Tx && !w && !dSx && rows < 65535) {
+            if (!pl->kidx)
+                SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
+            use_kidx = true;
+        }
+    }
     if constexpr (sizeof(T) == 4) {
         if (pl->fused) {
             StftFusedArgs A;
             A.xp = (const float*)pl->xp; A.window = (const float*)pl->window;
             A.diff_window = (const float*)pl->diff_window; A.ftw = (const c32*)pl->ftw;
-            A.Sx = (float2*)Sx; A.dSx = deriv ? (float2*)dS : nullptr;
+            A.Sx = (float2*)Sx; A.dSx = (deriv && !use_kidx) ? (float2*)dS : nullptr;
+            A.kidx = use_kidx ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated;
             switch (n_fft) {
-                case 128: rc = launch_stft_fused<128, 32, 16, 8, 1>(A, batch, stream); break;
-                case 256: rc = launch_stft_fused<256, 16, 16, 16, 1>(A, batch, stream); break;
-                case 512: rc = launch_stft_fused<512, 8, 8, 8, 8>(A, batch, stream); break;
-                case 1024: rc = launch_stft_fused<1024, 4, 16, 8, 8>(A, batch, stream); break;
-                default: rc = launch_stft_fused<2048, 2, 16, 16, 8>(A, batch, stream); break;
+                case 128: rc = launch_stft_fused<128, 32, 16, 8, 1>(A, pl->sp, batch, stream); break;
+                case 256: rc = launch_stft_fused<256, 16, 16, 16, 1>(A, pl->sp, batch, stream); break;
+                case 512: rc = launch_stft_fused<512, 8, 8, 8, 8>(A, pl->sp, batch, stream); break;
+                case 1024: rc = launch_stft_fused<1024, 4, 16, 8, 8>(A, pl->sp, batch, stream); break;
+                default: rc = launch_stft_fused<2048, 2, 16, 16, 8>(A, pl->sp, batch, stream); break;
             }
             if (rc) return rc;
         }
@@ -319,6 +347,9 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     if (Tx) {
         if (w)
             rc = launch_accumulate(d.dtype, BIN_FROM_W, Sx, w, nullptr, Tx, pl->cst, pl->sp, batch,
+                                   rows, n_hops, nullptr, stream);
+        else if (use_kidx)
+            rc = launch_accumulate(d.dtype, BIN_FROM_KIDX, Sx, pl->kidx, nullptr, Tx, pl->cst, pl->sp, batch,
                                    rows, n_hops, nullptr, stream);
         else
             rc = launch_accumulate(d.dtype, BIN_FROM_DWX, Sx, dS, pl->Sfs, Tx, pl->cst, pl->sp, batch,
