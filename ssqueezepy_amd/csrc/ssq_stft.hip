@@ -56,13 +56,19 @@ struct StftFusedArgs {
     unsigned short* kidx; const float* Sfs; double gamma;
     int64_t padlen, n_hops, rows;
     int hop, s20, s21, modulated;
+    int xcd;                            // grid.x padded to a multiple of 8, remapped per XCD
 };
 
 template <int L, int G, int R1, int R2, int R3>
 __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     constexpr int RL = (R3 > 1) ? R3 : R2;
-    const int tid = threadIdx.x, c0 = blockIdx.x * G;
+    // workgroups are dealt to the 8 XCDs round-robin: give each XCD one contiguous range of
+    // frames, so that the G*8-byte pieces of an output line meet in one L2 before they leave
+    int bx = blockIdx.x;
+    if (A.xcd) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
+    const int tid = threadIdx.x, c0 = bx * G;
+    if (c0 >= A.n_hops) return;
     const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
     const bool deriv = A.dSx != nullptr || A.kidx != nullptr;
     c32 z[PPT];
@@ -124,8 +130,13 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
 
 template <int L, int G, int R1, int R2, int R3>
 static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_t batch, hipStream_t stream) {
-    dim3 grid((unsigned)((A.n_hops + G - 1) / G), (unsigned)batch);
-    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, A, sp);
+    static const bool remap = [] { const char* e = getenv("SSQ_STFT_XCD"); return !e || atoi(e) != 0; }();
+    StftFusedArgs B = A;
+    unsigned nb = (unsigned)((A.n_hops + G - 1) / G);
+    B.xcd = remap && nb >= 64;
+    if (B.xcd) nb = (nb + 7u) & ~7u;
+    dim3 grid(nb, (unsigned)batch);
+    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
