@@ -530,7 +530,12 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
     __shared__ c32 buf[D_POINTS];
     constexpr int RL = (R3 > 1) ? R3 : R2;
     const int tid = threadIdx.x, r = blockIdx.y, row = E.rows[r];
-    const int c0 = blockIdx.x * G;                          // first n2 of this workgroup
+    // a workgroup writes G consecutive outputs per n1 (G*8-byte pieces of Wx, G*2 of the bin map):
+    // give each XCD (workgroup b -> XCD b % 8) a contiguous range of n2 so the pieces of one
+    // line meet in one L2
+    const int bx = (gridDim.x & 7) ? (int)blockIdx.x
+                                   : (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    const int c0 = bx * G;                                  // first n2 of this workgroup
     const c32* ZW = E.Z + (((int64_t)blockIdx.z * E.n_rows + r) * 2) * E.M;
     const c32* ZD = ZW + E.M;
     c32 zw[PPT], zd[PPT];
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
-                const int64_t q = (int64_t)blockIdx.x * E.A * G + (u + k * STR) * G + g;   // blocked Z
+                const int64_t q = (int64_t)bx * E.A * G + (u + k * STR) * G + g;   // blocked Z
                 zw[it * R1 + k] = ZW[q]; zd[it * R1 + k] = ZD[q];
             }
         }
