@@ -158,6 +158,35 @@ int ssq_istft(int dtype, const void* Sx, const void* win_a, const void* win_a1, 
               int64_t n_fft, int64_t n_hops, int64_t hop_len, int64_t N, int modulated,
               void* stream);
 
+/* ------------------------------------------------------------ ridge extraction
+ * The loop nests of extract_ridges (ridge_extraction.py:113-232) on arrays that are
+ * already on the device; (na, n) arrays are row-major, real, in `dtype`.
+ *
+ * energy <- |Tf|^2, `np.abs(Tf)**2` (:129). Tf: (na, n) complex (interleaved) when
+ * `is_complex`, else real. */
+int ssq_ridge_energy(int dtype, int is_complex, const void* Tf, void* energy, int64_t na,
+                     int64_t n, void* stream);
+
+/* E <- -log(energy / max_i energy[i, j] + eps)   (:138-139). */
+int ssq_ridge_neglog(int dtype, const void* energy, void* E, double eps, int64_t na, int64_t n,
+                     void* stream);
+
+/* Forward-backward tracking (fw_bw_ridge_tracking, :91-111 -> :143-232):
+ *   pe[f, t] = E[f, t] + min_g(pe[g, t-1] + P[f, g]),  P[f, g] = penalty * (sc[f] - sc[g])^2
+ *   ridge[t] = argmin_f pe[f, t], then for t = n-2 .. 0 the last f with
+ *   |pe[r, t+1] - E[r, t+1] - (pe[f, t] + P[r, f])| < eps, r = ridge[t+1], if any.
+ * `sc` (na,): the (log) scales in the penalty dtype -- float32 when `penalty_f32`
+ * (every input but complex128, :113-117), else float64; `pe` (na, n) and `ridge` (n,)
+ * int64 are outputs. Bit-identical to the reference's loops for identical E. */
+int ssq_ridge_track(int dtype, int penalty_f32, const void* E, void* pe, const void* sc,
+                    double penalty, double eps, int64_t na, int64_t n, int64_t* ridge,
+                    void* stream);
+
+/* ridge_e[j] <- energy[ridge[j], j] (NULL: skipped), then
+ * energy[int(ridge[j] - bw) : int(ridge[j] + bw), j] = 0 with Python's slice rules (:142-150). */
+int ssq_ridge_clear(int dtype, void* energy, const int64_t* ridge, double bw, void* ridge_e,
+                    int64_t na, int64_t n, void* stream);
+
 /* ----------------------------------------------------------------- CWT plan
  * Replaces the body of cwt() (_cwt.py:255-306: pad -> fft -> Psih*xh -> ifft
  * [-> *1j*xi/dt -> ifft] -> unpad) and, when ssq parameters are set, the

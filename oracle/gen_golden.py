@@ -384,8 +384,37 @@ def gen_icwt2():
     save('icwt2', **d)
 
 
+def gen_ridges():
+    """extract_ridges (ridge_extraction.py:11-141) on the reference's own transforms of
+    a two-chirp signal, and its 3x3 example (tests/ridge_extraction_test.py:17-26)."""
+    from ssqueezepy import extract_ridges
+    d = {}
+    tm = np.array([[1, 4, 4], [2, 2, 2], [5, 5, 4]])
+    fs = np.exp([1, 2, 3])
+    ri, rf, re = extract_ridges(tm, fs, penalty=2.0, get_params=True, parallel=False)
+    d['basic/Tf'], d['basic/scales'] = tm, fs
+    d['basic/idx'], d['basic/f'], d['basic/e'] = ri, rf, re
+    N = 384
+    x = two_chirps(N, seed=5, noise=0.02)
+    d['x'] = x
+    for dtype in ('float32', 'float64'):
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        Tx, Wx, ssq_freqs, scales = ssq_cwt(x, wav, nv=8)
+        Ts, Sx, sf, Sfs = ssq_stft(x, n_fft=128, dtype=dtype)
+        cases = (('cwt', Wx, scales, 'cwt', 15, 2.0), ('ssq_cwt', Tx, ssq_freqs, 'cwt', 4, 0.5),
+                 ('stft', Sx, Sfs, 'stft', 4, 2.0), ('ssq_stft', Ts, sf, 'stft', 4, 20.0))
+        for name, Tf, sc, tr, bw, pen in cases:
+            ri, rf, re = extract_ridges(Tf, sc, penalty=pen, n_ridges=2, bw=bw, transform=tr,
+                                        get_params=True, parallel=False)
+            k = f'{name}/{dtype}/'
+            d[k + 'Tf'], d[k + 'scales'] = Tf, np.asarray(sc)
+            d[k + 'idx'], d[k + 'f'], d[k + 'e'] = ri, rf, re
+            d[k + 'args'] = np.array([pen, bw, 0 if tr == 'cwt' else 1], dtype=np.float64)
+    save('ridges', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

@@ -280,3 +280,68 @@ def stft(x, window, diff_window, n_fft, hop_len, fs=1., modulated=True,
         frames *= win.reshape(-1, 1)
         outs.append(sfft.rfft(frames, axis=0, workers=workers))
     return (outs[0], outs[1]) if derivative else (outs[0], None)
+
+
+# --------------------------------------------------------- ridge extraction
+def ridge_design(Tf_dtype, scales, penalty, transform='cwt'):
+    """(dtype, eps, penalty matrix) of extract_ridges (ssqueezepy/ridge_extraction.py:
+    78-89, 113-128): float64 only for complex128 input, scales log'd for 'cwt',
+    `penalty * subtract.outer(scales, scales)**2` in that dtype."""
+    c128 = np.dtype(Tf_dtype) == np.complex128
+    dtype = np.float64 if c128 else np.float32
+    eps = np.asarray(np.finfo(dtype).eps, dtype=dtype)
+    scales = np.asarray(scales, dtype=dtype)
+    penalty = np.asarray(penalty, dtype=dtype)
+    sc = (np.log(scales) if transform == 'cwt' else scales).squeeze()
+    P = (penalty * np.subtract.outer(sc, sc)**2).squeeze()
+    return dtype, eps, P
+
+
+def ridge_track(E, P, eps):
+    """Forward-backward tracking (ridge_extraction.py:91-111, 143-232) on the
+    negative-log energy `E (na, n)`: returns (ridge indices int64 (n,), penalised
+    energy (na, n))."""
+    E = np.ascontiguousarray(E)
+    f32 = E.dtype == np.float32
+    T = np.float32 if f32 else np.float64
+    Pm = _c(P, T)                      # float32 -> float64 is exact
+    na, n = E.shape
+    pe = E.copy()
+    L = lib()
+    fw = L.orc_ridge_fw_f32 if f32 else L.orc_ridge_fw_f64
+    bw = L.orc_ridge_bw_f32 if f32 else L.orc_ridge_bw_f64
+    fw(_p(pe), _p(Pm), ctypes.c_int64(na), ctypes.c_int64(n))
+    # np.unravel_index(np.argmin(pe, axis=0), pe.shape)[1]  (:157-158)
+    ridge = np.unravel_index(np.argmin(pe, axis=0), pe.shape)[1].astype(np.int64)
+    ridge = np.ascontiguousarray(ridge)
+    bw(_p(E), _p(Pm), _p(pe), _p(ridge), ctypes.c_double(float(eps)),
+       ctypes.c_int64(na), ctypes.c_int64(n))
+    return ridge, pe
+
+
+def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
+                   get_params=False, neglog=None):
+    """ridge_extraction.py:11-141. `neglog(energy, energy_max, eps)` optionally replaces
+    the NumPy expression `-log(energy / energy_max + eps)` (tests feed the device's
+    values through it to compare the tracking bit for bit)."""
+    Tf = np.asarray(Tf)
+    dtype, eps, P = ridge_design(Tf.dtype, scales, penalty, transform)
+    scales_orig = np.asarray(scales, dtype=dtype).copy()
+    energy = np.abs(Tf)**2
+    n = Tf.shape[1]
+    ridge_idxs = np.zeros((n, n_ridges), dtype=int)
+    ridge_f = np.zeros((n, n_ridges), dtype=dtype)
+    ridge_e = np.zeros((n, n_ridges), dtype=dtype)
+    for i in range(n_ridges):
+        energy_max = energy.max(axis=0)
+        if neglog is None:
+            E = -np.log(energy / energy_max + eps)
+        else:
+            E = neglog(energy, energy_max, eps)
+        ridge_idxs[:, i], _ = ridge_track(E, P, eps)
+        ridge_f[:, i] = scales_orig.squeeze()[ridge_idxs[:, i]]
+        ridge_e[:, i] = energy[ridge_idxs[:, i], range(n)]
+        for t in range(n):
+            r = ridge_idxs[t, i]
+            energy[int(r - bw):int(r + bw), t] = 0
+    return (ridge_idxs, ridge_f, ridge_e) if get_params else ridge_idxs

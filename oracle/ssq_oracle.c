@@ -15,6 +15,8 @@
  *   orc_indexed_sum_*    algos.py:172-250   (_indexed_sum_{log,log_piecewise,lin})
  *   orc_replace_under_abs_*  algos.py:545-557
  *   orc_buffer_*         utils/stft_utils.py:69-98 (_buffer / _buffer_par)
+ *   orc_ridge_fw_*, orc_ridge_bw_*   ridge_extraction.py:163-232 (forward / backward
+ *                        penalised-energy passes of extract_ridges)
  *
  * Arithmetic types. The reference's loop nests are Python source compiled by numba;
  * for float32 inputs the *type* of three sub-expressions depends on who evaluates
@@ -49,6 +51,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 
 #define ORC_TYPING_NUMBA 0
 #define ORC_TYPING_NUMPY 1
@@ -360,3 +363,48 @@ void NAME(const T* x, T* out, int64_t n_x, int64_t seg_len, int64_t n_overlap,  
 }
 DEF_BUFFER(orc_buffer_f32, float)
 DEF_BUFFER(orc_buffer_f64, double)
+
+/* ======================================================== ridge tracking
+ * ridge_extraction.py:163-232. Forward pass (`__accumulated_penalty_energy_fw`,
+ * :163-176): for t >= 1, pe[f, t] += min_g(pe[g, t-1] + P[f, g]), every sum formed
+ * in the array type (the elementwise sum of two rows, then amin, then `+=`).
+ * Backward pass (`__accumulated_penalty_energy_bw`, :202-214): for t = n-2 .. 0 with
+ * r = ridge[t+1]: val = pe[r, t+1] - e[r, t+1]; every f with
+ * |val - (pe[f, t] + P[r, f])| < eps overwrites ridge[t] in ascending f (the last
+ * one stays); none -> the forward argmin ridge[t] stays.
+ * pe, e: (na, n) row-major; P: (na, na) row-major in the same type (a float32
+ * penalty matrix promoted to double is exact). */
+#define DEF_RIDGE(SFX, T, ABS)                                                     \
+void orc_ridge_fw_##SFX(T* pe, const T* P, int64_t na, int64_t n) {               \
+    T* prev = (T*)__builtin_malloc(sizeof(T) * (size_t)na);                       \
+    T* cur = (T*)__builtin_malloc(sizeof(T) * (size_t)na);                        \
+    for (int64_t f = 0; f < na; ++f) prev[f] = pe[f * n];                         \
+    for (int64_t t = 1; t < n; ++t) {                                             \
+        for (int64_t f = 0; f < na; ++f) {                                        \
+            const T* Pf = P + f * na;                                             \
+            T m = prev[0] + Pf[0];                                                \
+            for (int64_t g = 1; g < na; ++g) {                                    \
+                T v = prev[g] + Pf[g];                                            \
+                if (v < m) m = v;                                                 \
+            }                                                                     \
+            cur[f] = pe[f * n + t] + m;                                           \
+        }                                                                         \
+        for (int64_t f = 0; f < na; ++f) pe[f * n + t] = cur[f];                  \
+        T* sw = prev; prev = cur; cur = sw;                                       \
+    }                                                                             \
+    __builtin_free(prev); __builtin_free(cur);                                    \
+}                                                                                 \
+void orc_ridge_bw_##SFX(const T* e, const T* P, const T* pe, int64_t* ridge,      \
+                        double eps, int64_t na, int64_t n) {                      \
+    const T epsT = (T)eps;                                                        \
+    for (int64_t t = n - 2; t >= 0; --t) {                                        \
+        const int64_t r = ridge[t + 1];                                           \
+        const T val = pe[r * n + t + 1] - e[r * n + t + 1];                       \
+        for (int64_t f = 0; f < na; ++f) {                                        \
+            const T c = pe[f * n + t] + P[r * na + f];                            \
+            if (ABS(val - c) < epsT) ridge[t] = f;                                \
+        }                                                                         \
+    }                                                                             \
+}
+DEF_RIDGE(f32, float, fabsf)
+DEF_RIDGE(f64, double, fabs)

@@ -28,7 +28,7 @@ def __getattr__(name):
         'replace_under_abs': 'algos', 'phase_cwt_gpu': 'algos',
         'phase_stft_gpu': 'algos',
         'icwt': '_inverse', 'issq_cwt': '_inverse', 'istft': '_inverse',
-        'issq_stft': '_inverse',
+        'issq_stft': '_inverse', 'extract_ridges': 'ridge_extraction',
     }
     if name in _lazy:
         import importlib

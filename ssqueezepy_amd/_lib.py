@@ -85,6 +85,12 @@ _PROTOS = {
     'ssq_icwt2': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'ssq_istft': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                           c_int64, c_int64, c_int64, c_int, c_void_p]),
+    'ssq_ridge_energy': (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'ssq_ridge_neglog': (c_int, [c_int, c_void_p, c_void_p, c_double, c_int64, c_int64, c_void_p]),
+    'ssq_ridge_track': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                c_int64, c_int64, c_void_p, c_void_p]),
+    'ssq_ridge_clear': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int64,
+                                c_void_p]),
     'ssq_cwt_plan_create': (c_int, [POINTER(c_void_p), POINTER(CwtDesc)]),
     'ssq_cwt_plan_destroy': (None, [c_void_p]),
     'ssq_cwt_plan_set_ssq': (c_int, [c_void_p, c_int, POINTER(c_double), c_void_p,

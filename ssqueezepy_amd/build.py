@@ -26,6 +26,7 @@ SOURCES = [
     ('ssq_cwt_blocks.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
     ('ssq_inverse.hip', ['-ffp-contract=off']),
+    ('ssq_ridge.hip', ['-ffp-contract=off']),
     ('ssq_fft.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',

@@ -1,0 +1,164 @@
+# -*- coding: utf-8 -*-
+"""Ridge extraction on the MI355X (csrc/ssq_ridge.hip, ssqueezepy_amd/ridge_extraction.py)
+against the CPU oracle (oracle.ridge_track / extract_ridges, pinned to the reference's
+ridge_extraction.py by tests/test_oracle_vs_golden.py) and the reference-generated fixture
+tests/golden/ridges.npz.
+
+The forward / backward recurrences are index work on rounded sums: compared bit for bit on
+the same negative-log energy (the device's). The energy and its logarithm are floating
+point: 1e-6 / 1e-13 relative (float32 / float64). End to end against the reference's
+indices the only difference left is the last bit of `log`, which can move a ridge between
+neighbouring rows at isolated columns: at least 99 % identical, none further than 2 rows."""
+import ctypes
+import numpy as np
+import pytest
+from conftest import golden, two_chirps
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+@pytest.fixture(scope='module')
+def S():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import ssqueezepy_amd as S
+    from ssqueezepy_amd import _lib
+    _lib.load(build_if_missing=False)
+    return S
+
+
+def _stages(Tf, sc, penalty, eps, penalty_f32):
+    """energy, E, pe, ridge of one tracking pass through the C ABI."""
+    import torch
+    from ssqueezepy_amd import _lib
+    from ssqueezepy_amd._lib import check, F32, F64
+    lib = _lib.load(build_if_missing=False)
+    Tf = torch.as_tensor(Tf, device='cuda').contiguous()
+    f64 = Tf.dtype in (torch.complex128, torch.float64)
+    rdt, code = (torch.float64, F64) if f64 else (torch.float32, F32)
+    na, n = Tf.shape
+    en = torch.empty((na, n), dtype=rdt, device='cuda')
+    E, pe = torch.empty_like(en), torch.empty_like(en)
+    ridge = torch.empty(n, dtype=torch.int64, device='cuda')
+    scd = torch.as_tensor(np.ascontiguousarray(sc), device='cuda')
+    check(lib.ssq_ridge_energy(code, int(Tf.is_complex()), Tf.data_ptr(), en.data_ptr(), na, n, None))
+    check(lib.ssq_ridge_neglog(code, en.data_ptr(), E.data_ptr(), float(eps), na, n, None))
+    check(lib.ssq_ridge_track(code, int(penalty_f32), E.data_ptr(), pe.data_ptr(), scd.data_ptr(),
+                              float(penalty), float(eps), na, n, ridge.data_ptr(), None))
+    torch.cuda.synchronize()
+    return en.cpu().numpy(), E.cpu().numpy(), pe.cpu().numpy(), ridge.cpu().numpy()
+
+
+def _random_tf(rng, na, n, cdtype):
+    """A noisy two-ridge magnitude pattern with random phases."""
+    t = np.arange(n) / n
+    rows = np.arange(na)[:, None]
+    c1 = na * (0.2 + 0.5 * t)[None]
+    c2 = na * (0.8 - 0.3 * t**2)[None]
+    mag = np.exp(-0.5 * ((rows - c1) / 2.5)**2) + 0.6 * np.exp(-0.5 * ((rows - c2) / 2.0)**2)
+    mag = mag + 0.05 * rng.random((na, n))
+    return (mag * np.exp(2j * np.pi * rng.random((na, n)))).astype(cdtype)
+
+
+@pytest.mark.parametrize('cdtype,na,n,transform', [
+    ('complex64', 300, 3001, 'cwt'), ('complex64', 65, 384, 'stft'), ('complex64', 7, 50, 'cwt'),
+    ('complex64', 513, 700, 'stft'), ('complex64', 1100, 150, 'cwt'),
+    ('complex128', 300, 1500, 'cwt'), ('complex128', 552, 260, 'stft'),
+    ('float64', 40, 333, 'cwt'), ('float32', 129, 1000, 'stft'), ('complex64', 300, 1, 'cwt'),
+    ('complex64', 3, 2, 'stft')])
+def test_tracking_stages_vs_oracle(orc, S, cdtype, na, n, transform):
+    rng = np.random.default_rng(na * 7 + n)
+    Tf = _random_tf(rng, na, n, cdtype)
+    if not np.iscomplexobj(np.zeros(1, cdtype)):
+        Tf = np.abs(_random_tf(rng, na, n, 'complex128')).astype(cdtype)
+    scales = (np.exp(np.linspace(-0.3, 6.2, na)) if transform == 'cwt'
+              else np.linspace(0, .5, na))
+    penalty = 2.0 if transform == 'cwt' else 40.0
+    pdt, eps, P = orc.ridge_design(Tf.dtype, scales, penalty, transform)
+    sc = np.asarray(scales, dtype=pdt)
+    sc = np.log(sc) if transform == 'cwt' else sc
+    en, E, pe, ridge = _stages(Tf, sc, penalty, eps, pdt == np.float32)
+    # floating point stages
+    en_ref = np.abs(Tf)**2
+    E_ref = -np.log(en_ref / en_ref.max(axis=0) + eps)
+    tol = 1e-6 if en.dtype == np.float32 else 1e-13
+    assert en.dtype == en_ref.dtype and E.dtype == E_ref.dtype
+    assert np.abs(en - en_ref).max() <= tol * np.abs(en_ref).max()
+    assert np.abs(E - E_ref).max() <= 4 * tol * max(1., np.abs(E_ref).max())
+    # index work: bit for bit on the device's E
+    ridge_ref, pe_ref = orc.ridge_track(E, P.reshape(na, na), eps)
+    assert np.array_equal(pe, pe_ref)
+    assert np.array_equal(ridge, ridge_ref)
+
+
+def _golden_cases(g):
+    names = sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k})
+    for k in names:
+        if k == 'basic':
+            yield k, dict(penalty=2.0, bw=15, transform='cwt', n_ridges=1)
+        else:
+            a = g[k + '/args']
+            yield k, dict(penalty=a[0], bw=int(a[1]), transform=('cwt', 'stft')[int(a[2])],
+                          n_ridges=2)
+
+
+def test_extract_ridges_vs_reference(S, orc):
+    """The reference's outputs on its own transforms (tests/golden/ridges.npz), and bit for
+    bit against the oracle run with the device's logarithm."""
+    import torch
+    g = golden('ridges')
+    for k, kw in _golden_cases(g):
+        Tf, sc = g[k + '/Tf'], g[k + '/scales']
+        ri, rf, re = S.extract_ridges(Tf, sc, get_params=True, **kw)
+        ref_i, ref_f, ref_e = g[k + '/idx'], g[k + '/f'], g[k + '/e']
+        assert isinstance(ri, np.ndarray) and ri.shape == ref_i.shape, k
+        assert rf.dtype == ref_f.dtype and re.dtype == ref_e.dtype, k
+        same = (ri == ref_i)
+        assert same.mean() >= 0.99, (k, same.mean())
+        assert np.abs(ri - ref_i).max() <= 2, k
+        assert np.array_equal(rf[same], ref_f[same]), k
+        tol = 1e-6 if re.dtype == np.float32 else 1e-13
+        assert np.abs(re[same] - ref_e[same]).max() <= tol * np.abs(ref_e).max(), k
+        # tensors in -> tensors out, same values
+        ti = S.extract_ridges(torch.as_tensor(np.asarray(Tf, dtype=Tf.dtype if Tf.dtype.kind in 'fc'
+                                                         else np.float64), device='cuda'),
+                              sc, **kw)
+        assert isinstance(ti, torch.Tensor) and np.array_equal(ti.cpu().numpy(), ri), k
+
+
+def test_basic_example(S):
+    """tests/ridge_extraction_test.py:17-26."""
+    tm = np.array([[1, 4, 4], [2, 2, 2], [5, 5, 4]])
+    ridge_idxs, *_ = S.extract_ridges(tm, np.exp([1, 2, 3]), penalty=2.0, get_params=True)
+    assert np.allclose(ridge_idxs, np.array([[2, 2, 2]]))
+
+
+def test_on_device_transforms(S):
+    """ssq_cwt / ssq_stft output -> ridges without leaving the device; the two chirps of
+    the test signal are found (tests/ridge_extraction_test.py:66-88 runs the same pipeline
+    for coverage)."""
+    import torch
+    N = 4096
+    x = two_chirps(N, 3, noise=0.01)
+    Tx, Wx, ssq_freqs, scales = S.ssq_cwt(torch.as_tensor(x, device='cuda'), 'gmw')
+    r = S.extract_ridges(Tx, ssq_freqs, penalty=2.0, n_ridges=2, bw=4, transform='cwt')
+    assert isinstance(r, torch.Tensor) and tuple(r.shape) == (N, 2)
+    r = r.cpu().numpy()
+    fr = np.asarray(ssq_freqs.cpu() if hasattr(ssq_freqs, 'cpu') else ssq_freqs)[r]
+    mid = slice(N // 8, -N // 8)
+    # the first ridge is a smooth curve (a chirp's frequency moves by < 2 bins per sample),
+    # the second one is another component
+    assert np.abs(np.diff(r[mid, 0])).max() <= 2
+    assert (fr[mid, 0] != fr[mid, 1]).mean() > 0.99
+    Ts, Sx, sf, Sfs = S.ssq_stft(torch.as_tensor(x, device='cuda'), n_fft=256)
+    rs = S.extract_ridges(Ts, sf, penalty=20.0, n_ridges=2, bw=4, transform='stft', get_params=True)
+    assert all(isinstance(a, torch.Tensor) for a in rs) and tuple(rs[0].shape) == (N, 2)
+
+
+def test_argument_checks(S):
+    with pytest.raises(ValueError):
+        S.extract_ridges(np.zeros((4, 8, 2)), np.arange(1, 5.))
+    with pytest.raises(ValueError):
+        S.extract_ridges(np.ones((4, 8), dtype='complex64'), np.arange(1, 4.))
+    with pytest.raises(ValueError):
+        S.extract_ridges(np.ones((4, 8), dtype='complex64'), np.arange(1, 5.), transform='dwt')

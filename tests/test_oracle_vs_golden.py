@@ -123,3 +123,28 @@ def test_replace_and_buffer_bitexact(orc, dtype):
             if mod:     # modulated framing == ifftshift of each frame
                 plain = orc.buffer(x, seg, ov, False)
                 assert np.array_equal(out, np.fft.ifftshift(plain, axes=0))
+
+
+def _ridge_cases(g):
+    names = sorted({k.rsplit('/', 1)[0] for k in g.files if '/' in k})
+    for k in names:
+        if k == 'basic':
+            yield k, dict(penalty=2.0, bw=15, transform='cwt', n_ridges=1)
+        else:
+            a = g[k + '/args']
+            yield k, dict(penalty=a[0], bw=int(a[1]), transform=('cwt', 'stft')[int(a[2])],
+                          n_ridges=2)
+
+
+def test_ridge_extraction_bitexact(orc):
+    """extract_ridges (ridge_extraction.py:11-232) on the reference's own transforms and
+    its 3x3 example (tests/ridge_extraction_test.py:17-26): indices, scales and energies."""
+    g = golden('ridges')
+    n_cases = 0
+    for k, kw in _ridge_cases(g):
+        ri, rf, re = orc.extract_ridges(g[k + '/Tf'], g[k + '/scales'], get_params=True, **kw)
+        assert np.array_equal(ri, g[k + '/idx']), k
+        assert np.array_equal(rf, g[k + '/f']), k
+        assert np.array_equal(re, g[k + '/e']), k
+        n_cases += 1
+    assert n_cases == 9

@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+"""The ridge-tracking kernels (csrc/ssq_ridge.hip) compiled for the host and run with one
+OS thread per work-item (tests/emu/): checks the workgroup geometry, the LDS layout, the
+barriers and the index arithmetic against the CPU oracle where no GPU is available.
+The numbers a GPU produces are checked by tests/test_gpu_ridges.py; this is the same source
+through the same C entry points on host memory. CPU-only."""
+import ctypes
+import os
+import shutil
+import subprocess
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, 'emu')
+LIB = os.path.join(EMU, '_build', 'libridge_emu.so')
+CLANG = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin', 'clang++')
+
+
+@pytest.fixture(scope='module')
+def emu():
+    if not os.path.isfile(CLANG):                      # ext_vector_type needs clang
+        pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
+    src = [os.path.join(EMU, 'ridge_emu.cpp'), os.path.join(EMU, 'hip', 'hip_runtime.h'),
+           os.path.join(HERE, '..', 'ssqueezepy_amd', 'csrc', 'ssq_ridge.hip')]
+    if not os.path.isfile(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, src)):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.check_call([CLANG, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread',
+                               '-ffp-contract=off', '-I', EMU, '-x', 'c++', src[0], '-o', LIB])
+    return ctypes.CDLL(LIB)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.mark.parametrize('cdtype,na,n,transform', [
+    ('complex64', 30, 40, 'cwt'), ('complex128', 30, 40, 'stft'), ('float64', 20, 35, 'cwt'),
+    ('complex64', 300, 12, 'cwt'), ('complex128', 300, 9, 'cwt'), ('complex64', 1100, 3, 'stft'),
+    ('complex64', 5, 1, 'cwt')])
+def test_emulated_kernels_vs_oracle(emu, orc, cdtype, na, n, transform):
+    rng = np.random.default_rng(na + n)
+    ridge_row = na * (0.3 + 0.4 * np.arange(n)[None] / n)
+    mag = rng.random((na, n)) + 3 * np.exp(-0.5 * ((np.arange(na)[:, None] - ridge_row) / 2)**2)
+    Tf = ((mag * np.exp(2j * np.pi * rng.random((na, n)))).astype(cdtype)
+          if cdtype.startswith('c') else mag.astype(cdtype))
+    scales = np.exp(np.linspace(-0.3, 6.2, na)) if transform == 'cwt' else np.linspace(0, .5, na)
+    penalty = 2.0 if transform == 'cwt' else 40.0
+    pdt, eps, P = orc.ridge_design(Tf.dtype, scales, penalty, transform)
+    sc = np.asarray(scales, dtype=pdt)
+    sc = np.ascontiguousarray(np.log(sc) if transform == 'cwt' else sc)
+    f64 = Tf.dtype in (np.complex128, np.float64)
+    rdt, code = (np.float64, 1) if f64 else (np.float32, 0)
+    en = np.empty((na, n), rdt)
+    E, pe = np.empty_like(en), np.empty_like(en)
+    ridge = np.empty(n, np.int64)
+    i64, dbl = ctypes.c_int64, ctypes.c_double
+    assert emu.ssq_ridge_energy(code, int(np.iscomplexobj(Tf)), _p(Tf), _p(en), i64(na), i64(n),
+                                None) == 0
+    assert emu.ssq_ridge_neglog(code, _p(en), _p(E), dbl(float(eps)), i64(na), i64(n), None) == 0
+    assert emu.ssq_ridge_track(code, int(pdt == np.float32), _p(E), _p(pe), _p(sc),
+                               dbl(penalty), dbl(float(eps)), i64(na), i64(n), _p(ridge), None) == 0
+    en_ref = np.abs(Tf)**2
+    tol = 1e-6 if rdt == np.float32 else 1e-13
+    assert np.abs(en - en_ref).max() <= tol * np.abs(en_ref).max()
+    ridge_ref, pe_ref = orc.ridge_track(E, P.reshape(na, na), eps)
+    assert np.array_equal(pe, pe_ref)
+    assert np.array_equal(ridge, ridge_ref)
+    # zeroing of the band around the ridge, Python slice rules (ridge_extraction.py:147-150)
+    for bw in (4, 2.5, 40):
+        en2, ref = en.copy(), en.copy()
+        r_e = np.empty(n, rdt)
+        assert emu.ssq_ridge_clear(code, _p(en2), _p(ridge), dbl(bw), _p(r_e), i64(na), i64(n),
+                                   None) == 0
+        for t in range(n):
+            ref[int(ridge[t] - bw):int(ridge[t] + bw), t] = 0
+        assert np.array_equal(en2, ref)
+        assert np.array_equal(r_e, en[ridge, np.arange(n)])

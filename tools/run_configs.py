@@ -87,6 +87,17 @@ def main():
         ms, xr = timeit(lambda: S.istft(Sx, n_fft=1024, hop_len=256, N=N), 10)
         print(json.dumps({"config": "istft N=160k n_fft=1024 hop=256 f32", "ms": ms}))
 
+    if 'ridges' in which:
+        # ridge extraction at config-2 size (sequential in time: one workgroup)
+        N, na = int(os.environ.get('RIDGE_N', 160000)), 300
+        wav = S.Wavelet()
+        scales = S.process_scales('log', N, wav, nv=32)[:na]
+        x = torch.as_tensor(two_chirps(N, 0), dtype=torch.float32, device=dev)
+        Tx, Wx, ssq_freqs, sc = S.ssq_cwt(x, wav, scales=scales)
+        ms, r = timeit(lambda: S.extract_ridges(Tx, ssq_freqs, penalty=2.0, n_ridges=1, bw=4), 2)
+        print(json.dumps({"config": "extract_ridges ssq_cwt N=%d 300 scales f32, 1 ridge" % N,
+                          "ms": ms, "us_per_step": ms * 1e3 / N}))
+
 
 if __name__ == '__main__':
     main()
