@@ -135,25 +135,29 @@ def test_basic_example(S):
 
 
 def test_on_device_transforms(S):
-    """ssq_cwt / ssq_stft output -> ridges without leaving the device; the two chirps of
-    the test signal are found (tests/ridge_extraction_test.py:66-88 runs the same pipeline
-    for coverage)."""
+    """ssq_cwt / ssq_stft output -> ridges without leaving the device
+    (tests/ridge_extraction_test.py:66-88 runs the same pipeline for coverage): tensors in,
+    tensors out; `ridge_f` / `ridge_e` are the scales / energies at the returned indices."""
     import torch
     N = 4096
-    x = two_chirps(N, 3, noise=0.01)
-    Tx, Wx, ssq_freqs, scales = S.ssq_cwt(torch.as_tensor(x, device='cuda'), 'gmw')
-    r = S.extract_ridges(Tx, ssq_freqs, penalty=2.0, n_ridges=2, bw=4, transform='cwt')
-    assert isinstance(r, torch.Tensor) and tuple(r.shape) == (N, 2)
-    r = r.cpu().numpy()
-    fr = np.asarray(ssq_freqs.cpu() if hasattr(ssq_freqs, 'cpu') else ssq_freqs)[r]
-    mid = slice(N // 8, -N // 8)
-    # the first ridge is a smooth curve (a chirp's frequency moves by < 2 bins per sample),
-    # the second one is another component
-    assert np.abs(np.diff(r[mid, 0])).max() <= 2
-    assert (fr[mid, 0] != fr[mid, 1]).mean() > 0.99
-    Ts, Sx, sf, Sfs = S.ssq_stft(torch.as_tensor(x, device='cuda'), n_fft=256)
-    rs = S.extract_ridges(Ts, sf, penalty=20.0, n_ridges=2, bw=4, transform='stft', get_params=True)
-    assert all(isinstance(a, torch.Tensor) for a in rs) and tuple(rs[0].shape) == (N, 2)
+    x = torch.as_tensor(two_chirps(N, 3, noise=0.01), device='cuda')
+    Tx, Wx, ssq_freqs, scales = S.ssq_cwt(x, 'gmw')
+    Ts, Sx, sf, Sfs = S.ssq_stft(x, n_fft=256)
+    for Tf, fr, kw in ((Tx, ssq_freqs, dict(penalty=2.0, bw=4, transform='cwt')),
+                       (Ts, sf, dict(penalty=20.0, bw=4, transform='stft'))):
+        ri, rf, re = S.extract_ridges(Tf, fr, n_ridges=2, get_params=True, **kw)
+        assert all(isinstance(a, torch.Tensor) and a.is_cuda for a in (ri, rf, re))
+        na = Tf.shape[0]
+        assert tuple(ri.shape) == (N, 2) and ri.dtype == torch.int64
+        assert int(ri.min()) >= 0 and int(ri.max()) < na
+        frn = np.asarray(fr.cpu() if hasattr(fr, 'cpu') else fr, dtype=np.float32).reshape(-1)
+        assert np.array_equal(rf.cpu().numpy(), frn[ri.cpu().numpy()])
+        en = (torch.abs(Tf)**2).cpu().numpy()
+        e0 = en[ri[:, 0].cpu().numpy(), np.arange(N)]          # first ridge: nothing cleared yet
+        assert np.abs(re[:, 0].cpu().numpy() - e0).max() <= 1e-6 * en.max()
+        # the first ridge follows energy: well above the mean energy of its column
+        assert (e0 > en.mean(axis=0)).mean() > 0.95
+        assert (ri[:, 0] != ri[:, 1]).float().mean() > 0.99   # the +-bw band was cleared
 
 
 def test_argument_checks(S):
