@@ -17,6 +17,7 @@
 // Everything is bit-identical to the reference's loops for identical E.
 #include "ssq_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace ssq {
@@ -127,25 +128,42 @@ struct Cand4<float, float> {                                     // packed fp32:
     }
 };
 
-constexpr int RIDGE_NT = 1024;     // forward-pass workgroup
-constexpr int RIDGE_F = 4;         // rows f per thread (they share the candidates read from LDS)
 
+// Forward-pass geometry. Work item (s, q), q < nf = ceil(na / F), s < S: the F rows q, q + nf,
+// ..., q + (F - 1) nf (they share the candidates read from LDS) against the candidates g in
+// [s C, (s + 1) C).
+//   generic  : 1024 threads, C at run time, the penalty re-formed every step (2.5 VALU
+//              instructions per candidate);
+//   register : 512 threads (256 VGPRs each), (F, C) template constants, the thread's F x C
+//              penalties formed once and kept in registers (1 instruction per candidate);
+//              float32 penalties with nf * ceil(na / C) <= 512: up to 320 rows in float32.
 struct RidgeGeom {
-    int nf;       // groups of RIDGE_F rows: group q owns rows q, q + nf, q + 2 nf, q + 3 nf
-    int S;        // threads per group; thread s scans candidates g in [s C, (s + 1) C)
-    int C;        // candidates per thread, a multiple of 4
-    int TT;       // tile width in time steps (power of two)
+    int F, nf, S, C, TT, creg, nt;
     size_t lds;   // dynamic LDS bytes
 };
 
 template <typename T, typename TP>
 static RidgeGeom ridge_geometry(int64_t na) {
     RidgeGeom g;
-    g.nf = (int)((na + RIDGE_F - 1) / RIDGE_F);
-    g.S = RIDGE_NT / g.nf;
-    if (g.S < 1) g.S = 1;
-    if (g.S > 32) g.S = 32;
-    g.C = (int)(((na + g.S - 1) / g.S + 3) / 4 * 4);
+    g.F = 4; g.creg = 0; g.nt = 1024;
+    static const bool no_reg = getenv("SSQ_RIDGE_GENERIC") != nullptr;
+    if (sizeof(TP) == 4 && !no_reg) {
+        const int fc[3][2] = {{4, 16}, {4, 32}, {5, 40}};      // instantiated below
+        for (int i = 0; i < (sizeof(T) == 4 ? 3 : 1); ++i)
+            if (((na + fc[i][0] - 1) / fc[i][0]) * ((na + fc[i][1] - 1) / fc[i][1]) <= 512) {
+                g.F = fc[i][0]; g.creg = fc[i][1];
+                break;
+            }
+    }
+    g.nf = (int)((na + g.F - 1) / g.F);
+    if (g.creg) {
+        g.nt = 512; g.C = g.creg; g.S = (int)((na + g.C - 1) / g.C);
+    } else {
+        g.S = g.nt / g.nf;
+        if (g.S < 1) g.S = 1;
+        if (g.S > 32) g.S = 32;
+        g.C = (int)(((na + g.S - 1) / g.S + 3) / 4 * 4);
+    }
     g.TT = 32;
     for (;;) {
         g.lds = (size_t)3 * g.S * g.C * sizeof(T) + (size_t)g.S * na * sizeof(T) +
@@ -156,11 +174,12 @@ static RidgeGeom ridge_geometry(int64_t na) {
     return g;
 }
 
-template <typename T, typename TP>
-__global__ __launch_bounds__(RIDGE_NT) void ridge_fw_kernel(const T* __restrict__ E, T* __restrict__ pe,
-                                                            const TP* __restrict__ sc, TP pen, int na,
-                                                            int64_t n, int nf, int S, int C, int TT) {
+template <typename T, typename TP, int NT, int RIDGE_F, int CREG>
+__global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T* __restrict__ pe,
+                                                      const TP* __restrict__ sc, TP pen, int na,
+                                                      int64_t n, int nf, int S, int Crt, int TT) {
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
+    const int C = CREG ? CREG : Crt;
     const int SC = S * C, W = TT + 1;
     T* prev0 = reinterpret_cast<T*>(smem);                      // pe[:, t-1], +inf beyond na
     T* prev1 = prev0 + SC;
@@ -169,55 +188,101 @@ __global__ __launch_bounds__(RIDGE_NT) void ridge_fw_kernel(const T* __restrict_
     T* tile = part + (size_t)S * na;                            // (na, TT + 1) E in, pe out
     const int tid = threadIdx.x;
     const T inf = std::numeric_limits<T>::infinity();
-    for (int i = tid; i < SC; i += RIDGE_NT) {
+    for (int i = tid; i < SC; i += NT) {
         prev0[i] = inf; prev1[i] = inf;
         negs[i] = i < na ? -sc[i] : (TP)0;
     }
-    const int q0 = tid / S, s = tid - q0 * S, qstride = RIDGE_NT / S;
+    // work item w = s * nf + q: the lanes of a wavefront share the slice s (at most two slices
+    // per wavefront), so the candidate reads below are LDS broadcasts
+    const int nwork = nf * S, s0 = tid / nf, q0 = tid - s0 * nf;
     const int ntile = (int)((n + TT - 1) / TT);
     T* cur = prev0;
     T* nxt = prev1;
+    // register variant: this thread's penalties P[f_u, g], g in its slice (nwork <= NT)
+    constexpr int NP = CREG ? CREG : 1;
+    TP Preg[RIDGE_F][NP];
+    if constexpr (CREG != 0) {
+        __syncthreads();
+        if (tid < nwork) {
+#pragma unroll
+            for (int u = 0; u < RIDGE_F; ++u) {
+                const int f = q0 + u * nf;
+                const TP sf = f < na ? -negs[f] : (TP)0;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const TP d = sf + negs[s0 * C + k];          // s_f - s_g
+                    Preg[u][k] = pen * (d * d);
+                }
+            }
+        }
+    }
     for (int b = 0; b < ntile; ++b) {
         const int64_t t0 = (int64_t)b * TT;
         const int len = (int)((n - t0) < TT ? (n - t0) : TT);
         __syncthreads();
-        for (int i = tid; i < na * TT; i += RIDGE_NT) {
+        for (int i = tid; i < na * TT; i += NT) {
             const int f = i / TT, tt = i - f * TT;
             if (tt < len) tile[f * W + tt] = E[(int64_t)f * n + t0 + tt];
         }
         __syncthreads();
         int tl = 0;
         if (b == 0) {                                           // pe[:, 0] = E[:, 0]
-            for (int f = tid; f < na; f += RIDGE_NT) cur[f] = tile[f * W];
+            for (int f = tid; f < na; f += NT) cur[f] = tile[f * W];
             __syncthreads();
             tl = 1;
         }
         for (; tl < len; ++tl) {
-            for (int q = q0 < qstride ? q0 : nf; q < nf; q += qstride) {
-                TP sf[RIDGE_F]; T m[RIDGE_F];
+            if constexpr (CREG != 0) {
+                if (tid < nwork) {
+                    T m[RIDGE_F];
 #pragma unroll
-                for (int u = 0; u < RIDGE_F; ++u) {
-                    const int f = q + u * nf;
-                    sf[u] = f < na ? -negs[f] : (TP)0;
-                    m[u] = inf;
+                    for (int u = 0; u < RIDGE_F; ++u) m[u] = inf;
+                    const T* pv = cur + s0 * C;
+#pragma unroll
+                    for (int k = 0; k < NP; k += 4) {
+                        T p4[4];
+                        lds_load4(pv + k, p4);
+#pragma unroll
+                        for (int u = 0; u < RIDGE_F; ++u) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m[u] = min_(m[u], p4[e] + (T)Preg[u][(k + e) % NP]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < RIDGE_F; ++u) {
+                        const int f = q0 + u * nf;
+                        if (f < na) part[s0 * na + f] = m[u];
+                    }
                 }
-                const T* pv = cur + s * C;
-                const TP* ng = negs + s * C;
-                for (int k = 0; k < C; k += 4) {
-                    T p4[4]; TP g4[4];
-                    lds_load4(pv + k, p4);
-                    lds_load4(ng + k, g4);
+            } else {
+                for (int w = tid; w < nwork; w += NT) {
+                    int s = s0, q = q0;
+                    if (w != tid) { s = w / nf; q = w - s * nf; }
+                    TP sf[RIDGE_F]; T m[RIDGE_F];
 #pragma unroll
-                    for (int u = 0; u < RIDGE_F; ++u) Cand4<T, TP>::run(m[u], sf[u], pen, p4, g4);
-                }
+                    for (int u = 0; u < RIDGE_F; ++u) {
+                        const int f = q + u * nf;
+                        sf[u] = f < na ? -negs[f] : (TP)0;
+                        m[u] = inf;
+                    }
+                    const T* pv = cur + s * C;
+                    const TP* ng = negs + s * C;
+                    for (int k = 0; k < C; k += 4) {
+                        T p4[4]; TP g4[4];
+                        lds_load4(pv + k, p4);
+                        lds_load4(ng + k, g4);
 #pragma unroll
-                for (int u = 0; u < RIDGE_F; ++u) {
-                    const int f = q + u * nf;
-                    if (f < na) part[s * na + f] = m[u];
+                        for (int u = 0; u < RIDGE_F; ++u) Cand4<T, TP>::run(m[u], sf[u], pen, p4, g4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < RIDGE_F; ++u) {
+                        const int f = q + u * nf;
+                        if (f < na) part[s * na + f] = m[u];
+                    }
                 }
             }
             __syncthreads();
-            for (int f = tid; f < na; f += RIDGE_NT) {
+            for (int f = tid; f < na; f += NT) {
                 T m = part[f];
                 for (int k = 1; k < S; ++k) m = min_(m, part[k * na + f]);
                 const T v = tile[f * W + tl] + m;
@@ -227,7 +292,7 @@ __global__ __launch_bounds__(RIDGE_NT) void ridge_fw_kernel(const T* __restrict_
             __syncthreads();
             T* sw = cur; cur = nxt; nxt = sw;
         }
-        for (int i = tid; i < na * TT; i += RIDGE_NT) {
+        for (int i = tid; i < na * TT; i += NT) {
             const int f = i / TT, tt = i - f * TT;
             if (tt < len) pe[(int64_t)f * n + t0 + tt] = tile[f * W + tt];
         }
@@ -268,20 +333,28 @@ __global__ __launch_bounds__(256) void ridge_bw_kernel(const T* __restrict__ E, 
             for (int tl = len - 1; tl >= 0; --tl) {
                 const T val = peT[r * W + tl + 1] - eT[r * W + tl + 1];
                 const TP sr = scs[r];
+                const int fwd = idx[tl];                        // the forward argmin of column tl
                 int best = -1;
-                for (int k = K - 1; k >= 0; --k) {
-                    const int f = k * 64 + lane;
-                    bool hit = false;
-                    if (f < na) {
-                        const TP d = sr - scs[f];
-                        const TP p = pen * (d * d);
-                        const T c = peT[f * W + tl] + (T)p;
-                        hit = fabs(val - c) < eps;
+                for (int k1 = K; k1 > 0 && best < 0; k1 -= 4) {  // rows [64 (k1 - 4), 64 k1), top first
+                    T c4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {               // independent LDS reads
+                        const int f = (k1 - 1 - j) * 64 + lane;
+                        c4[j] = (T)0;
+                        if (f >= 0 && f < na) {
+                            const TP d = sr - scs[f];
+                            c4[j] = peT[f * W + tl] + (T)(pen * (d * d));
+                        }
                     }
-                    const unsigned long long bal = __ballot(hit);
-                    if (bal) { best = k * 64 + 63 - __builtin_clzll(bal); break; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = (k1 - 1 - j) * 64 + lane;
+                        const bool hit = f >= 0 && f < na && fabs(val - c4[j]) < eps;
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal && best < 0) best = (k1 - 1 - j) * 64 + 63 - __builtin_clzll(bal);
+                    }
                 }
-                r = best >= 0 ? best : idx[tl];
+                r = best >= 0 ? best : fwd;
                 if (lane == 0) idx[tl] = r;
             }
         }
@@ -296,11 +369,20 @@ static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double
     const RidgeGeom g = ridge_geometry<T, TP>(na);
     SSQ_REQUIRE(g.lds <= 160 * 1024, "ssq_ridge_track: %lld rows do not fit the workgroup's LDS",
                 (long long)na);
-    auto fw = ridge_fw_kernel<T, TP>;
-    SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fw),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds));
-    hipLaunchKernelGGL(fw, dim3(1), dim3(RIDGE_NT), g.lds, stream, E, pe, sc, (TP)penalty, (int)na, n,
-                       g.nf, g.S, g.C, g.TT);
+#define FW_LAUNCH(NT, F, CREG)                                                                     \
+    do {                                                                                           \
+        auto fw = ridge_fw_kernel<T, TP, NT, F, CREG>;                                             \
+        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fw),                       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)); \
+        hipLaunchKernelGGL(fw, dim3(1), dim3(NT), g.lds, stream, E, pe, sc, (TP)penalty, (int)na, n, \
+                           g.nf, g.S, g.C, g.TT);                                                  \
+    } while (0)
+    constexpr bool PF = sizeof(TP) == 4, TF = sizeof(T) == 4;   // register variants: see ridge_geometry
+    if (PF && g.creg == 16) FW_LAUNCH(512, 4, (PF ? 16 : 0));
+    else if (PF && TF && g.creg == 32) FW_LAUNCH(512, 4, (PF && TF ? 32 : 0));
+    else if (PF && TF && g.creg == 40) FW_LAUNCH(512, 5, (PF && TF ? 40 : 0));
+    else FW_LAUNCH(1024, 4, 0);
+#undef FW_LAUNCH
     SSQ_LAUNCH_CHECK();
     hipLaunchKernelGGL((ridge_argmin_kernel<T>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
                        (const T*)pe, ridge, na, n);

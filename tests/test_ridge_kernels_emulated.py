@@ -37,7 +37,10 @@ def _p(a):
 @pytest.mark.parametrize('cdtype,na,n,transform', [
     ('complex64', 30, 40, 'cwt'), ('complex128', 30, 40, 'stft'), ('float64', 20, 35, 'cwt'),
     ('complex64', 300, 12, 'cwt'), ('complex128', 300, 9, 'cwt'), ('complex64', 1100, 3, 'stft'),
-    ('complex64', 5, 1, 'cwt')])
+    ('complex64', 5, 1, 'cwt'),
+    # register-resident penalty variants (F, C) = (4, 32), (4, 16), (4, 16) with float64 data
+    ('complex64', 256, 6, 'cwt'), ('complex64', 129, 8, 'stft'), ('float64', 150, 5, 'cwt'),
+    ('complex64', 320, 4, 'stft'), ('complex64', 321, 4, 'cwt')])
 def test_emulated_kernels_vs_oracle(emu, orc, cdtype, na, n, transform):
     rng = np.random.default_rng(na + n)
     ridge_row = na * (0.3 + 0.4 * np.arange(n)[None] / n)
