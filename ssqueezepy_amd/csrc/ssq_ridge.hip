@@ -196,6 +196,7 @@ __global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T
     // per wavefront), so the candidate reads below are LDS broadcasts
     const int nwork = nf * S, s0 = tid / nf, q0 = tid - s0 * nf;
     const int ntile = (int)((n + TT - 1) / TT);
+    const int lt = 31 - __builtin_clz((unsigned)TT);           // TT is a power of two
     T* cur = prev0;
     T* nxt = prev1;
     // register variant: this thread's penalties P[f_u, g], g in its slice (nwork <= NT)
@@ -220,9 +221,19 @@ __global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T
         const int64_t t0 = (int64_t)b * TT;
         const int len = (int)((n - t0) < TT ? (n - t0) : TT);
         __syncthreads();
-        for (int i = tid; i < na * TT; i += NT) {
-            const int f = i / TT, tt = i - f * TT;
-            if (tt < len) tile[f * W + tt] = E[(int64_t)f * n + t0 + tt];
+        for (int i0 = tid; i0 < na * TT; i0 += NT * 8) {       // 8 loads in flight per thread
+            T v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * NT, f = i >> lt, tt = i & (TT - 1);
+                v8[j] = (T)0;
+                if (f < na && tt < len) v8[j] = E[(int64_t)f * n + t0 + tt];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * NT, f = i >> lt, tt = i & (TT - 1);
+                if (f < na && tt < len) tile[f * W + tt] = v8[j];
+            }
         }
         __syncthreads();
         int tl = 0;
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T
             T* sw = cur; cur = nxt; nxt = sw;
         }
         for (int i = tid; i < na * TT; i += NT) {
-            const int f = i / TT, tt = i - f * TT;
+            const int f = i >> lt, tt = i & (TT - 1);
             if (tt < len) pe[(int64_t)f * n + t0 + tt] = tile[f * W + tt];
         }
     }
@@ -301,9 +312,10 @@ __global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T
 
 // -------------------------------------------------------------------- backward pass
 // One wavefront walks t = n-2 .. 0 (every step depends on the index chosen at t+1); the
-// workgroup's four wavefronts stage the (na x TT+1)-column tiles of pe and E in LDS.
+// workgroup's eight wavefronts stage the (na x TT+1)-column tiles of pe and E in LDS.
+constexpr int RIDGE_BW_NT = 512;
 template <typename T, typename TP>
-__global__ __launch_bounds__(256) void ridge_bw_kernel(const T* __restrict__ E, const T* __restrict__ pe,
+__global__ __launch_bounds__(RIDGE_BW_NT) void ridge_bw_kernel(const T* __restrict__ E, const T* __restrict__ pe,
                                                        const TP* __restrict__ sc, TP pen, T eps, int na,
                                                        int64_t n, int64_t* __restrict__ ridge, int TT) {
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
@@ -313,7 +325,8 @@ __global__ __launch_bounds__(256) void ridge_bw_kernel(const T* __restrict__ E, 
     TP* scs = reinterpret_cast<TP*>(eT + (size_t)na * W);
     int* idx = reinterpret_cast<int*>(scs + na + (na & 1));
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < na; i += 256) scs[i] = sc[i];
+    for (int i = tid; i < na; i += RIDGE_BW_NT) scs[i] = sc[i];
+    const int lt = 31 - __builtin_clz((unsigned)TT);           // TT is a power of two
     if (n < 2) return;
     int r = (int)ridge[n - 1];
     const int K = (na + 63) / 64;
@@ -322,12 +335,28 @@ __global__ __launch_bounds__(256) void ridge_bw_kernel(const T* __restrict__ E, 
         const int64_t t0 = (int64_t)b * TT;
         const int len = (int)((n - 1 - t0) < TT ? (n - 1 - t0) : TT);   // steps in this tile
         __syncthreads();
-        for (int i = tid; i < na * (len + 1); i += 256) {
-            const int f = i / (len + 1), tt = i - f * (len + 1);
-            peT[f * W + tt] = pe[(int64_t)f * n + t0 + tt];
-            eT[f * W + tt] = E[(int64_t)f * n + t0 + tt];
+        for (int i0 = tid; i0 < na * TT; i0 += RIDGE_BW_NT * 4) {   // columns t0 .. t0 + len - 1
+            T a4[4], b4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * RIDGE_BW_NT, f = i >> lt, tt = i & (TT - 1);
+                a4[j] = b4[j] = (T)0;
+                if (f < na && tt < len) {
+                    a4[j] = pe[(int64_t)f * n + t0 + tt];
+                    b4[j] = E[(int64_t)f * n + t0 + tt];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = i0 + j * RIDGE_BW_NT, f = i >> lt, tt = i & (TT - 1);
+                if (f < na && tt < len) { peT[f * W + tt] = a4[j]; eT[f * W + tt] = b4[j]; }
+            }
         }
-        for (int i = tid; i < len; i += 256) idx[i] = (int)ridge[t0 + i];
+        for (int f = tid; f < na; f += RIDGE_BW_NT) {              // column t0 + len (<= n - 1)
+            peT[f * W + len] = pe[(int64_t)f * n + t0 + len];
+            eT[f * W + len] = E[(int64_t)f * n + t0 + len];
+        }
+        for (int i = tid; i < len; i += RIDGE_BW_NT) idx[i] = (int)ridge[t0 + i];
         __syncthreads();
         if (tid < 64) {
             for (int tl = len - 1; tl >= 0; --tl) {
@@ -359,7 +388,7 @@ __global__ __launch_bounds__(256) void ridge_bw_kernel(const T* __restrict__ E, 
             }
         }
         __syncthreads();
-        for (int i = tid; i < len; i += 256) ridge[t0 + i] = idx[i];
+        for (int i = tid; i < len; i += RIDGE_BW_NT) ridge[t0 + i] = idx[i];
     }
 }
 
@@ -399,7 +428,7 @@ static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double
     auto bwk = ridge_bw_kernel<T, TP>;
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bwk, dim3(1), dim3(256), lds, stream, E, (const T*)pe, sc, (TP)penalty, (T)eps,
+    hipLaunchKernelGGL(bwk, dim3(1), dim3(RIDGE_BW_NT), lds, stream, E, (const T*)pe, sc, (TP)penalty, (T)eps,
                        (int)na, n, ridge, TT);
     SSQ_LAUNCH_CHECK();
     return 0;
