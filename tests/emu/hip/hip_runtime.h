@@ -1,151 +1,273 @@
-// Host stand-in for <hip/hip_runtime.h>, just large enough to run csrc/ssq_ridge.hip and
-// csrc/ssq_kernels.hip on CPU threads (tests/emu/*_emu.cpp): one OS thread per work-item, pthread barriers
-// for __syncthreads, a per-wavefront rendezvous for __ballot. TEST INFRASTRUCTURE ONLY --
-// it checks the kernels' control flow and index arithmetic where no GPU is available.
+// Host stand-in for <hip/hip_runtime.h>, just large enough to run ssqueezepy_amd/csrc on the
+// CPU: every work-item of a workgroup is a fiber (ucontext) of one OS thread, scheduled
+// wavefront by wavefront; __syncthreads and the wavefront operations (ballot, DPP moves,
+// wave_barrier) are the points where a fiber yields. The workgroups of a launch are spread
+// over the host's cores (block-scope and dynamic LDS arrays are thread_local).
+// TEST INFRASTRUCTURE ONLY -- it checks the kernels' control flow, LDS layout and index
+// arithmetic where no GPU is available; the product never includes it.
 #pragma once
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <functional>
 #include <thread>
 #include <vector>
-#include <pthread.h>
+#include <sys/mman.h>
+#include <ucontext.h>
 
 // HIP's global-namespace device math that the kernels use unqualified
-#include <algorithm>
 using std::isinf; using std::isnan; using std::min; using std::max;
 inline long long min(long long a, long b) { return a < b ? a : b; }
 inline long long max(long long a, int b) { return a > b ? a : b; }
+
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
 #define __align__(x) __attribute__((aligned(x)))
+#ifdef EMU_STATIC_SHARED
+#define __shared__ static thread_local      // block-scope LDS arrays: one copy per OS thread
+#else
+#define __shared__ thread_local             // `extern __shared__` dynamic LDS: emu_globals.cpp
+#endif
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 struct alignas(16) float4 { float x, y, z, w; };
 struct alignas(32) double4 { double x, y, z, w; };
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) double2 { double x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
+// ------------------------------------------------------------------ runtime API ("device"
+// memory is host memory, streams and events are no-ops)
 typedef int hipError_t;
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
+constexpr int hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3;
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
-// "device" memory is host memory
-struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
-constexpr int hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3;
 inline hipError_t hipGetDeviceCount(int* c) { *c = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
-    __builtin_strcpy(p->name, "host emulation"); __builtin_strcpy(p->gcnArchName, "host");
+    strcpy(p->name, "host emulation"); strcpy(p->gcnArchName, "host");
     p->multiProcessorCount = 1; p->totalGlobalMem = 0;
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 template <typename P> hipError_t hipMalloc(P** p, size_t n) { return hipMalloc((void**)p, n); }
+inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+template <typename P> hipError_t hipMallocAsync(P** p, size_t n, hipStream_t) { return hipMalloc((void**)p, n); }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) {
-    __builtin_memcpy(d, s, n); return hipSuccess;
-}
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { __builtin_memset(d, v, n); return hipSuccess; }
+inline hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 
+// ------------------------------------------------------------------ fibers
 namespace emu {
-struct Block {
-    pthread_barrier_t bar;
-    std::vector<pthread_barrier_t> wave_bar;
-    std::vector<unsigned long long> votes;      // one word per wavefront
-    std::vector<int> xchg;                      // one word per lane (DPP moves)
+enum Wait { RUNNABLE = 0, AT_WAVE = 1, AT_BLOCK = 2, FINISHED = 3 };
+struct Fiber {
+    ucontext_t ctx;
+    void* stack = nullptr;
+    int wait = RUNNABLE;
+    unsigned tid = 0;
+    unsigned gen = 0;                        // wavefront operations executed so far
 };
-extern thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
-extern thread_local Block* t_block;
+struct Wave {                                // rotating slots: see __ballot below
+    unsigned long long votes[3];
+    int xchg[3][64];
+};
+struct Worker {                              // one per OS thread: the workgroup it is running
+    ~Worker() { for (auto& f : fibers) if (f.stack) munmap(f.stack, 256 * 1024); }
+    ucontext_t sched;
+    std::vector<Fiber> fibers;               // grown to the largest workgroup seen
+    std::vector<Wave> waves;
+    Fiber* cur = nullptr;
+    const std::function<void()>* body = nullptr;
+    dim3 blockIdx_, blockDim_, gridDim_;
+};
+extern thread_local Worker t_worker;
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+inline void yield(int why) {
+    Worker& w = t_worker;
+    Fiber* f = w.cur;
+    f->wait = why;
+    swapcontext(&f->ctx, &w.sched);
 }
-#define threadIdx (emu::t_threadIdx)
-#define blockIdx (emu::t_blockIdx)
-#define blockDim (emu::t_blockDim)
-#define gridDim (emu::t_gridDim)
+inline void fiber_main() {
+    Worker& w = t_worker;
+    (*w.body)();
+    w.cur->wait = FINISHED;
+    swapcontext(&w.cur->ctx, &w.sched);      // never resumed
+}
+inline void resume(Worker& w, Fiber& f) {
+    w.cur = &f;
+    f.wait = RUNNABLE;
+    swapcontext(&w.sched, &f.ctx);
+}
+// run one workgroup of `nt` work-items to completion on the calling OS thread
+inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, dim3 gdim) {
+    Worker& w = t_worker;
+    const unsigned nt = bdim.x, nw = (nt + 63) / 64;
+    if (w.fibers.size() < nt) {
+        const size_t old = w.fibers.size();
+        w.fibers.resize(nt);
+        for (size_t i = old; i < nt; ++i) {
+            w.fibers[i].stack = mmap(nullptr, STACK_BYTES, PROT_READ | PROT_WRITE,
+                                     MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (w.fibers[i].stack == MAP_FAILED) { perror("emu: mmap"); abort(); }
+        }
+    }
+    if (w.waves.size() < nw) w.waves.resize(nw);
+    for (unsigned i = 0; i < nw; ++i) memset(&w.waves[i], 0, sizeof(Wave));
+    w.body = &body; w.blockIdx_ = bidx; w.blockDim_ = bdim; w.gridDim_ = gdim;
+    for (unsigned t = 0; t < nt; ++t) {
+        Fiber& f = w.fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK_BYTES; f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_main, 0);
+        f.wait = RUNNABLE; f.tid = t; f.gen = 0;
+    }
+    for (;;) {                               // one iteration = one __syncthreads phase
+        bool any_alive = false;
+        for (unsigned wv = 0; wv < nw; ++wv) {
+            const unsigned lo = wv * 64, hi = std::min(nt, lo + 64);
+            for (;;) {                       // sweep the wave until it reaches a block barrier
+                bool at_wave = false, other = false;
+                for (unsigned t = lo; t < hi; ++t) {
+                    Fiber& f = w.fibers[t];
+                    if (f.wait == FINISHED || f.wait == AT_BLOCK) continue;
+                    resume(w, f);            // RUNNABLE or AT_WAVE: run to its next yield
+                }
+                for (unsigned t = lo; t < hi; ++t) {
+                    const int s = w.fibers[t].wait;
+                    if (s == AT_WAVE) at_wave = true;
+                    else if (s == AT_BLOCK) other = true;
+                }
+                if (!at_wave) break;
+                if (other) {
+                    fprintf(stderr, "emu: wavefront %u of workgroup (%u,%u,%u) diverged: some lanes "
+                            "wait at a wavefront operation, others at __syncthreads\n", wv, bidx.x, bidx.y, bidx.z);
+                    abort();
+                }
+            }
+            for (unsigned t = lo; t < hi; ++t) any_alive |= w.fibers[t].wait == AT_BLOCK;
+        }
+        if (!any_alive) break;
+        for (unsigned t = 0; t < nt; ++t)
+            if (w.fibers[t].wait == AT_BLOCK) w.fibers[t].wait = RUNNABLE;
+    }
+}
+}  // namespace emu
 
-inline void __syncthreads() { pthread_barrier_wait(&emu::t_block->bar); }
+#define threadIdx (dim3(emu::t_worker.cur->tid))
+#define blockIdx (emu::t_worker.blockIdx_)
+#define blockDim (emu::t_worker.blockDim_)
+#define gridDim (emu::t_worker.gridDim_)
 
-// ---- wavefront-level operations: every lane of the wavefront must take part (the kernels call
-// them under wave-uniform control flow only), realised as rendezvous of the wave's 64 threads
+inline void __syncthreads() { emu::yield(emu::AT_BLOCK); }
+
+// ---- wavefront-level operations. Every live lane of a wavefront executes the same sequence
+// of them (the kernels call them under wave-uniform control flow only). A lane publishes its
+// contribution in slot gen % 3, yields, and reads the slot after every lane has run up to the
+// same point; slot (gen + 2) % 3 -- last used two operations ago, no lane can still need it --
+// is cleared for later use.
 inline void emu_wave_barrier() {
-    pthread_barrier_wait(&emu::t_block->wave_bar[emu::t_threadIdx.x / 64]);
+    emu::Worker& w = emu::t_worker;
+    const unsigned g = w.cur->gen++;
+    emu::yield(emu::AT_WAVE);
+    w.waves[w.cur->tid / 64].votes[(g + 2) % 3] = 0;
 }
 #define __builtin_amdgcn_wave_barrier emu_wave_barrier
+
+inline unsigned long long __ballot(bool pred) {
+    emu::Worker& w = emu::t_worker;
+    emu::Fiber* f = w.cur;
+    emu::Wave& wv = w.waves[f->tid / 64];
+    const unsigned g = f->gen++, lane = f->tid % 64;
+    if (pred) wv.votes[g % 3] |= 1ull << lane;
+    emu::yield(emu::AT_WAVE);
+    wv.votes[(g + 2) % 3] = 0;
+    return wv.votes[g % 3];
+}
+#define __builtin_amdgcn_ballot_w64 __ballot
 
 // v_mov_b32_dpp row_shr:N (ctrl 0x110 + N): lane L of a 16-lane row reads lane L - N of the
 // same row; without a source: 0 if bound_ctrl, else `old`
 inline int emu_update_dpp(int old, int v, int ctrl, int, int, bool bound_ctrl) {
-    emu::Block* b = emu::t_block;
-    const unsigned w = emu::t_threadIdx.x / 64, lane = emu::t_threadIdx.x % 64;
+    emu::Worker& w = emu::t_worker;
+    emu::Fiber* f = w.cur;
+    emu::Wave& wv = w.waves[f->tid / 64];
+    const unsigned g = f->gen++, lane = f->tid % 64;
     const int N = ctrl - 0x110;
-    if (N < 1 || N > 15) abort();
-    b->xchg[w * 64 + lane] = v;
-    pthread_barrier_wait(&b->wave_bar[w]);
+    if (N < 1 || N > 15) { fprintf(stderr, "emu: unsupported dpp_ctrl %#x\n", ctrl); abort(); }
+    wv.xchg[g % 3][lane] = v;
+    emu::yield(emu::AT_WAVE);
+    wv.votes[(g + 2) % 3] = 0;
     const bool has = (int)(lane % 16) >= N;
-    const int r = has ? b->xchg[w * 64 + lane - N] : (bound_ctrl ? 0 : old);
-    pthread_barrier_wait(&b->wave_bar[w]);
-    return r;
+    return has ? wv.xchg[g % 3][lane - N] : (bound_ctrl ? 0 : old);
 }
 #define __builtin_amdgcn_update_dpp emu_update_dpp
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 
 inline float __log2f(float x) { return log2f(x); }          // v_log_f32 (1 ulp)
-inline int __float_as_int(float f) { int i; __builtin_memcpy(&i, &f, 4); return i; }
-inline float __int_as_float(int i) { float f; __builtin_memcpy(&f, &i, 4); return f; }
-inline int __double2loint(double d) { long long q; __builtin_memcpy(&q, &d, 8); return (int)(q & 0xffffffffll); }
-inline int __double2hiint(double d) { long long q; __builtin_memcpy(&q, &d, 8); return (int)(q >> 32); }
+inline int __ffs(int x) { return __builtin_ffs(x); }
+inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+inline int __double2loint(double d) { long long q; memcpy(&q, &d, 8); return (int)(q & 0xffffffffll); }
+inline int __double2hiint(double d) { long long q; memcpy(&q, &d, 8); return (int)(q >> 32); }
 inline double __hiloint2double(int hi, int lo) {
-    long long q = ((long long)hi << 32) | (unsigned int)lo; double d; __builtin_memcpy(&d, &q, 8); return d;
+    long long q = ((long long)hi << 32) | (unsigned int)lo; double d; memcpy(&d, &q, 8); return d;
 }
 
-// wave64 ballot: every lane of the (fully active) wavefront must call it
-inline unsigned long long __ballot(bool pred) {
-    emu::Block* b = emu::t_block;
-    const unsigned w = emu::t_threadIdx.x / 64, lane = emu::t_threadIdx.x % 64;
-    if (lane == 0) b->votes[w] = 0;
-    pthread_barrier_wait(&b->wave_bar[w]);
-    if (pred) __atomic_fetch_or(&b->votes[w], 1ull << lane, __ATOMIC_SEQ_CST);
-    pthread_barrier_wait(&b->wave_bar[w]);
-    const unsigned long long v = b->votes[w];
-    pthread_barrier_wait(&b->wave_bar[w]);
-    return v;
-}
-
-#define __builtin_amdgcn_ballot_w64 __ballot
-
+// ------------------------------------------------------------------ launch
 template <typename K, typename... Args>
 void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
-    const unsigned nt = block.x, nw = (nt + 63) / 64;
-    for (unsigned by = 0; by < grid.y; ++by)
-        for (unsigned bx = 0; bx < grid.x; ++bx) {
-            emu::Block blk;
-            pthread_barrier_init(&blk.bar, nullptr, nt);
-            blk.wave_bar.resize(nw); blk.votes.assign(nw, 0); blk.xchg.assign(nw * 64, 0);
-            for (unsigned w = 0; w < nw; ++w) {
-                const unsigned cnt = (w + 1) * 64 <= nt ? 64 : nt - w * 64;
-                pthread_barrier_init(&blk.wave_bar[w], nullptr, cnt);
-            }
-            std::vector<std::thread> th;
-            th.reserve(nt);
-            for (unsigned t = 0; t < nt; ++t)
-                th.emplace_back([&, t] {
-                    emu::t_threadIdx = dim3(t); emu::t_blockIdx = dim3(bx, by);
-                    emu::t_blockDim = block; emu::t_gridDim = grid; emu::t_block = &blk;
-                    kernel(args...);
-                });
-            for (auto& x : th) x.join();
-            pthread_barrier_destroy(&blk.bar);
-            for (auto& wb : blk.wave_bar) pthread_barrier_destroy(&wb);
+    const std::function<void()> body = [=] { kernel(args...); };
+    const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t b = next.fetch_add(1);
+            if (b >= nblocks) return;
+            const unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y),
+                           bz = (unsigned)(b / ((size_t)grid.x * grid.y));
+            emu::run_block(body, dim3(bx, by, bz), block, grid);
         }
+    };
+    static const unsigned ncpu = [] {
+        const char* e = getenv("SSQ_EMU_THREADS");
+        unsigned n = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        return n < 1 ? 1u : (n > 16 ? 16u : n);
+    }();
+    const unsigned nth = (unsigned)std::min<size_t>(ncpu, nblocks);
+    if (nth <= 1) { work(); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nth; ++i) th.emplace_back(work);
+    for (auto& t : th) t.join();
 }
 // (kernel), grid, block, dynamic LDS bytes, stream, args...
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \

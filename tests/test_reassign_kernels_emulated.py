@@ -6,45 +6,22 @@ DPP moves / ballots), driven through the product's own host layer (ssqueezepy_am
 and compared bit for bit with the CPU oracle. It checks tile geometry, LDS layout, the
 in-order fold and the index arithmetic where no GPU is available; what a GPU computes is
 checked by tests/test_gpu_kernels.py. CPU-only."""
-import ctypes
-import os
-import subprocess
 import numpy as np
 import pytest
+import emu_backend
 from conftest import kernel_inputs, make_ssq_freqs, const_of
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-EMU = os.path.join(HERE, 'emu')
-LIB = os.path.join(EMU, '_build', 'libkernels_emu.so')
-CLANG = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin', 'clang++')
 NUMBA = 0
 
 
 @pytest.fixture(scope='module')
 def A():
     """ssqueezepy_amd.algos bound to the emulated library, tensors on the host."""
-    if not os.path.isfile(CLANG):
+    if not emu_backend.available():
         pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
-    csrc = os.path.join(HERE, '..', 'ssqueezepy_amd', 'csrc')
-    src = [os.path.join(EMU, 'kernels_emu.cpp'), os.path.join(EMU, 'hip', 'hip_runtime.h')] + [
-        os.path.join(csrc, f) for f in ('ssq_kernels.hip', 'ssq_point_math.inl', 'ssq_common.h')]
-    if not os.path.isfile(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, src)):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call([CLANG, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread',
-                               '-ffp-contract=off', '-I', EMU, '-x', 'c++', src[0], '-o', LIB])
-    import torch
-    from ssqueezepy_amd import _lib, algos
-    lib = ctypes.CDLL(LIB)
-    for name, (res, args) in _lib._PROTOS.items():
-        if hasattr(lib, name):
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
-    saved = (_lib.load, algos.device, algos.stream)
-    _lib.load = lambda *a, **k: lib
-    algos.device = lambda: torch.device('cpu')
-    algos.stream = lambda: None
-    yield algos
-    _lib.load, algos.device, algos.stream = saved
+    with emu_backend.emulated():
+        from ssqueezepy_amd import algos
+        yield algos
 
 
 def _np(t):

@@ -1,33 +1,20 @@
 # -*- coding: utf-8 -*-
 """The ridge-tracking kernels (csrc/ssq_ridge.hip) compiled for the host and run with one
-OS thread per work-item (tests/emu/): checks the workgroup geometry, the LDS layout, the
+OS thread per work-item (tests/emu/, tests/emu_backend.py): checks the workgroup geometry, the LDS layout, the
 barriers and the index arithmetic against the CPU oracle where no GPU is available.
 The numbers a GPU produces are checked by tests/test_gpu_ridges.py; this is the same source
 through the same C entry points on host memory. CPU-only."""
 import ctypes
-import os
-import shutil
-import subprocess
 import numpy as np
 import pytest
-
-HERE = os.path.dirname(os.path.abspath(__file__))
-EMU = os.path.join(HERE, 'emu')
-LIB = os.path.join(EMU, '_build', 'libridge_emu.so')
-CLANG = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib', 'llvm', 'bin', 'clang++')
+import emu_backend
 
 
 @pytest.fixture(scope='module')
 def emu():
-    if not os.path.isfile(CLANG):                      # ext_vector_type needs clang
+    if not emu_backend.available():                    # ext_vector_type needs clang
         pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
-    src = [os.path.join(EMU, 'ridge_emu.cpp'), os.path.join(EMU, 'hip', 'hip_runtime.h'),
-           os.path.join(HERE, '..', 'ssqueezepy_amd', 'csrc', 'ssq_ridge.hip')]
-    if not os.path.isfile(LIB) or os.path.getmtime(LIB) < max(map(os.path.getmtime, src)):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.check_call([CLANG, '-O1', '-std=c++17', '-fPIC', '-shared', '-pthread',
-                               '-ffp-contract=off', '-I', EMU, '-x', 'c++', src[0], '-o', LIB])
-    return ctypes.CDLL(LIB)
+    return ctypes.CDLL(emu_backend.build())
 
 
 def _p(a):

@@ -1,0 +1,90 @@
+# -*- coding: utf-8 -*-
+"""cwt / ssq_cwt / stft / ssq_stft / inverses through the public API with the product's own
+kernels and host code running under the CPU emulator (tests/emu/, tests/emu_backend.py: every
+translation unit of csrc/ compiled for the host, one OS thread per work-item, a CPU DFT in
+rocFFT's place). Same assertions as the GPU suite -- several of its test functions are run
+as they are -- at sizes the emulator finishes in seconds: the reference's fixtures for the
+generic plans and the fused STFT kernel, the CPU oracle for the block ("overlap-save zoom")
+kernels in both precisions. It checks everything but what only a GPU can show (speed, the
+hardware's arithmetic in `log2`/`rcp`/rocFFT). CPU-only."""
+import numpy as np
+import pytest
+import emu_backend
+from conftest import golden, two_chirps
+from pipeline import oracle_ssq_cwt
+
+RTOL = {'float32': 1e-5, 'float64': 1e-12}
+
+
+@pytest.fixture(scope='module')
+def S():
+    if not emu_backend.available():
+        pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
+    with emu_backend.emulated() as mod:
+        yield mod
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, 'detach') else t
+
+
+@pytest.mark.parametrize('dtype,N,st,nv', [('float32', 256, 'log-piecewise', 16),
+                                          ('float64', 256, 'log', 16),
+                                          ('float32', 256, 'linear', None)])
+def test_generic_plan_vs_reference(S, orc, dtype, N, st, nv):
+    """ssq_cwt below the block path's minimum length: banded multiply -> inverse FFT ->
+    epilogue -> reassignment, against the reference's outputs (tests/golden/cwt_*.npz)."""
+    from test_gpu_transforms import check_Tx
+    g = golden('cwt_' + dtype)
+    wav = S.Wavelet(('gmw', {'dtype': dtype}))
+    x = g[f'x/{N}']
+    Tx, Wx, ssq_freqs, scales, dWx = S.ssq_cwt(x, wav, scales=st, nv=nv, get_dWx=True)
+    Tx, Wx, dWx = _np(Tx), _np(Wx), _np(dWx)
+    pre = f'{N}/{st}'
+    assert np.array_equal(scales, g[f'scales/{pre}'])
+    assert np.array_equal(ssq_freqs, g[f'ssq_freqs/{pre}'])
+    assert relmax(Wx, g[f'Wx/{pre}']) <= RTOL[dtype]
+    r = oracle_ssq_cwt(orc, x, dtype, scales=st, nv=nv)
+    check_Tx(orc, Tx, Wx, dWx, r, dtype)          # exact given the emulated Wx, dWx
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_block_kernels_vs_oracle(S, orc, dtype):
+    """The block ("overlap-save zoom") kernels -- LDS FFT, fused epilogue with the 2-byte bin
+    map, reassignment from the bin map -- against the oracle of the reference's full-length
+    algorithm."""
+    from test_gpu_transforms import check_Tx
+    from ssqueezepy_amd import _cwt
+    N, nv = 1500, 8
+    x = two_chirps(N, seed=N)
+    wav = S.Wavelet(('gmw', {'dtype': dtype}))
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+    assert plan.algo.startswith('blockzoom') and plan.block_rows > 0.5 * len(sc)
+    r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=nv, typing=1)
+    assert np.array_equal(sf, r['ssq_freqs']) and np.array_equal(sc, r['scales'])
+    assert relmax(Wx, r['Wx']) <= RTOL[dtype] and relmax(dWx, r['dWx']) <= RTOL[dtype]
+    check_Tx(orc, Tx, Wx, dWx, r, dtype)
+    # without dWx the kernels write the bin map only (the bench configuration)
+    Tx2, Wx2, *_ = S.ssq_cwt(x, wav, scales='log', nv=nv, astensor=False)
+    assert np.array_equal(Wx2, Wx) and np.array_equal(Tx2, Tx)
+    _cwt.clear_plan_cache()
+
+
+def test_stft_paths_vs_reference(S, orc):
+    """The GPU suite's own ssq_stft test (fused STFT kernel with the bin map, generic
+    rocFFT path, reference fixtures) under the emulator."""
+    from test_gpu_transforms import test_ssq_stft_vs_reference
+    test_ssq_stft_vs_reference(S, orc, 'float32')
+
+
+def test_inverses_vs_reference(S):
+    """icwt / issq_cwt / istft / issq_stft (tests/test_gpu_inverse.py) under the emulator."""
+    import test_gpu_inverse as TI
+    TI.test_icwt_and_issq_cwt(S, 'float32')
+    TI.test_istft_and_issq_stft(S, 'float64')
