@@ -16,6 +16,24 @@ def pytest_configure(config):
         "markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def compute_module():
+    """Generator behind the `S` / `A` fixtures of the GPU test modules: the package bound to
+    the in-tree HIP library on a real GPU -- or, with SSQ_EMULATE=1 (a development aid, run
+    e.g. `SSQ_EMULATE=1 pytest tests -m gpu -k "not full_size"` in a container without a GPU),
+    bound to the CPU emulation of the same kernels (tests/emu_backend.py)."""
+    if os.environ.get('SSQ_EMULATE') == '1':
+        import emu_backend
+        with emu_backend.emulated() as mod:
+            yield mod
+        return
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import ssqueezepy_amd
+    from ssqueezepy_amd import _lib
+    _lib.load(build_if_missing=False)          # the in-tree HIP library must exist
+    yield ssqueezepy_amd
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 

@@ -47,3 +47,16 @@ def test_compute_layer_fails_loudly_without_gpu():
     from ssqueezepy_amd import cwt
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cwt(np.random.randn(512), 'gmw', scales='log')
+
+
+def test_c_client_against_emulated_library(tmp_path):
+    """tests/cabi/cabi_smoke.c (the plain-C client of include/ssq_hip.h that the GPU suite
+    runs against libssq_hip.so) linked against the host build of the same sources
+    (tests/emu/): the C ABI exercised end to end without a GPU."""
+    import emu_backend
+    from test_gpu_cabi_c import build_and_run
+    if not emu_backend.available():
+        import pytest
+        pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
+    lib = emu_backend.build()
+    build_and_run(tmp_path, os.path.dirname(lib), os.path.basename(lib))

@@ -13,12 +13,8 @@ NUMBA = 0
 
 @pytest.fixture(scope='module')
 def S():
-    import torch
-    assert torch.cuda.is_available()
-    import ssqueezepy_amd
-    from ssqueezepy_amd import _lib
-    _lib.load(build_if_missing=False)
-    return ssqueezepy_amd
+    from conftest import compute_module
+    yield from compute_module()
 
 
 def relmax(a, b):

@@ -21,12 +21,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 
 @pytest.fixture(scope='module')
 def S():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
-    import ssqueezepy_amd as S
-    from ssqueezepy_amd import _lib
-    _lib.load(build_if_missing=False)
-    return S
+    from conftest import compute_module
+    yield from compute_module()
 
 
 def _stages(Tf, sc, penalty, eps, penalty_f32):

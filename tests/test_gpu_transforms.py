@@ -23,12 +23,8 @@ RTOL = {'float32': 1e-5, 'float64': 1e-12}
 
 @pytest.fixture(scope='module')
 def S():
-    import torch
-    assert torch.cuda.is_available()
-    import ssqueezepy_amd
-    from ssqueezepy_amd import _lib
-    _lib.load(build_if_missing=False)
-    return ssqueezepy_amd
+    from conftest import compute_module
+    yield from compute_module()
 
 
 def _np(t):
