@@ -11,10 +11,12 @@ indices the only difference left is the last bit of |Tf| and `log`, which can mo
 ridge at isolated columns (synchrosqueezed transforms are mostly exact zeros, i.e. ties):
 at least 99 % of the indices identical (measured: 8 of 9 cases identical, the second ridge
 of the float32 ssq_cwt case differs at 2 of 384 columns)."""
-import ctypes
+import os
 import numpy as np
 import pytest
 from conftest import golden, two_chirps
+
+DEV = 'cpu' if os.environ.get('SSQ_EMULATE') == '1' else 'cuda'    # see conftest.compute_module
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 
@@ -30,20 +32,21 @@ def _stages(Tf, sc, penalty, eps, penalty_f32):
     import torch
     from ssqueezepy_amd import _lib
     from ssqueezepy_amd._lib import check, F32, F64
-    lib = _lib.load(build_if_missing=False)
-    Tf = torch.as_tensor(Tf, device='cuda').contiguous()
+    lib = _lib.load()
+    Tf = torch.as_tensor(Tf, device=DEV).contiguous()
     f64 = Tf.dtype in (torch.complex128, torch.float64)
     rdt, code = (torch.float64, F64) if f64 else (torch.float32, F32)
     na, n = Tf.shape
-    en = torch.empty((na, n), dtype=rdt, device='cuda')
+    en = torch.empty((na, n), dtype=rdt, device=DEV)
     E, pe = torch.empty_like(en), torch.empty_like(en)
-    ridge = torch.empty(n, dtype=torch.int64, device='cuda')
-    scd = torch.as_tensor(np.ascontiguousarray(sc), device='cuda')
+    ridge = torch.empty(n, dtype=torch.int64, device=DEV)
+    scd = torch.as_tensor(np.ascontiguousarray(sc), device=DEV)
     check(lib.ssq_ridge_energy(code, int(Tf.is_complex()), Tf.data_ptr(), en.data_ptr(), na, n, None))
     check(lib.ssq_ridge_neglog(code, en.data_ptr(), E.data_ptr(), float(eps), na, n, None))
     check(lib.ssq_ridge_track(code, int(penalty_f32), E.data_ptr(), pe.data_ptr(), scd.data_ptr(),
                               float(penalty), float(eps), na, n, ridge.data_ptr(), None))
-    torch.cuda.synchronize()
+    if DEV == 'cuda':
+        torch.cuda.synchronize()
     return en.cpu().numpy(), E.cpu().numpy(), pe.cpu().numpy(), ridge.cpu().numpy()
 
 
@@ -118,7 +121,7 @@ def test_extract_ridges_vs_reference(S, orc):
         assert np.abs(re[same] - ref_e[same]).max() <= tol * np.abs(ref_e).max(), k
         # tensors in -> tensors out, same values
         ti = S.extract_ridges(torch.as_tensor(np.asarray(Tf, dtype=Tf.dtype if Tf.dtype.kind in 'fc'
-                                                         else np.float64), device='cuda'),
+                                                         else np.float64), device=DEV),
                               sc, **kw)
         assert isinstance(ti, torch.Tensor) and np.array_equal(ti.cpu().numpy(), ri), k
 
@@ -136,7 +139,7 @@ def test_on_device_transforms(S):
     tensors out; `ridge_f` / `ridge_e` are the scales / energies at the returned indices."""
     import torch
     N = 4096
-    x = torch.as_tensor(two_chirps(N, 3, noise=0.01), device='cuda')
+    x = torch.as_tensor(two_chirps(N, 3, noise=0.01), device=DEV)
     Tx, Wx, ssq_freqs, scales = S.ssq_cwt(x, 'gmw')
     Ts, Sx, sf, Sfs = S.ssq_stft(x, n_fft=256)
     for Tf, fr, kw in ((Tx, ssq_freqs, dict(penalty=2.0, bw=4, transform='cwt')),
