@@ -413,8 +413,27 @@ def gen_ridges():
     save('ridges', **d)
 
 
+def gen_experimental():
+    """freq_to_scale / scale_to_freq (experimental.py:15-143)."""
+    from ssqueezepy.experimental import freq_to_scale, scale_to_freq
+    d = {}
+    for name in ('gmw', 'morlet', 'bump'):
+        wav = Wavelet(name)
+        for N in (512, 2000):
+            sc = process_scales('log', N, wav, nv=8)
+            d[f's2f/{name}/{N}/scales'] = sc
+            d[f's2f/{name}/{N}/reflect'] = scale_to_freq(sc, wav, N, fs=2.0)
+            d[f's2f/{name}/{N}/none'] = scale_to_freq(sc, wav, N, padtype=None)
+        fr = np.linspace(0.02, 0.45, 24)
+        d[f'f2s/{name}/freqs'] = fr
+        d[f'f2s/{name}/peak'] = freq_to_scale(fr, wav, 1024)
+        d[f'f2s/{name}/energy'] = freq_to_scale(fr * 4, wav, 1024, fs=4, kind='energy',
+                                                n_search_scales=100, base=3)
+    save('experimental', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges', 'experimental']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

@@ -29,6 +29,7 @@ def __getattr__(name):
         'phase_stft_gpu': 'algos',
         'icwt': '_inverse', 'issq_cwt': '_inverse', 'istft': '_inverse',
         'issq_stft': '_inverse', 'extract_ridges': 'ridge_extraction',
+        'freq_to_scale': 'experimental', 'scale_to_freq': 'experimental',
     }
     if name in _lazy:
         import importlib

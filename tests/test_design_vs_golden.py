@@ -145,3 +145,23 @@ def test_degenerate_frequency_range_raises():
     scales, st, _, nv = process_scales('log', N, wav, nv=4, get_params=True)
     with pytest.raises(ValueError):
         _compute_associated_frequencies(scales, N, wav, st, 'peak', True, 1., 'cwt')
+
+
+def test_scale_frequency_conversions():
+    """freq_to_scale / scale_to_freq (experimental.py:15-143) against the reference."""
+    import warnings
+    from ssqueezepy_amd import Wavelet
+    from ssqueezepy_amd.experimental import freq_to_scale, scale_to_freq
+    g = golden('experimental')
+    for name in ('gmw', 'morlet', 'bump'):
+        wav = Wavelet(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for N in (512, 2000):
+                sc = g[f's2f/{name}/{N}/scales']
+                assert np.array_equal(scale_to_freq(sc, wav, N, fs=2.0), g[f's2f/{name}/{N}/reflect'])
+                assert np.array_equal(scale_to_freq(sc, wav, N, padtype=None), g[f's2f/{name}/{N}/none'])
+        fr = g[f'f2s/{name}/freqs']
+        assert np.array_equal(freq_to_scale(fr, wav, 1024), g[f'f2s/{name}/peak'])
+        assert np.array_equal(freq_to_scale(fr * 4, wav, 1024, fs=4, kind='energy',
+                                            n_search_scales=100, base=3), g[f'f2s/{name}/energy'])
