@@ -2,6 +2,7 @@
 """Randomised parity sweep (design aid): ssq_cwt / ssq_stft on the device against the CPU
 oracle pipeline for random lengths, voices, wavelets, pad types, dtypes and batch sizes.
     python tools/fuzz_parity.py [n_cases] [seed]
+(SSQ_EMULATE=1: against the CPU emulation of the kernels, tests/emu/, where there is no GPU.)
 Prints one line per case; exits non-zero on the first mismatch."""
 import os, sys
 import numpy as np
@@ -70,6 +71,10 @@ def main(n_cases=30, seed=0):
             ref = orc.ssqueeze(Sx, dSx, 'linear', p, Sfs[1] - Sfs[0], ro['gamma'], False,
                                Sfs=Sfs, typing=0)
             ok = eS <= tol and eD <= tol and np.array_equal(Tx, ref)
+            # without dSx the fused kernel hands the reassignment a 2-byte bin map instead
+            T2, S2, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, modulated=mod, dtype=dtype,
+                                    astensor=False)
+            ok = ok and np.array_equal(T2, Tx) and np.array_equal(S2, Sx)
             print('stft', dtype, 'N=%d n_fft=%d hop=%d mod=%d' % (N, n_fft, hop, mod),
                   'eS=%.1e eD=%.1e' % (eS, eD), 'OK' if ok else 'MISMATCH')
         if not ok:
@@ -78,4 +83,9 @@ def main(n_cases=30, seed=0):
 
 
 if __name__ == '__main__':
-    main(*(int(a) for a in sys.argv[1:3]))
+    if os.environ.get('SSQ_EMULATE') == '1':      # no GPU: the kernels under the CPU emulator
+        import emu_backend
+        with emu_backend.emulated():
+            main(*(int(a) for a in sys.argv[1:3]))
+    else:
+        main(*(int(a) for a in sys.argv[1:3]))
