@@ -151,9 +151,26 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         makecontext(&f.ctx, (void (*)())fiber_main, 0);
         f.wait = RUNNABLE; f.tid = t; f.gen = 0;
     }
+    // Wavefronts of a workgroup run one after another between two __syncthreads; a kernel that
+    // is free of LDS races gives the same result in any order. SSQ_EMU_ORDER=reverse|shuffle
+    // changes the order (shuffle: a new pseudo-random order every phase) to expose a missing
+    // barrier, which the default order could hide.
+    static const int order_mode = [] {
+        const char* e = getenv("SSQ_EMU_ORDER");
+        return !e ? 0 : (strcmp(e, "reverse") == 0 ? 1 : (strcmp(e, "shuffle") == 0 ? 2 : 0));
+    }();
+    std::vector<unsigned> order(nw);
+    unsigned long long rng = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)bidx.x * 7919u + bidx.y);
     for (;;) {                               // one iteration = one __syncthreads phase
         bool any_alive = false;
-        for (unsigned wv = 0; wv < nw; ++wv) {
+        for (unsigned i = 0; i < nw; ++i) order[i] = order_mode == 1 ? nw - 1 - i : i;
+        if (order_mode == 2)
+            for (unsigned i = nw; i > 1; --i) {
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                std::swap(order[i - 1], order[(rng >> 33) % i]);
+            }
+        for (unsigned oi = 0; oi < nw; ++oi) {
+            const unsigned wv = order[oi];
             const unsigned lo = wv * 64, hi = std::min(nt, lo + 64);
             for (;;) {                       // sweep the wave until it reaches a block barrier
                 bool at_wave = false, other = false;
