@@ -150,6 +150,13 @@ int ssq_band_colsum(int dtype, const void* Z, const int32_t* lo, const int32_t* 
 int ssq_icwt2(int dtype, void* Wp, const void* psih, void* out, int64_t na, int64_t n_up,
               void* stream);
 
+/* Frequency-domain differentiation of the rows of a CWT-like array (trigdiff,
+ * utils/common.py:161-245): out (rows, N) complex <- ifft(fft(Ap) * 1j * xi * fs)[:, n1 : n1 + N].
+ * `Ap` (rows, n_up) complex: the (padded) rows, overwritten (FFT workspace); `xi` (n_up) real:
+ * the frequency grid `_xifn(1, n_up)` in the data dtype. */
+int ssq_trigdiff(int dtype, void* Ap, const void* xi, double fs, void* out, int64_t rows,
+                 int64_t n_up, int64_t n1, int64_t N, void* stream);
+
 /* Inverse STFT: x (N) <- Sx (n_fft/2 + 1, n_hops) complex. irfft of every column
  * (rocFFT), fftshift of the frame if `modulated`, overlap-add with win_a = window^a,
  * division by the overlap-added win_a1 = window^(a+1), trim of n_fft/2 leading samples.

@@ -432,8 +432,27 @@ def gen_experimental():
     save('experimental', **d)
 
 
+def gen_trigdiff():
+    """trigdiff (utils/common.py:161-245) on the reference's own CWTs."""
+    from ssqueezepy.utils.common import trigdiff
+    d = {}
+    N = 300
+    x = two_chirps(N, seed=9)
+    for dtype in ('float32', 'float64'):
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        Wx, sc = cwt(x, wav, nv=4)
+        Wp, _ = cwt(x, wav, nv=4, rpadded=True)
+        d[f'Wx/{dtype}'], d[f'Wp/{dtype}'] = Wx, Wp
+        d[f'pad_N/{dtype}'] = trigdiff(Wx, fs=2.0, padtype='reflect', N=N)
+        d[f'pad_zero/{dtype}'] = trigdiff(Wx, fs=1.0, padtype='zero', N=N)
+        d[f'pad_quirk/{dtype}'] = trigdiff(Wx, fs=1.0, padtype='reflect')       # N=None
+        d[f'rpadded/{dtype}'] = trigdiff(Wp, fs=0.5, rpadded=True, N=N)
+        d[f'batched/{dtype}'] = trigdiff(np.stack([Wp, 2 * Wp[::-1]]), fs=1.0, rpadded=True, N=N)
+    save('trigdiff', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges', 'experimental']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges', 'experimental', 'trigdiff']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

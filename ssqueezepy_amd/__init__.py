@@ -29,7 +29,7 @@ def __getattr__(name):
         'phase_stft_gpu': 'algos',
         'icwt': '_inverse', 'issq_cwt': '_inverse', 'istft': '_inverse',
         'issq_stft': '_inverse', 'extract_ridges': 'ridge_extraction',
-        'freq_to_scale': 'experimental', 'scale_to_freq': 'experimental',
+        'freq_to_scale': 'experimental', 'scale_to_freq': 'experimental', 'trigdiff': 'common',
     }
     if name in _lazy:
         import importlib

@@ -83,6 +83,8 @@ _PROTOS = {
     'ssq_band_colsum': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                 c_void_p, c_int64, c_int64, c_void_p]),
     'ssq_icwt2': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    'ssq_trigdiff': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int64,
+                             c_int64, c_int64, c_void_p]),
     'ssq_istft': (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                           c_int64, c_int64, c_int64, c_int, c_void_p]),
     'ssq_ridge_energy': (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),

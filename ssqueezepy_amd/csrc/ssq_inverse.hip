@@ -12,6 +12,7 @@
 #include "ssq_common.h"
 #include "ssq_fft.h"
 #include <rocfft/rocfft.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -183,6 +184,70 @@ static int icwt2_t(int dtype, void* Wp, const void* psih, void* out, int64_t na,
     return rc;
 }
 
+// ------------------------------------------------------------------- trigdiff
+// F[r][k] *= 1j * xi[k] * fs, formed as the reference's complex expression
+// `A_freqdom * 1j * xi * fs` rounds it (utils/common.py:220): the rotation is exact, then one
+// rounding per real factor
+template <typename T>
+__global__ __launch_bounds__(256) void mul_ixi_kernel(T* __restrict__ F, const T* __restrict__ xi, T fs,
+                                                      int64_t rows, int64_t n) {
+    const int64_t total = rows * n;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const T x = xi[q % n];
+        const T re = F[2 * q], im = F[2 * q + 1];
+        F[2 * q] = (-im * x) * fs;
+        F[2 * q + 1] = (re * x) * fs;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unpad_rows_kernel(const T* __restrict__ F, T* __restrict__ out,
+                                                         int64_t rows, int64_t n_up, int64_t n1, int64_t N) {
+    const int64_t total = rows * N;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t r = q / N, j = q - r * N;
+        out[2 * q] = F[2 * (r * n_up + n1 + j)];
+        out[2 * q + 1] = F[2 * (r * n_up + n1 + j) + 1];
+    }
+}
+
+static std::mutex g_trig_mu;
+static std::map<std::tuple<int, int64_t, int64_t>, std::pair<FftPlan, FftPlan>> g_trig_plans;
+
+template <typename T>
+static int trigdiff_t(int dtype, void* Ap, const void* xi, double fs, void* out, int64_t rows,
+                      int64_t n_up, int64_t n1, int64_t N, hipStream_t stream) {
+    std::pair<FftPlan, FftPlan>* pp = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_trig_mu);
+        auto key = std::make_tuple(dtype, rows, n_up);
+        auto it = g_trig_plans.find(key);
+        if (it == g_trig_plans.end()) {
+            std::pair<FftPlan, FftPlan> pr;
+            int rc = pr.first.create(2, dtype, (size_t)n_up, (size_t)rows, 1.0);
+            if (rc) return rc;
+            rc = pr.second.create(1, dtype, (size_t)n_up, (size_t)rows, 1.0 / (double)n_up);
+            if (rc) return rc;
+            it = g_trig_plans.emplace(key, pr).first;
+        }
+        pp = &it->second;
+    }
+    int rc = pp->first.execute(Ap, nullptr, stream);
+    if (rc) return rc;
+    const int64_t total = rows * n_up;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL((mul_ixi_kernel<T>), dim3(blocks), dim3(256), 0, stream, (T*)Ap, (const T*)xi, (T)fs,
+                       rows, n_up);
+    SSQ_LAUNCH_CHECK();
+    rc = pp->second.execute(Ap, nullptr, stream);
+    if (rc) return rc;
+    const unsigned blocks2 = (unsigned)std::min<int64_t>((rows * N + 255) / 256, 65536);
+    hipLaunchKernelGGL((unpad_rows_kernel<T>), dim3(blocks2), dim3(256), 0, stream, (const T*)Ap, (T*)out, rows,
+                       n_up, n1, N);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
 struct IstftFft {
     rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr; void* work = nullptr;
 };
@@ -295,6 +360,17 @@ int ssq_icwt2(int dtype, void* Wp, const void* psih, void* out, int64_t na, int6
     SSQ_REQUIRE(na >= 1 && n_up >= 2, "icwt2: bad shape (%lld, %lld)", (long long)na, (long long)n_up);
     if (dtype == SSQ_F32) return icwt2_t<float>(dtype, Wp, psih, out, na, n_up, as_stream(stream));
     return icwt2_t<double>(dtype, Wp, psih, out, na, n_up, as_stream(stream));
+}
+
+int ssq_trigdiff(int dtype, void* Ap, const void* xi, double fs, void* out, int64_t rows, int64_t n_up,
+                 int64_t n1, int64_t N, void* stream) {
+    SSQ_REQUIRE(Ap && xi && out, "ssq_trigdiff: null pointer");
+    SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "bad dtype %d", dtype);
+    SSQ_REQUIRE(rows >= 1 && n_up >= 2 && n1 >= 0 && N >= 1 && n1 + N <= n_up,
+                "trigdiff: bad shape (%lld, %lld) / slice (%lld, %lld)", (long long)rows, (long long)n_up,
+                (long long)n1, (long long)N);
+    if (dtype == SSQ_F32) return trigdiff_t<float>(dtype, Ap, xi, fs, out, rows, n_up, n1, N, as_stream(stream));
+    return trigdiff_t<double>(dtype, Ap, xi, fs, out, rows, n_up, n1, N, as_stream(stream));
 }
 
 int ssq_istft(int dtype, const void* Sx, const void* win_a, const void* win_a1, void* x, int64_t n_fft,

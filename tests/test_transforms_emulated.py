@@ -84,7 +84,10 @@ def test_stft_paths_vs_reference(S, orc):
 
 
 def test_inverses_vs_reference(S):
-    """icwt / issq_cwt / istft / issq_stft (tests/test_gpu_inverse.py) under the emulator."""
+    """icwt / issq_cwt / istft / issq_stft / trigdiff (tests/test_gpu_inverse.py) under the
+    emulator."""
     import test_gpu_inverse as TI
     TI.test_icwt_and_issq_cwt(S, 'float32')
     TI.test_istft_and_issq_stft(S, 'float64')
+    TI.test_trigdiff_vs_reference(S, 'float32')
+    TI.test_trigdiff_vs_reference(S, 'float64')
