@@ -451,8 +451,39 @@ def gen_trigdiff():
     save('trigdiff', **d)
 
 
+def gen_phase_ssq():
+    """experimental.phase_ssqueeze (experimental.py:146-253) on the reference's own CWT / STFT."""
+    from ssqueezepy.experimental import phase_ssqueeze
+    d = {}
+    N = 256
+    x = two_chirps(N, seed=13)
+    for dtype in ('float32', 'float64'):
+        wav = Wavelet(('gmw', {'dtype': dtype}))
+        Wx, sc = cwt(x, wav, nv=8)
+        d[f'Wx/{dtype}'], d[f'sc/{dtype}'] = Wx, sc
+        for get_w in (True, False):
+            Tx, _, sf, _, _, w, dWx = phase_ssqueeze(Wx.copy(), None, scales=sc, wavelet=wav,
+                                                     padtype='reflect', difftype='trig',
+                                                     get_w=get_w, get_dWx=True, transform='cwt')
+            k = f'cwt/{dtype}/{int(get_w)}/'
+            d[k + 'Tx'], d[k + 'sf'], d[k + 'dWx'] = Tx, sf, dWx
+            if get_w:
+                d[k + 'w'] = w
+        Sx, dSx = stft(x, n_fft=64, hop_len=2, dtype=dtype, derivative=True)
+        d[f'Sx/{dtype}'], d[f'dSx/{dtype}'] = Sx, dSx
+        for get_w in (True, False):
+            Sfs0 = np.linspace(0, .5, len(Sx), dtype=dtype)
+            Tx, _, sf, _, Sfs, w, _ = phase_ssqueeze(Sx.copy(), dSx.copy(), ssq_freqs=Sfs0, Sfs=Sfs0,
+                                                     fs=1., get_w=get_w, transform='stft')
+            k = f'stft/{dtype}/{int(get_w)}/'
+            d[k + 'Tx'], d[k + 'sf'], d[k + 'Sfs'] = Tx, sf, Sfs
+            if get_w:
+                d[k + 'w'] = w
+    save('phase_ssq', **d)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges', 'experimental', 'trigdiff']
+    which = sys.argv[1:] or ['design', 'kernels', 'cwt', 'stft', 'inverse', 'hiorder', 'icwt2', 'ridges', 'experimental', 'trigdiff', 'phase_ssq']
     print("reference: ssqueezepy", sp.__version__, "numpy", np.__version__)
     for w in which:
         globals()['gen_' + w]()

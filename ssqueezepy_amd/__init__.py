@@ -30,6 +30,7 @@ def __getattr__(name):
         'icwt': '_inverse', 'issq_cwt': '_inverse', 'istft': '_inverse',
         'issq_stft': '_inverse', 'extract_ridges': 'ridge_extraction',
         'freq_to_scale': 'experimental', 'scale_to_freq': 'experimental', 'trigdiff': 'common',
+        'phase_ssqueeze': 'experimental', 'phase_transform': 'experimental',
     }
     if name in _lazy:
         import importlib

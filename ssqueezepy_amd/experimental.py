@@ -1,8 +1,9 @@
 # -*- coding: utf-8 -*-
-"""Scale <-> frequency conversions of ssqueezepy/experimental.py (`freq_to_scale` :15-85,
-`scale_to_freq` :88-143). Host-side design code (NumPy), value-exact with the reference;
-the transforms themselves (`phase_ssqueeze`, `phase_transform`) are `ssq_cwt` / `ssq_stft` /
-`ssqueeze` / `phase_cwt` / `phase_stft` of this package."""
+"""ssqueezepy/experimental.py on the MI355X: scale <-> frequency conversions
+(`freq_to_scale` :15-85, `scale_to_freq` :88-143; host-side design code, value-exact with the
+reference) and `phase_transform` / `phase_ssqueeze` (:146-253) for arbitrary CWT/STFT-like
+arrays, composed of this package's device functions (`trigdiff`, `phase_cwt`, `phase_stft`,
+`ssqueeze`)."""
 import warnings
 import numpy as np
 
@@ -10,7 +11,7 @@ from .wavelets import Wavelet, center_frequency
 from .scales import cwt_scalebounds
 from .padding import p2up
 
-__all__ = ['freq_to_scale', 'scale_to_freq']
+__all__ = ['freq_to_scale', 'scale_to_freq', 'phase_ssqueeze', 'phase_transform']
 
 
 def freq_to_scale(freqs, wavelet, N, fs=1, n_search_scales=None, kind='peak', base=2):
@@ -66,3 +67,73 @@ def scale_to_freq(scales, wavelet, N, fs=1, padtype='reflect'):
     assert freqs.max() <= 0.5, freqs.max()
     freqs *= fs
     return freqs
+
+
+def phase_ssqueeze(Wx, dWx=None, ssq_freqs=None, scales=None, Sfs=None, fs=1., t=None,
+                   squeezing='sum', maprange=None, wavelet=None, gamma=None,
+                   was_padded=True, flipud=False, rpadded=False, padtype=None, N=None,
+                   n1=None, difftype=None, difforder=None, get_w=False, get_dWx=False,
+                   transform='cwt'):
+    """`phase_transform`, then `ssqueeze`, on an arbitrary CWT/STFT-like `Wx`
+    (experimental.py:146-187). Returns ``Tx, Wx, ssq_freqs, scales, Sfs, w, dWx``."""
+    from .ssqueezing import ssqueeze
+    w, Wx, dWx, Sfs, gamma = phase_transform(
+        Wx, dWx, difftype, difforder=difforder, gamma=gamma, rpadded=rpadded,
+        padtype=padtype, N=N, n1=n1, get_w=get_w, fs=fs, transform=transform)
+    if w is not None and not get_dWx:
+        dWx = None
+    if maprange is None:
+        maprange = 'peak' if transform == 'cwt' else 'maximal'
+    Tx, ssq_freqs = ssqueeze(Wx, w, ssq_freqs, scales, Sfs, fs=fs, t=t,
+                             squeezing=squeezing, maprange=maprange, wavelet=wavelet,
+                             gamma=gamma, was_padded=was_padded, flipud=flipud, dWx=dWx,
+                             transform=transform)
+    return Tx, Wx, ssq_freqs, scales, Sfs, w, dWx
+
+
+def phase_transform(Wx, dWx=None, difftype='trig', difforder=4, gamma=None, fs=1.,
+                    Sfs=None, rpadded=False, padtype='reflect', N=None, n1=None,
+                    get_w=False, transform='cwt'):
+    """Unified CWT / STFT phase transform (experimental.py:190-253): computes `dWx` by
+    `trigdiff` when it is not given (CWT), and `w` when `get_w`. Only `difftype='trig'`
+    (`None` counts as 'trig' when `dWx` has to be formed) runs on the device, as in the
+    reference's GPU mode. Returns ``w, Wx, dWx, Sfs, gamma``."""
+    import torch
+    from . import algos
+    from .common import trigdiff
+    from .configs import EPS32, EPS64
+    from ._ssq_cwt import phase_cwt
+    from ._ssq_stft import phase_stft, _make_Sfs
+
+    if transform == 'stft' and dWx is None:
+        raise NotImplementedError("`phase_transform` without `dWx` for STFT is not "
+                                  "currently supported.")
+    if rpadded and N is None:
+        raise ValueError("`rpadded=True` requires `N`")
+    if Wx.ndim > 2 and get_w:
+        raise NotImplementedError("`get_w=True` unsupported with batched input.")
+    Wx = algos.to_device(Wx)
+    if gamma is None:
+        gamma = 10 * (EPS64 if Wx.dtype == torch.complex128 else EPS32)
+
+    if transform == 'cwt':
+        if N is None and not rpadded:
+            N = Wx.shape[-1]
+        if n1 is None:
+            _, n1, _ = p2up(N)
+        if dWx is None:
+            dWx = trigdiff(Wx, fs, padtype, rpadded, N=N, n1=n1, transform='cwt')
+        w = None
+        if get_w:
+            if difftype not in (None, 'trig'):
+                raise ValueError("`difftype != 'trig'` unsupported with tensor inputs.")
+            w = phase_cwt(Wx, dWx, 'trig', gamma)
+        Sfs = None
+    elif transform == 'stft':
+        if Sfs is None:
+            rdt = np.float64 if Wx.dtype == torch.complex128 else np.float32
+            Sfs = _make_Sfs(Wx.shape[-2], fs, rdt)
+        w = phase_stft(Wx, dWx, Sfs, gamma) if get_w else None
+    else:
+        raise ValueError("`transform` must be one of: cwt, stft (got %s)" % transform)
+    return w, Wx, dWx, Sfs, gamma

@@ -91,3 +91,5 @@ def test_inverses_vs_reference(S):
     TI.test_istft_and_issq_stft(S, 'float64')
     TI.test_trigdiff_vs_reference(S, 'float32')
     TI.test_trigdiff_vs_reference(S, 'float64')
+    TI.test_phase_ssqueeze_vs_reference(S, 'float32')
+    TI.test_phase_ssqueeze_vs_reference(S, 'float64')
