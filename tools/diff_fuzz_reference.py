@@ -1,0 +1,142 @@
+# -*- coding: utf-8 -*-
+"""Differential fuzz against the REFERENCE ITSELF (build container only: needs /root/reference).
+
+Runs ssqueezepy (imported with the numba stand-in of oracle/refshim, i.e. its CPU path with the
+loop nests as plain Python) and ssqueezepy_amd (its kernels under the CPU emulator, tests/emu/)
+in one process on random signals and random option combinations of the public API, and compares
+what the two return:
+    PYTHONPATH=oracle/refshim:/root/reference MPLBACKEND=Agg SSQ_GPU=0 SSQ_PARALLEL=0 \
+        python tools/diff_fuzz_reference.py [n_cases] [seed]
+`Wx`, `dWx`, `Sx`, inverses: 1e-5 / 1e-11 relative. `scales`, `ssq_freqs`: exact. `Tx` moves whole
+bins under last-bit input changes, so: column sums (assignment-invariant) and the fraction of
+entries that differ (<= 1 %)."""
+import os, sys, warnings, logging
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+os.environ.setdefault('SSQ_GPU', '0'); os.environ['SSQ_PARALLEL'] = '0'
+logging.disable(logging.WARNING)
+warnings.simplefilter('ignore')
+import ssqueezepy as R                      # the reference
+import emu_backend
+from conftest import two_chirps
+
+
+def relmax(a, b):
+    b = np.asarray(b)
+    return np.abs(np.asarray(a) - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def np_(t):
+    return t.detach().cpu().numpy() if hasattr(t, 'detach') else np.asarray(t)
+
+
+def same_Tx(Tx, ref, tol):
+    cs, cr = Tx.sum(-2), ref.sum(-2)
+    e = np.abs(cs - cr).max() / max(np.abs(cr).max(), 1e-300)
+    frac = (np.abs(Tx - ref) > 1e-5 * np.abs(ref).max()).mean()
+    return e <= 100 * tol and frac <= 1e-2, 'colsum %.1e differ %.1e' % (e, frac)
+
+
+def main(n_cases=40, seed=0):
+    rng = np.random.default_rng(seed)
+    bad = 0
+    with emu_backend.emulated() as S:
+        for case in range(n_cases):
+            dtype = str(rng.choice(['float32', 'float64']))
+            tol = 1e-5 if dtype == 'float32' else 1e-11
+            kind = rng.choice(['ssq_cwt', 'cwt', 'ssq_stft', 'inverse', 'ridges'])
+            N = int(rng.integers(64, 400))
+            x = two_chirps(N, seed=case + 1000 * seed)
+            fam = str(rng.choice(['gmw', 'morlet', 'bump', 'cmhat', 'hhhat']))
+            nv = int(rng.choice([4, 8, 16]))
+            pad = str(rng.choice(['reflect', 'zero', 'symmetric', 'wrap', 'replicate']))
+            st = str(rng.choice(['log', 'log-piecewise', 'linear']))
+            fs = float(rng.choice([1.0, 2.5, 100.0]))
+            desc, ok, info = '', True, ''
+            try:
+                if kind == 'cwt':
+                    l1 = bool(rng.random() < 0.7)
+                    kw = dict(scales=st, nv=nv, padtype=pad, fs=fs, l1_norm=l1, derivative=True,
+                              rpadded=bool(rng.random() < 0.2))
+                    desc = f'cwt {dtype} {fam} {kw}'
+                    a = R.cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
+                    b = S.cwt(x, S.Wavelet((fam, {'dtype': dtype})), **kw)
+                    ok = (np.array_equal(np_(b[1]), a[1]) and relmax(np_(b[0]), a[0]) <= tol
+                          and relmax(np_(b[2]), a[2]) <= tol)
+                    info = 'eW %.1e eD %.1e' % (relmax(np_(b[0]), a[0]), relmax(np_(b[2]), a[2]))
+                elif kind == 'ssq_cwt':
+                    kw = dict(scales=st, nv=nv, padtype=pad, fs=fs,
+                              squeezing=str(rng.choice(['sum', 'lebesgue', 'abs'])),
+                              maprange=str(rng.choice(['peak', 'maximal', 'energy'])),
+                              flipud=bool(rng.random() < 0.7),
+                              preserve_transform=bool(rng.random() < 0.5))
+                    if rng.random() < 0.3:
+                        kw['gamma'] = float(rng.choice([1e-3, 1e-1]))
+                    desc = f'ssq_cwt {dtype} {fam} N={N} {kw}'
+                    a = R.ssq_cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
+                    b = S.ssq_cwt(x, S.Wavelet((fam, {'dtype': dtype})), **kw)
+                    okT, info = same_Tx(np_(b[0]), a[0], tol)
+                    ok = (okT and relmax(np_(b[1]), a[1]) <= tol and np.array_equal(np_(b[2]), a[2])
+                          and np.array_equal(np_(b[3]), a[3]))
+                elif kind == 'ssq_stft':
+                    n_fft = int(rng.choice([32, 50, 64, 128]))
+                    n_fft = min(n_fft, N // 2)
+                    kw = dict(n_fft=n_fft, hop_len=int(rng.integers(1, n_fft // 2 + 1)), fs=fs,
+                              modulated=bool(rng.random() < 0.7), padtype=pad, dtype=dtype,
+                              squeezing=str(rng.choice(['sum', 'lebesgue'])),
+                              flipud=bool(rng.random() < 0.3))
+                    if rng.random() < 0.4:
+                        kw['window'] = str(rng.choice(['hann', 'hamming', 'blackman']))
+                    desc = f'ssq_stft N={N} {kw}'
+                    a = R.ssq_stft(x, **kw)
+                    b = S.ssq_stft(x, **kw)
+                    okT, info = same_Tx(np_(b[0]), a[0], tol)
+                    ok = (okT and relmax(np_(b[1]), a[1]) <= tol and np.array_equal(np_(b[2]), a[2])
+                          and np.array_equal(np_(b[3]), a[3]))
+                elif kind == 'inverse':
+                    wa, wb = R.Wavelet((fam, {'dtype': dtype})), S.Wavelet((fam, {'dtype': dtype}))
+                    st2 = str(rng.choice(['log', 'log-piecewise']))
+                    Tx, Wx, sf, sc = R.ssq_cwt(x, wa, scales=st2, nv=nv)
+                    desc = f'inverses {dtype} {fam} {st2} nv={nv} N={N}'
+                    e1 = relmax(np_(S.issq_cwt(Tx, wb)), R.issq_cwt(Tx, wa))
+                    e2 = relmax(np_(S.icwt(Wx, wb, scales=sc, nv=nv)), R.icwt(Wx, wa, scales=sc, nv=nv))
+                    n_fft = int(min(64, N // 2))
+                    Sx = R.stft(x, n_fft=n_fft, hop_len=4, dtype=dtype)
+                    e3 = relmax(np_(S.istft(Sx, n_fft=n_fft, hop_len=4, N=N)),
+                                R.istft(Sx, n_fft=n_fft, hop_len=4, N=N))
+                    ok = max(e1, e2) <= 1e-6 and e3 <= 100 * tol
+                    info = 'issq_cwt %.1e icwt %.1e istft %.1e' % (e1, e2, e3)
+                else:
+                    wa = R.Wavelet((fam, {'dtype': dtype}))
+                    Tx, Wx, sf, sc = R.ssq_cwt(x, wa, nv=nv)
+                    Tf, scl = (Tx, sf) if rng.random() < 0.5 else (Wx, sc)
+                    kw = dict(penalty=float(rng.choice([0.5, 2.0, 20.0])), n_ridges=int(rng.integers(1, 4)),
+                              bw=int(rng.choice([2, 4, 15])))
+                    desc = f'ridges {dtype} {fam} N={N} {kw}'
+                    a = R.extract_ridges(Tf, scl, parallel=False, **kw)
+                    b = S.extract_ridges(Tf, scl, **kw)
+                    same = (a == b)
+                    ok = same.mean() >= 0.97 and same[:, 0].mean() >= 0.99
+                    info = 'identical %.4f (first ridge %.4f)' % (same.mean(), same[:, 0].mean())
+            except Exception as e:
+                # both must fail alike
+                try:
+                    ra = None
+                    if kind in ('cwt',):
+                        R.cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
+                    elif kind == 'ssq_cwt':
+                        R.ssq_cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
+                    elif kind == 'ssq_stft':
+                        R.ssq_stft(x, **kw)
+                    ok, info = False, 'ONLY OURS RAISED: %r' % (e,)
+                except Exception as e2:
+                    ok, info = True, 'both raise (%s / %s)' % (type(e).__name__, type(e2).__name__)
+            print('%3d %-8s %s | %s | %s' % (case, 'OK' if ok else 'MISMATCH', desc, info, ''), flush=True)
+            bad += not ok
+    print('%d cases, %d mismatches' % (n_cases, bad))
+    return bad
+
+
+if __name__ == '__main__':
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)
