@@ -70,6 +70,9 @@ class CwtPlan():
         desc.algo = int(algo)
         self._h = ctypes.c_void_p()
         check(self.lib.ssq_cwt_plan_create(ctypes.byref(self._h), ctypes.byref(desc)))
+        self._bank = (vals, off, lo, row_scale)     # host copy: dense rows for `backward`
+        self._psih_dev = None
+        self._pad_src = None
         self._ssq_key = None
         self.block_rows = 0
         if algo == 0 and os.environ.get('SSQ_CWT_ALGO', 'auto') != 'generic':
@@ -211,6 +214,82 @@ class CwtPlan():
         return out
 
 
+    # ---- adjoint (autograd) -------------------------------------------------------------
+    def dense_bank(self, device):
+        """(na, M) real: the rows the plan applies (band-limited, Nyquist-halved, times
+        sqrt(scale) when L2-normalised), on `device`."""
+        if self._psih_dev is None or self._psih_dev.device != device:
+            vals, off, lo, row_scale = self._bank
+            P = np.zeros((self.na, self.M), dtype=vals.dtype)
+            for a in range(self.na):
+                P[a, lo[a]:lo[a] + (off[a + 1] - off[a])] = vals[off[a]:off[a + 1]]
+            if row_scale is not None:
+                P *= row_scale[:, None]
+            self._psih_dev = torch.from_numpy(P).to(device)
+        return self._psih_dev
+
+    def pad_sources(self, device):
+        """Index of the input sample every padded position copies (-1: a zero)."""
+        if self._pad_src is None or self._pad_src.device != device:
+            if self.padtype is None:
+                src = np.arange(self.N)
+            elif self.padtype == 'zero':
+                src = np.full(self.M, -1, dtype=np.int64)
+                src[self.n1:self.n1 + self.N] = np.arange(self.N)
+            else:
+                mode = {'reflect': 'reflect', 'replicate': 'edge', 'wrap': 'wrap',
+                        'symmetric': 'symmetric'}[self.padtype]
+                src = np.pad(np.arange(self.N), (self.n1, self.n2), mode=mode)
+            self._pad_src = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int64)).to(device)
+        return self._pad_src
+
+    def adjoint(self, gW, rpadded=False):
+        """Gradient w.r.t. the real input of a real loss whose gradient w.r.t. `Wx` is `gW`
+        ((na, N) / (B, na, N), or padded width if `rpadded`): with A = unpad . ifft . diag(psih)
+        . fft . pad, ``Re(A^H gW)`` = pad^T Re ifft(sum_a psih_a fft(zero-extended gW_a)) -- the
+        double-integral inverse's kernel (`ssq_icwt2`) followed by the adjoint of the signal
+        extension."""
+        cdt, rdt = _CDT[self.dtype], _TDT[self.dtype]
+        batched = gW.ndim == 3
+        g3 = gW if batched else gW[None]
+        dev = g3.device
+        psih = self.dense_bank(dev)
+        src = self.pad_sources(dev)
+        code = F32 if self.dtype == 'float32' else F64
+        out = torch.zeros((g3.shape[0], self.N), dtype=rdt, device=dev)
+        v = torch.empty(self.M, dtype=rdt, device=dev)
+        keep = src >= 0
+        for b in range(g3.shape[0]):
+            if rpadded:
+                Gp = g3[b].to(cdt).contiguous().clone()
+            else:
+                Gp = torch.zeros((self.na, self.M), dtype=cdt, device=dev)
+                Gp[:, self.n1:self.n1 + self.N] = g3[b]
+            check(self.lib.ssq_icwt2(code, Gp.data_ptr(), psih.data_ptr(), v.data_ptr(),
+                                     self.na, self.M, algos.stream()))
+            out[b].index_add_(0, src[keep], v[keep])
+        return out if batched else out[0]
+
+
+class _CwtFunction(torch.autograd.Function):
+    """`Wx = plan(x)` with a backward through `Wx` (`dWx`, when requested, carries no
+    gradient), so that `cwt` of a tensor that requires grad is differentiable as in the
+    reference's GPU mode (examples/reconstruction.py:1-70)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, want_dWx, rpadded):
+        out = plan.execute(x.detach(), want_dWx=want_dWx, rpadded=rpadded)
+        ctx.plan, ctx.rpadded = plan, rpadded
+        if want_dWx:
+            ctx.mark_non_differentiable(out['dWx'])
+            return out['Wx'], out['dWx']
+        return out['Wx']
+
+    @staticmethod
+    def backward(ctx, gW, *unused):
+        return ctx.plan.adjoint(gW, ctx.rpadded), None, None, None
+
+
 _PLAN_CACHE = {}
 _PLAN_CACHE_MAX = 8
 
@@ -326,9 +405,13 @@ def cwt(x, wavelet='gmw', scales='log-piecewise', fs=None, t=None, nv=32,
     xd = algos.to_device(x, _TDT[dtype])
     B = xd.shape[0] if xd.ndim == 2 else 1
     plan = get_cwt_plan(wavelet, scales, N, padtype, dt, l1_norm, B, cache=use_cache)
-    out = plan.execute(xd, want_dWx=derivative, rpadded=(rpadded and
-                                                         padtype is not None))
-    Wx, dWx = out['Wx'], out.get('dWx')
+    rp = bool(rpadded and padtype is not None)
+    if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+        res = _CwtFunction.apply(xd, plan, bool(derivative), rp)
+        Wx, dWx = res if derivative else (res, None)
+    else:
+        out = plan.execute(xd, want_dWx=derivative, rpadded=rp)
+        Wx, dWx = out['Wx'], out.get('dWx')
     scales = scales.squeeze()
     if not astensor:
         Wx = Wx.cpu().numpy()

@@ -427,3 +427,53 @@ def test_higher_order_gmw_vs_reference(S, orc, dtype):
         assert np.abs(Tx.sum(0) - ref.sum(0)).max() <= 20 * tol * np.abs(ref.sum(0)).max()
     with pytest.raises(ValueError):
         S.cwt(x, 'morlet', order=1)
+
+
+@pytest.mark.parametrize('dtype,padtype,l1_norm', [('float64', 'reflect', True), ('float64', 'zero', False),
+                                                  ('float64', 'wrap', True), ('float32', 'symmetric', True)])
+def test_cwt_is_differentiable(S, dtype, padtype, l1_norm):
+    """`cwt` of a tensor that requires grad (examples/reconstruction.py:1-70: gradient-based
+    scalogram inversion): the custom backward (adjoint of the plan) against torch.autograd
+    through a plain torch.fft statement of the same transform."""
+    import torch
+    from ssqueezepy_amd import _cwt
+    dev = 'cpu' if __import__('os').environ.get('SSQ_EMULATE') == '1' else 'cuda'
+    N, B = 300, 2
+    rng = np.random.default_rng(3)
+    tdt = torch.float64 if dtype == 'float64' else torch.float32
+    wav = S.Wavelet(('gmw' if l1_norm else 'morlet', {'dtype': dtype}))
+    x0 = torch.as_tensor(np.stack([two_chirps(N, 1), two_chirps(N, 2)]), dtype=tdt, device=dev)
+    wgt = torch.as_tensor(rng.random((B, 1, N)) + 0.5, dtype=tdt, device=dev)
+    _cwt.clear_plan_cache()
+
+    x = x0.clone().requires_grad_(True)
+    Wx, scales = S.cwt(x, wav, nv=8, padtype=padtype, l1_norm=l1_norm)
+    assert Wx.requires_grad
+    loss = (torch.abs(Wx)**2 * wgt).sum() + (Wx.real * wgt).sum()
+    loss.backward()
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+
+    # the same linear map with torch ops
+    psih = plan.dense_bank(x0.device)
+    src = plan.pad_sources(x0.device)
+    xr = x0.clone().requires_grad_(True)
+    xp = torch.where(src >= 0, xr[:, src.clamp(min=0)], torch.zeros((), dtype=tdt, device=dev))
+    Wr = torch.fft.ifft(psih[None] * torch.fft.fft(xp, dim=-1)[:, None], dim=-1)
+    Wr = Wr[..., plan.n1:plan.n1 + N]
+    tol = 1e-5 if dtype == 'float32' else 1e-12
+    assert relmax(_np(Wx.detach()), _np(Wr.detach())) <= tol
+    lr = (torch.abs(Wr)**2 * wgt).sum() + (Wr.real * wgt).sum()
+    lr.backward()
+    assert relmax(_np(x.grad), _np(xr.grad)) <= 20 * tol
+    # a 1-D signal, and no gradient bookkeeping when it is not asked for
+    x1 = x0[0].clone().requires_grad_(True)
+    W1, _ = S.cwt(x1, wav, nv=8, padtype=padtype, l1_norm=l1_norm)
+    (torch.abs(W1)**2 * wgt[0]).sum().backward()
+    xr1 = x0[0].clone().requires_grad_(True)
+    xp1 = torch.where(src >= 0, xr1[src.clamp(min=0)], torch.zeros((), dtype=tdt, device=dev))
+    Wr1 = torch.fft.ifft(psih * torch.fft.fft(xp1)[None], dim=-1)[:, plan.n1:plan.n1 + N]
+    (torch.abs(Wr1)**2 * wgt[0]).sum().backward()
+    assert relmax(_np(x1.grad), _np(xr1.grad)) <= 20 * tol
+    with torch.no_grad():
+        assert not S.cwt(x1, wav, nv=8, padtype=padtype, l1_norm=l1_norm)[0].requires_grad
+    _cwt.clear_plan_cache()

@@ -93,3 +93,12 @@ def test_inverses_vs_reference(S):
     TI.test_trigdiff_vs_reference(S, 'float64')
     TI.test_phase_ssqueeze_vs_reference(S, 'float32')
     TI.test_phase_ssqueeze_vs_reference(S, 'float64')
+
+
+def test_cwt_autograd(S, monkeypatch):
+    """`cwt` is differentiable (tests/test_gpu_transforms.py::test_cwt_is_differentiable): the
+    adjoint of the plan against torch.autograd through a torch.fft statement of the transform."""
+    from test_gpu_transforms import test_cwt_is_differentiable
+    monkeypatch.setenv('SSQ_EMULATE', '1')        # the test places its tensors accordingly
+    test_cwt_is_differentiable(S, 'float64', 'reflect', True)
+    test_cwt_is_differentiable(S, 'float32', 'zero', False)
