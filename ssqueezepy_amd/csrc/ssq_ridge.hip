@@ -23,16 +23,30 @@
 namespace ssq {
 
 // -------------------------------------------------------------------- elementwise
+// correctly rounded (clang's default for HIP: v_sqrt_f32 plus the +-1 ulp fix-up; the
+// `__fsqrt_rn` intrinsic lowers to the bare 1-ulp instruction)
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_rn(double x) { return sqrt(x); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return fma(a, b, c); }
+
 template <typename T, bool CPLX>
 __global__ __launch_bounds__(256) void ridge_energy_kernel(const T* __restrict__ Tf, T* __restrict__ en,
                                                            int64_t total) {
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
         T a;
         if (CPLX) {
-            const T re = Tf[2 * q], im = Tf[2 * q + 1];
-            // |z| as glibc's hypotf forms it (double sqrt of the exact sum, rounded once more)
-            if (sizeof(T) == 4) a = (T)sqrt((double)re * (double)re + (double)im * (double)im);
-            else a = (T)hypot((double)re, (double)im);
+            // |z| as NumPy's complex `absolute` loop forms it: m * sqrt(fma(r, r, 1)) with
+            // m = max(|re|, |im|), r = min / max (verified bit for bit against np.abs on 10^6
+            // complex64 / complex128 values). Energies the reference finds exactly equal stay
+            // exactly equal here, which is what its `< eps` tie tests in the tracking see.
+            const T re = fabs(Tf[2 * q]), im = fabs(Tf[2 * q + 1]);
+            const T m = re > im ? re : im, n = re > im ? im : re;
+            a = m;
+            if (m > T(0) && !isinf(m)) {
+                const T r = n / m;
+                a = m * sqrt_rn(fma_(r, r, T(1)));
+            }
         } else {
             a = fabs(Tf[q]);
         }

@@ -53,6 +53,7 @@ def test_emulated_kernels_vs_oracle(emu, orc, cdtype, na, n, transform):
     en_ref = np.abs(Tf)**2
     tol = 1e-6 if rdt == np.float32 else 1e-13
     assert np.abs(en - en_ref).max() <= tol * np.abs(en_ref).max()
+    assert np.array_equal(en, en_ref)      # NumPy's |z| formula: m * sqrt(fma(r, r, 1)), then squared
     ridge_ref, pe_ref = orc.ridge_track(E, P.reshape(na, na), eps)
     assert np.array_equal(pe, pe_ref)
     assert np.array_equal(ridge, ridge_ref)

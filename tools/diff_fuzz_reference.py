@@ -24,7 +24,7 @@ from conftest import two_chirps
 
 def relmax(a, b):
     b = np.asarray(b)
-    return np.abs(np.asarray(a) - b).max() / max(np.abs(b).max(), 1e-300)
+    return float(np.abs(np.asarray(a) - b).max()) / max(float(np.abs(b).max()), 1e-300)
 
 
 def np_(t):
@@ -33,9 +33,13 @@ def np_(t):
 
 def same_Tx(Tx, ref, tol):
     cs, cr = Tx.sum(-2), ref.sum(-2)
-    e = np.abs(cs - cr).max() / max(np.abs(cr).max(), 1e-300)
+    e = float(np.abs(cs - cr).max()) / max(float(np.abs(cr).max()), 1e-300)
     frac = (np.abs(Tx - ref) > 1e-5 * np.abs(ref).max()).mean()
-    return e <= 100 * tol and frac <= 1e-2, 'colsum %.1e differ %.1e' % (e, frac)
+    extra = ''
+    if not np.isfinite(e):
+        extra = ' [nan ours %d ref %d, inf ours %d ref %d]' % (np.isnan(Tx).sum(), np.isnan(ref).sum(),
+                                                           np.isinf(Tx).sum(), np.isinf(ref).sum())
+    return e <= 100 * tol and frac <= 1e-2, 'colsum %.1e differ %.1e%s' % (e, frac, extra)
 
 
 def main(n_cases=40, seed=0):
@@ -120,18 +124,24 @@ def main(n_cases=40, seed=0):
                     ok = same.mean() >= 0.97 and same[:, 0].mean() >= 0.99
                     info = 'identical %.4f (first ridge %.4f)' % (same.mean(), same[:, 0].mean())
             except Exception as e:
-                # both must fail alike
-                try:
-                    ra = None
-                    if kind in ('cwt',):
-                        R.cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
-                    elif kind == 'ssq_cwt':
-                        R.ssq_cwt(x, R.Wavelet((fam, {'dtype': dtype})), **kw)
-                    elif kind == 'ssq_stft':
-                        R.ssq_stft(x, **kw)
+                # a failing call must fail on both sides (in every branch the reference runs first)
+                import traceback
+                ours = any('ssqueezepy_amd' in f.filename for f in traceback.extract_tb(e.__traceback__))
+                if not ours:
+                    if kind in ('inverse', 'ridges'):
+                        ok, info = True, 'reference raised while preparing inputs (%s): skipped' % type(e).__name__
+                    else:
+                        try:
+                            fn = {'cwt': S.cwt, 'ssq_cwt': S.ssq_cwt}.get(kind)
+                            if fn is not None:
+                                fn(x, S.Wavelet((fam, {'dtype': dtype})), **kw)
+                            else:
+                                S.ssq_stft(x, **kw)
+                            ok, info = False, 'ONLY THE REFERENCE RAISED: %r' % (e,)
+                        except Exception as e2:
+                            ok, info = True, 'both raise (%s / %s)' % (type(e).__name__, type(e2).__name__)
+                else:
                     ok, info = False, 'ONLY OURS RAISED: %r' % (e,)
-                except Exception as e2:
-                    ok, info = True, 'both raise (%s / %s)' % (type(e).__name__, type(e2).__name__)
             print('%3d %-8s %s | %s | %s' % (case, 'OK' if ok else 'MISMATCH', desc, info, ''), flush=True)
             bad += not ok
     print('%d cases, %d mismatches' % (n_cases, bad))
