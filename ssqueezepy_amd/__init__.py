@@ -3,7 +3,8 @@
 
 Drop-in for the transform path of ssqueezepy (`cwt`, `stft`, `ssq_cwt`, `ssq_stft`,
 `ssqueeze`, `phase_cwt`, `phase_stft`, their inverses `icwt`, `issq_cwt`, `istft`,
-`issq_stft`, `extract_ridges`, `Wavelet` and the scale-design utilities): same Python API, computed by hand-written HIP kernels (gfx950) behind a
+`issq_stft`, `extract_ridges`, `trigdiff`, `phase_ssqueeze`, `Wavelet` and the scale-design
+utilities): same Python API, computed by hand-written HIP kernels (gfx950) behind a
 C ABI (include/ssq_hip.h, libssq_hip.so). The design step (scales, filter bank,
 frequency grid, windows) is host NumPy and value-exact with the reference; all
 O(na * N) work is on the GPU and there is no CPU fallback.
