@@ -7,10 +7,10 @@ tests/golden/ridges.npz.
 The forward / backward recurrences are index work on rounded sums: compared bit for bit on
 the same negative-log energy (the device's). The energy and its logarithm are floating
 point: 1e-6 / 1e-13 relative (float32 / float64). End to end against the reference's
-indices the only difference left is the last bit of `log`, which can move a weak
-ridge at isolated columns (synchrosqueezed transforms are mostly exact zeros, i.e. ties):
-at least 99 % of the indices identical (measured: 8 of 9 cases identical, the second ridge
-of the float32 ssq_cwt case differs at 2 of 384 columns)."""
+indices: float32 energies and logarithms follow NumPy's operation order (IEEE-exact), the
+float64 logarithm is the device's and its last bit can move a weak ridge at isolated columns
+(synchrosqueezed transforms are mostly exact zeros, i.e. ties): at least 99 % of the indices
+identical, the dominant ridge identical."""
 import os
 import numpy as np
 import pytest

@@ -54,6 +54,8 @@ def test_emulated_kernels_vs_oracle(emu, orc, cdtype, na, n, transform):
     tol = 1e-6 if rdt == np.float32 else 1e-13
     assert np.abs(en - en_ref).max() <= tol * np.abs(en_ref).max()
     assert np.array_equal(en, en_ref)      # NumPy's |z| formula: m * sqrt(fma(r, r, 1)), then squared
+    if rdt == np.float32:                  # NumPy's float32 log, operation for operation
+        assert np.array_equal(E, -np.log(en_ref / en_ref.max(axis=0) + eps))
     ridge_ref, pe_ref = orc.ridge_track(E, P.reshape(na, na), eps)
     assert np.array_equal(pe, pe_ref)
     assert np.array_equal(ridge, ridge_ref)
