@@ -77,3 +77,55 @@ def test_two_rank_sharded_batch_matches_single_process():
         r = oracle_ssq_cwt(orc, two_chirps(256, seed=s), 'float32', scales='log', nv=8)
         ref.append([np.abs(r['Tx']).sum(dtype=np.float64), np.abs(r['Wx']).sum(dtype=np.float64)])
     assert np.allclose(got[0][1], np.array(ref), rtol=1e-6)
+
+
+def _worker_emulated(rank, world, port, q):
+    """As `_worker`, but every rank runs the product itself -- `ssq_cwt` on its shard of the
+    batch through the kernels under the CPU emulator (tests/emu_backend.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['SSQ_EMU_THREADS'] = '2'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import emu_backend
+    from conftest import two_chirps
+    from ssqueezepy_amd.sharding import gather_summaries, signal_summary
+    B, N = 5, 256
+    x = np.stack([two_chirps(N, seed=s) for s in range(B)]).astype(np.float32)
+    mine = shard_signals(x, world, rank)
+    with emu_backend.emulated() as S:
+        Tx, Wx, *_ = S.ssq_cwt(np.ascontiguousarray(mine), S.Wavelet(), scales='log', nv=8)
+        table = gather_summaries(signal_summary(Tx, Wx), B)
+    q.put((rank, table.numpy(), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_batch_through_the_emulated_kernels():
+    import emu_backend
+    if not emu_backend.available():
+        pytest.skip("no clang++ under $ROCM_PATH/lib/llvm/bin")
+    emu_backend.build()
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_emulated, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    assert [g[2] for g in got] == [3, 2]
+    assert np.array_equal(got[0][1], got[1][1])
+    from conftest import two_chirps
+    from pipeline import oracle_ssq_cwt
+    from oracle import oracle as orc
+    ref = []
+    for s in range(5):
+        r = oracle_ssq_cwt(orc, two_chirps(256, seed=s), 'float32', scales='log', nv=8)
+        ref.append([np.abs(r['Tx']).sum(dtype=np.float64), np.abs(r['Wx']).sum(dtype=np.float64)])
+    assert np.allclose(got[0][1], np.array(ref), rtol=1e-5)
