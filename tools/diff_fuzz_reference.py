@@ -113,7 +113,8 @@ def main(n_cases=40, seed=0):
                     info = 'issq_cwt %.1e icwt %.1e istft %.1e' % (e1, e2, e3)
                 elif kind == 'extras':
                     wa, wb = R.Wavelet(('gmw', {'dtype': dtype})), S.Wavelet(('gmw', {'dtype': dtype}))
-                    sub = str(rng.choice(['batch_w', 'hiorder', 'trigdiff', 'phase_ssq', 'tvec']))
+                    sub = str(rng.choice(['batch_w', 'hiorder', 'trigdiff', 'phase_ssq', 'tvec', 'stft_opts',
+                                          'components', 'icwt_opts']))
                     desc = f'extras/{sub} {dtype} N={N} nv={nv}'
                     if sub == 'batch_w':          # batched input; get_w / get_dWx outputs
                         xb = np.stack([x, x[::-1].copy()])
@@ -147,6 +148,49 @@ def main(n_cases=40, seed=0):
                                              difftype='trig', get_w=(a[5] is not None), transform='cwt')
                         okT, info = same_Tx(np_(b[0]), a[0], tol)
                         ok = okT and np.array_equal(np_(b[2]), a[2])
+                    elif sub == 'stft_opts':      # win_len < n_fft, window arrays, get_w, no padding
+                        n_fft = int(rng.choice([32, 64, 96]))
+                        n_fft = min(n_fft, N // 2)
+                        kw2 = dict(n_fft=n_fft, win_len=int(rng.integers(n_fft // 2, n_fft + 1)),
+                                   hop_len=int(rng.integers(1, 9)), dtype=dtype,
+                                   modulated=bool(rng.random() < 0.5))
+                        if rng.random() < 0.4:
+                            kw2['window'] = np.hanning(kw2['win_len']).astype(dtype)
+                        a = R.ssq_stft(x, get_w=True, get_dWx=True, **kw2)
+                        b = S.ssq_stft(x, get_w=True, get_dWx=True, **kw2)
+                        okT, info = same_Tx(np_(b[0]), a[0], tol)
+                        wr, wo = a[4], np_(b[4])
+                        fin = np.isfinite(wr) & np.isfinite(wo)
+                        ok = (okT and relmax(np_(b[1]), a[1]) <= tol and relmax(np_(b[5]), a[5]) <= tol
+                              and (np.isfinite(wr) == np.isfinite(wo)).mean() > 0.999
+                              and np.array_equal(np_(b[2]), a[2]))
+                        desc += ' %s' % {k: v for k, v in kw2.items() if k != 'window'}
+                    elif sub == 'components':     # component inversion around curves
+                        Tx, Wx, sf, sc = R.ssq_cwt(x, wa, nv=nv)
+                        na = len(Tx)
+                        K = int(rng.integers(1, 3))
+                        cc = np.stack([np.clip((na * (0.3 + 0.4 * k / K) + 3 * np.sin(np.arange(N) / 20)), 0, na - 1)
+                                       for k in range(K)], axis=1).astype(int)
+                        cw = np.full((N, K), int(rng.integers(1, 6)))
+                        a = R.issq_cwt(Tx, wa, cc, cw); b = S.issq_cwt(Tx, wb, cc, cw)
+                        e1 = relmax(np_(b), a)
+                        Ts, Sx, sfs, Sfs = R.ssq_stft(x, n_fft=64, dtype=dtype)
+                        ns = len(Ts)
+                        cc2 = np.full((N, 1), ns // 3); cw2 = np.full((N, 1), 4)
+                        e2 = relmax(np_(S.issq_stft(Ts, cc=cc2, cw=cw2, n_fft=64)), R.issq_stft(Ts, cc=cc2, cw=cw2, n_fft=64))
+                        ok = e1 <= 1e-6 and e2 <= 1e-6
+                        info = 'issq_cwt comps %.1e issq_stft comps %.1e' % (e1, e2)
+                    elif sub == 'icwt_opts':      # double integral, x_mean, L2 norm, padded input
+                        st2 = str(rng.choice(['log', 'log-piecewise', 'linear']))
+                        Wx, sc = R.cwt(x, wa, scales=st2, nv=nv)
+                        xm = float(x.mean())
+                        e1 = relmax(np_(S.icwt(Wx, wb, scales=sc, nv=nv, one_int=False, x_len=N, x_mean=xm)),
+                                    R.icwt(Wx, wa, scales=sc, nv=nv, one_int=False, x_len=N, x_mean=xm))
+                        Wp, _ = R.cwt(x, wa, scales=st2, nv=nv, rpadded=True)
+                        e2 = relmax(np_(S.icwt(Wp, wb, scales=sc, nv=nv, x_len=N, rpadded=True, x_mean=xm)),
+                                    R.icwt(Wp, wa, scales=sc, nv=nv, x_len=N, rpadded=True, x_mean=xm))
+                        ok = e1 <= 100 * tol and e2 <= 1e-6
+                        info = '%s icwt2 %.1e icwt(rpadded) %.1e' % (st2, e1, e2)
                     else:                         # non-uniformly scaled time vector instead of fs
                         tv = np.linspace(0., N / fs, N, endpoint=False)
                         a = R.ssq_cwt(x, wa, nv=nv, t=tv); b = S.ssq_cwt(x, wb, nv=nv, t=tv)
