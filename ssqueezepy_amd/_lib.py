@@ -7,7 +7,7 @@ when the in-tree .so is missing (hipcc is part of the ROCm image).
 """
 import ctypes
 import os
-from ctypes import (c_int, c_int32, c_int64, c_double, c_void_p, c_char_p, POINTER,
+from ctypes import (c_int, c_int64, c_double, c_void_p, c_char_p, POINTER,
                     Structure)
 
 HERE = os.path.dirname(os.path.abspath(__file__))

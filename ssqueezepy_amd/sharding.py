@@ -11,7 +11,6 @@ sharded -- the full `Tx` + `Wx` of BASELINE config 4 (512 x 768 MB = 393 GB) fit
 no single GPU. The one collective is an `all_gather` of small per-signal summaries
 (RCCL over xGMI with the 'nccl' backend; 'gloo' in the CPU tests).
 """
-import numpy as np
 
 __all__ = ['shard_bounds', 'shard_signals', 'gather_summaries', 'signal_summary']
 
