@@ -159,6 +159,7 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         const char* e = getenv("SSQ_EMU_ORDER");
         return !e ? 0 : (strcmp(e, "reverse") == 0 ? 1 : (strcmp(e, "shuffle") == 0 ? 2 : 0));
     }();
+    static const bool lanes_reversed = [] { const char* e = getenv("SSQ_EMU_LANES"); return e && strcmp(e, "reverse") == 0; }();
     std::vector<unsigned> order(nw);
     unsigned long long rng = 0x9E3779B97F4A7C15ull ^ ((unsigned long long)bidx.x * 7919u + bidx.y);
     for (;;) {                               // one iteration = one __syncthreads phase
@@ -174,7 +175,10 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
             const unsigned lo = wv * 64, hi = std::min(nt, lo + 64);
             for (;;) {                       // sweep the wave until it reaches a block barrier
                 bool at_wave = false, other = false;
-                for (unsigned t = lo; t < hi; ++t) {
+                for (unsigned i = lo; i < hi; ++i) {
+                    // SSQ_EMU_LANES=reverse: the lanes of a wavefront in descending order (code
+                    // that is correct only in lockstep, without a wave_barrier, shows up)
+                    const unsigned t = lanes_reversed ? hi - 1 - (i - lo) : i;
                     Fiber& f = w.fibers[t];
                     if (f.wait == FINISHED || f.wait == AT_BLOCK) continue;
                     resume(w, f);            // RUNNABLE or AT_WAVE: run to its next yield
