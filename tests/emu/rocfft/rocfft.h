@@ -6,6 +6,7 @@
 #include <cmath>
 #include <complex>
 #include <cstddef>
+#include <cstdlib>
 #include <vector>
 
 typedef enum { rocfft_status_success = 0, rocfft_status_failure = 1 } rocfft_status;
@@ -71,12 +72,14 @@ inline rocfft_status rocfft_execution_info_set_work_buffer(rocfft_execution_info
 inline rocfft_status rocfft_execution_info_set_stream(rocfft_execution_info, void*) { return rocfft_status_success; }
 
 namespace emu_fft {
-typedef std::complex<double> cd;
-// unnormalised DFT, sign = -1 forward / +1 inverse; radix-2 when n is a power of two, else direct
-inline void dft(std::vector<cd>& a, int sign) {
+// unnormalised DFT in working precision W, sign = -1 forward / +1 inverse; radix-2 when n is a
+// power of two, else direct
+template <typename W>
+inline void dft(std::vector<std::complex<W>>& a, int sign) {
+    typedef std::complex<W> cd;
     const size_t n = a.size();
     if (n <= 1) return;
-    const double PI = 3.141592653589793238462643383279502884;
+    const W PI = (W)3.141592653589793238462643383279502884L;
     if ((n & (n - 1)) == 0) {
         for (size_t i = 1, j = 0; i < n; ++i) {
             size_t bit = n >> 1;
@@ -87,7 +90,7 @@ inline void dft(std::vector<cd>& a, int sign) {
         for (size_t len = 2; len <= n; len <<= 1) {
             std::vector<cd> w(len / 2);
             for (size_t k = 0; k < len / 2; ++k) {
-                const double ang = sign * 2.0 * PI * (double)k / (double)len;
+                const W ang = sign * (W)2 * PI * (W)k / (W)len;
                 w[k] = cd(std::cos(ang), std::sin(ang));
             }
             for (size_t i = 0; i < n; i += len)
@@ -101,7 +104,7 @@ inline void dft(std::vector<cd>& a, int sign) {
         for (size_t k = 0; k < n; ++k) {
             cd s = 0;
             for (size_t t = 0; t < n; ++t) {
-                const double ang = sign * 2.0 * PI * (double)((k * t) % n) / (double)n;
+                const W ang = sign * (W)2 * PI * (W)((k * t) % n) / (W)n;
                 s += a[t] * cd(std::cos(ang), std::sin(ang));
             }
             out[k] = s;
@@ -109,39 +112,42 @@ inline void dft(std::vector<cd>& a, int sign) {
         a.swap(out);
     }
 }
-template <typename R>
+// R: data precision; W: working precision (double by default; SSQ_EMU_FFT32=1 computes float32
+// plans in float32, so that tolerances are exercised at rocFFT-like accuracy)
+template <typename R, typename W>
 void run(rocfft_plan p, void* in, void* out) {
+    typedef std::complex<W> cd;
     const size_t n = p->n, h = n / 2 + 1;
     const auto& d = p->d;
     std::vector<cd> a(n);
     for (size_t b = 0; b < p->batch; ++b) {
         if (p->type == rocfft_transform_type_real_forward) {
             const R* x = (const R*)in + b * d.in_dist;
-            for (size_t t = 0; t < n; ++t) a[t] = cd((double)x[t * d.in_stride], 0.0);
+            for (size_t t = 0; t < n; ++t) a[t] = cd((W)x[t * d.in_stride], (W)0);
             dft(a, -1);
             R* y = (R*)out + 2 * b * d.out_dist;
             for (size_t k = 0; k < h; ++k) {
-                y[2 * k * d.out_stride] = (R)(a[k].real() * d.scale);
-                y[2 * k * d.out_stride + 1] = (R)(a[k].imag() * d.scale);
+                y[2 * k * d.out_stride] = (R)(a[k].real() * (W)d.scale);
+                y[2 * k * d.out_stride + 1] = (R)(a[k].imag() * (W)d.scale);
             }
         } else if (p->type == rocfft_transform_type_real_inverse) {
             const R* x = (const R*)in + 2 * b * d.in_dist;
-            for (size_t k = 0; k < h; ++k) a[k] = cd((double)x[2 * k * d.in_stride], (double)x[2 * k * d.in_stride + 1]);
+            for (size_t k = 0; k < h; ++k) a[k] = cd((W)x[2 * k * d.in_stride], (W)x[2 * k * d.in_stride + 1]);
             for (size_t k = h; k < n; ++k) a[k] = std::conj(a[n - k]);
-            a[0] = cd(a[0].real(), 0.0);
-            if (n % 2 == 0) a[n / 2] = cd(a[n / 2].real(), 0.0);
+            a[0] = cd(a[0].real(), (W)0);
+            if (n % 2 == 0) a[n / 2] = cd(a[n / 2].real(), (W)0);
             dft(a, +1);
             R* y = (R*)out + b * d.out_dist;
-            for (size_t t = 0; t < n; ++t) y[t * d.out_stride] = (R)(a[t].real() * d.scale);
+            for (size_t t = 0; t < n; ++t) y[t * d.out_stride] = (R)(a[t].real() * (W)d.scale);
         } else {
             const int sign = p->type == rocfft_transform_type_complex_forward ? -1 : +1;
             const R* x = (const R*)in + 2 * b * d.in_dist;
-            for (size_t t = 0; t < n; ++t) a[t] = cd((double)x[2 * t * d.in_stride], (double)x[2 * t * d.in_stride + 1]);
+            for (size_t t = 0; t < n; ++t) a[t] = cd((W)x[2 * t * d.in_stride], (W)x[2 * t * d.in_stride + 1]);
             dft(a, sign);
             R* y = (R*)(p->place == rocfft_placement_inplace ? in : out) + 2 * b * d.out_dist;
             for (size_t t = 0; t < n; ++t) {
-                y[2 * t * d.out_stride] = (R)(a[t].real() * d.scale);
-                y[2 * t * d.out_stride + 1] = (R)(a[t].imag() * d.scale);
+                y[2 * t * d.out_stride] = (R)(a[t].real() * (W)d.scale);
+                y[2 * t * d.out_stride + 1] = (R)(a[t].imag() * (W)d.scale);
             }
         }
     }
@@ -150,7 +156,12 @@ void run(rocfft_plan p, void* in, void* out) {
 
 inline rocfft_status rocfft_execute(rocfft_plan p, void** in, void** out, rocfft_execution_info) {
     void* o = out ? out[0] : nullptr;
-    if (p->prec == rocfft_precision_single) emu_fft::run<float>(p, in[0], o);
-    else emu_fft::run<double>(p, in[0], o);
+    static const bool fft32 = getenv("SSQ_EMU_FFT32") != nullptr;
+    if (p->prec == rocfft_precision_single) {
+        if (fft32) emu_fft::run<float, float>(p, in[0], o);
+        else emu_fft::run<float, double>(p, in[0], o);
+    } else {
+        emu_fft::run<double, double>(p, in[0], o);
+    }
     return rocfft_status_success;
 }

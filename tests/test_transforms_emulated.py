@@ -83,7 +83,7 @@ def test_stft_paths_vs_reference(S, orc):
     test_ssq_stft_vs_reference(S, orc, 'float32')
 
 
-def test_inverses_vs_reference(S):
+def test_inverses_vs_reference(S, orc):
     """icwt / issq_cwt / istft / issq_stft / trigdiff (tests/test_gpu_inverse.py) under the
     emulator."""
     import test_gpu_inverse as TI
@@ -91,8 +91,8 @@ def test_inverses_vs_reference(S):
     TI.test_istft_and_issq_stft(S, 'float64')
     TI.test_trigdiff_vs_reference(S, 'float32')
     TI.test_trigdiff_vs_reference(S, 'float64')
-    TI.test_phase_ssqueeze_vs_reference(S, 'float32')
-    TI.test_phase_ssqueeze_vs_reference(S, 'float64')
+    TI.test_phase_ssqueeze_vs_reference(S, orc, 'float32')
+    TI.test_phase_ssqueeze_vs_reference(S, orc, 'float64')
 
 
 def test_cwt_autograd(S, monkeypatch):
