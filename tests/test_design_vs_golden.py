@@ -165,3 +165,18 @@ def test_scale_frequency_conversions():
         assert np.array_equal(freq_to_scale(fr, wav, 1024), g[f'f2s/{name}/peak'])
         assert np.array_equal(freq_to_scale(fr * 4, wav, 1024, fs=4, kind='energy',
                                             n_search_scales=100, base=3), g[f'f2s/{name}/energy'])
+
+
+def test_admissibility_and_bounds_sweeps():
+    """The reference's own stability sweeps of the host design code: admissibility constants
+    stay away from zero over mu in [4, 30] for every family (tests/adm_coef_test.py, 1e-3), and
+    `cwt_scalebounds` runs for N = 64 ... 4096 (tests/misc_test.py:13-20)."""
+    from ssqueezepy_amd import Wavelet, adm_cwt, adm_ssq, cwt_scalebounds
+    for fam in ('morlet', 'bump', 'cmhat', 'hhhat'):
+        for mu in np.linspace(4, 30, 40):
+            wav = (fam, {'mu': mu})
+            assert adm_cwt(wav) > 1e-3 and adm_ssq(wav) > 1e-3, (fam, mu)
+    wavelet = Wavelet(('morlet', {'mu': 6}))
+    for N in (4096, 2048, 1024, 512, 256, 128, 64):
+        smin, smax = cwt_scalebounds(wavelet, N=N)
+        assert 0 < smin < smax
