@@ -265,9 +265,30 @@ inline double __hiloint2double(int hi, int lo) {
 }
 
 // ------------------------------------------------------------------ launch
+namespace ssq { extern thread_local unsigned char lds_raw[], smem[]; }   // emu_globals.cpp
+namespace emu {
+constexpr size_t DYN_LDS_BYTES = 160 * 1024;
+// SSQ_EMU_LDSGUARD=1: the part of the dynamic LDS buffers beyond what the launch asked for is
+// filled with a pattern before every workgroup and checked after it (out-of-bounds writes)
+inline void lds_guard(size_t asked, bool check, dim3 b) {
+    for (unsigned char* buf : {ssq::lds_raw, ssq::smem}) {
+        if (!check) { memset(buf + asked, 0xA5, DYN_LDS_BYTES - asked); continue; }
+        for (size_t i = asked; i < DYN_LDS_BYTES; ++i)
+            if (buf[i] != 0xA5) {
+                fprintf(stderr, "emu: workgroup (%u,%u,%u) wrote dynamic LDS at byte %zu, beyond the %zu "
+                        "bytes of its launch\n", b.x, b.y, b.z, i, asked);
+                abort();
+            }
+    }
+}
+}  // namespace emu
+
 template <typename K, typename... Args>
-void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
-    const std::function<void()> body = [=] { kernel(args...); };
+void emu_launch(K kernel, dim3 grid, dim3 block, size_t dyn_lds, Args... args) {
+    static const bool guard = getenv("SSQ_EMU_LDSGUARD") != nullptr;
+    if (dyn_lds > emu::DYN_LDS_BYTES) { fprintf(stderr, "emu: %zu bytes of dynamic LDS requested\n", dyn_lds); abort(); }
+    const std::function<void()> kbody = [=] { kernel(args...); };
+    const std::function<void()>& body = kbody;
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     std::atomic<size_t> next{0};
     auto work = [&] {
@@ -276,7 +297,9 @@ void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
             if (b >= nblocks) return;
             const unsigned bx = (unsigned)(b % grid.x), by = (unsigned)((b / grid.x) % grid.y),
                            bz = (unsigned)(b / ((size_t)grid.x * grid.y));
+            if (guard) emu::lds_guard(dyn_lds, false, dim3(bx, by, bz));
             emu::run_block(body, dim3(bx, by, bz), block, grid);
+            if (guard) emu::lds_guard(dyn_lds, true, dim3(bx, by, bz));
         }
     };
     static const unsigned ncpu = [] {
@@ -292,4 +315,4 @@ void emu_launch(K kernel, dim3 grid, dim3 block, Args... args) {
 }
 // (kernel), grid, block, dynamic LDS bytes, stream, args...
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    emu_launch(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+    emu_launch(kernel, dim3(grid), dim3(block), (size_t)(lds), __VA_ARGS__)
