@@ -50,6 +50,8 @@ def main(n_cases=40, seed=0):
             dtype = str(rng.choice(['float32', 'float64']))
             tol = 1e-5 if dtype == 'float32' else 1e-11
             kind = rng.choice(['ssq_cwt', 'cwt', 'ssq_stft', 'inverse', 'ridges', 'extras'])
+            if os.environ.get('FUZZ_KIND'):           # e.g. FUZZ_KIND=extras/opts2
+                kind = os.environ['FUZZ_KIND'].split('/')[0]
             N = int(rng.integers(64, 400))
             x = two_chirps(N, seed=case + 1000 * seed)
             fam = str(rng.choice(['gmw', 'morlet', 'bump', 'cmhat', 'hhhat']))
@@ -114,7 +116,9 @@ def main(n_cases=40, seed=0):
                 elif kind == 'extras':
                     wa, wb = R.Wavelet(('gmw', {'dtype': dtype})), S.Wavelet(('gmw', {'dtype': dtype}))
                     sub = str(rng.choice(['batch_w', 'hiorder', 'trigdiff', 'phase_ssq', 'tvec', 'stft_opts',
-                                          'components', 'icwt_opts']))
+                                          'components', 'icwt_opts', 'opts2']))
+                    if '/' in os.environ.get('FUZZ_KIND', ''):
+                        sub = os.environ['FUZZ_KIND'].split('/')[1]
                     desc = f'extras/{sub} {dtype} N={N} nv={nv}'
                     if sub == 'batch_w':          # batched input; get_w / get_dWx outputs
                         xb = np.stack([x, x[::-1].copy()])
@@ -148,6 +152,33 @@ def main(n_cases=40, seed=0):
                                              difftype='trig', get_w=(a[5] is not None), transform='cwt')
                         okT, info = same_Tx(np_(b[0]), a[0], tol)
                         ok = okT and np.array_equal(np_(b[2]), a[2])
+                    elif sub == 'opts2':          # wavelet parameters, scale arrays, ssq_freqs / maprange forms
+                        wcfg = {'gmw': {'gamma': float(rng.choice([2, 3, 4])), 'beta': float(rng.choice([20, 60, 90]))},
+                                'morlet': {'mu': float(rng.choice([5, 10, 13.4]))},
+                                'bump': {'mu': float(rng.choice([4, 6])), 's': float(rng.choice([0.8, 1.2]))},
+                                'cmhat': {'mu': float(rng.choice([1, 2]))}, 'hhhat': {'mu': float(rng.choice([4, 6]))}}[fam]
+                        wcfg['dtype'] = dtype
+                        wa, wb = R.Wavelet((fam, wcfg)), S.Wavelet((fam, wcfg))
+                        kw2 = {}
+                        if rng.random() < 0.5:
+                            kw2['scales'] = (2 ** np.linspace(1, 6, int(rng.integers(10, 40)))).astype(dtype)
+                        else:
+                            kw2['scales'] = str(rng.choice(['log:maximal', 'log-piecewise:minimal', 'log']))
+                            kw2['nv'] = nv
+                        r3 = rng.random()
+                        if r3 < 0.3:
+                            kw2['ssq_freqs'] = str(rng.choice(['log', 'linear']))
+                        elif r3 < 0.5:
+                            kw2['maprange'] = (0.02 * fs, 0.4 * fs)
+                        elif r3 < 0.65:
+                            kw2['ssq_freqs'] = np.linspace(0.01 * fs, 0.45 * fs, 50)
+                        kw2['padtype'] = pad if rng.random() < 0.8 else None
+                        kw2['fs'] = fs
+                        desc += ' %s %s' % (fam, {k: (v if not isinstance(v, np.ndarray) else 'array[%d]' % len(v)) for k, v in kw2.items()})
+                        a = R.ssq_cwt(x, wa, **kw2); b = S.ssq_cwt(x, wb, **kw2)
+                        okT, info = same_Tx(np_(b[0]), a[0], tol)
+                        ok = (okT and relmax(np_(b[1]), a[1]) <= tol and np.array_equal(np_(b[2]), a[2])
+                              and np.array_equal(np_(b[3]), a[3]))
                     elif sub == 'stft_opts':      # win_len < n_fft, window arrays, get_w, no padding
                         n_fft = int(rng.choice([32, 64, 96]))
                         n_fft = min(n_fft, N // 2)
