@@ -15,58 +15,48 @@ __all__ = ['freq_to_scale', 'scale_to_freq', 'phase_ssqueeze', 'phase_transform'
 
 
 def freq_to_scale(freqs, wavelet, N, fs=1, n_search_scales=None, kind='peak', base=2):
-    """Scales whose centre frequencies (`center_frequency(kind)`) span `freqs` (ascending,
-    within [0, fs/2]), log-spaced in `base`. Approximate: searches `n_search_scales`
-    (default 10 * len(freqs)) candidate scales. Reference: experimental.py:15-85."""
-    def log(x):
-        return np.log(x) / np.log(base)
-
-    freqs = np.asarray(freqs) / fs  # unitless, [0., 0.5)
-    assert np.all(freqs >= 0),       "frequencies must be positive"
-    assert freqs.max() <= 0.5,       "max frequency must be 0.5"
-    assert freqs.max() == freqs[-1], "max frequency must be last sample"
-    assert freqs.min() == freqs[0],  "min frequency must be first sample"
-
-    M = len(freqs)
-    if n_search_scales is None:
-        n_search_scales = 10 * M
-    smin, smax = cwt_scalebounds(wavelet, N, preset='maximal', use_padded_N=False)
-    search_scales = np.logspace(log(smin), log(smax), n_search_scales, base=base)
-
-    w_from_scales = []
-    for scale in search_scales:
-        w = center_frequency(wavelet, scale, N, kind=kind)
-        w_from_scales.append(min(max(w, 0), np.pi))
-    f_from_scales = np.array(w_from_scales) / (2*np.pi)
-
-    fmin, fmax = freqs.min(), freqs.max()
-    smax = search_scales[np.argmin(np.abs(f_from_scales - fmin))]
-    smin = search_scales[np.argmin(np.abs(f_from_scales - fmax))]
-    return np.logspace(log(smax), log(smin), M, base=base)
+    """Scales whose centre frequencies (`center_frequency(kind)`) span the ascending
+    `freqs` (within [0, fs/2]), log-spaced in `base`. A search, not a closed form:
+    `n_search_scales` candidates (default 10 per frequency) between the wavelet's 'maximal'
+    scale bounds are mapped to frequencies and the two that land closest to the ends of
+    `freqs` delimit the answer. Reference: experimental.py:15-85 (same values)."""
+    f = np.asarray(freqs) / fs                      # cycles / sample
+    for bad, what in (((f < 0).any(), "frequencies must be positive"),
+                      (f.max() > 0.5, "max frequency must be 0.5"),
+                      (f.max() != f[-1], "max frequency must be last sample"),
+                      (f.min() != f[0], "min frequency must be first sample")):
+        if bad:
+            raise AssertionError(what)
+    n_out = len(f)
+    n_grid = 10 * n_out if n_search_scales is None else n_search_scales
+    ln_b = np.log(base)
+    bounds = cwt_scalebounds(wavelet, N, preset='maximal', use_padded_N=False)
+    grid = np.logspace(np.log(bounds[0]) / ln_b, np.log(bounds[1]) / ln_b, n_grid, base=base)
+    radians = [min(max(center_frequency(wavelet, s, N, kind=kind), 0), np.pi) for s in grid]
+    grid_f = np.array(radians) / (2*np.pi)
+    s_first = grid[np.argmin(np.abs(grid_f - f.min()))]      # lowest frequency <-> largest scale
+    s_last = grid[np.argmin(np.abs(grid_f - f.max()))]
+    return np.logspace(np.log(s_first) / ln_b, np.log(s_last) / ln_b, n_out, base=base)
 
 
 def scale_to_freq(scales, wavelet, N, fs=1, padtype='reflect'):
-    """Frequencies [0, fs/2] of the peaks of the wavelets at `scales` on the grid the
-    transform uses (padded length unless `padtype is None`). Reference:
-    experimental.py:88-143."""
-    if isinstance(scales, float):
-        scales = np.array([scales])
+    """Frequencies in [0, fs/2] at which the wavelets at `scales` peak on the grid the
+    transform uses (the padded length unless `padtype is None`). Reference:
+    experimental.py:88-143 (same values)."""
+    scales = np.array([scales]) if isinstance(scales, float) else scales
     wavelet = Wavelet._init_if_not_isinstance(wavelet)
-    Npad = p2up(N)[0] if padtype is not None else N
-    psis = wavelet(scale=scales, N=Npad)
-    idxs = np.argmax(psis, axis=-1)
-    if np.any(idxs > Npad//2) or 0 in idxs:
+    n_grid = N if padtype is None else p2up(N)[0]
+    peak = np.argmax(wavelet(scale=scales, N=n_grid), axis=-1)
+    off_grid = (peak > n_grid // 2) | (peak == 0)     # negative-frequency or dc "peak"
+    if off_grid.any():
         warnings.warn("found potentially ill-behaved wavelets (peak indices at "
                       "negative freqs or at dc); will round idxs to 1 or N/2")
-        n_psis = len(psis)
-        for i, ix in enumerate(idxs):
-            if ix > Npad//2 or ix == 0:
-                idxs[i] = 1 if i > n_psis // 2 else Npad//2
-    freqs = idxs / Npad
-    assert freqs.min() >= 0,   freqs.min()
-    assert freqs.max() <= 0.5, freqs.max()
-    freqs *= fs
-    return freqs
+        low_freq_half = np.arange(len(peak)) > len(peak) // 2
+        peak = np.where(off_grid, np.where(low_freq_half, 1, n_grid // 2), peak)
+    f = peak / n_grid
+    if f.min() < 0 or f.max() > 0.5:
+        raise AssertionError((f.min(), f.max()))
+    return f * fs
 
 
 def phase_ssqueeze(Wx, dWx=None, ssq_freqs=None, scales=None, Sfs=None, fs=1., t=None,
