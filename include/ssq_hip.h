@@ -266,6 +266,43 @@ typedef struct {
 
 int  ssq_cwt_plan_set_blocks(ssq_cwt_plan* plan, const ssq_cwt_blocks_desc* desc);
 
+/* Optional column-tile path of the fused ssq_cwt form (float32, power-of-two m, block
+ * tables set, Tx requested without w): rows that are at least 2x oversampled after a
+ * decimation by R >= 4 are not transformed at full length at all. Their band is
+ * inverse-transformed at length m / R into a plan-owned intermediate, and one kernel per
+ * 64-column tile interpolates Wx / dWx from it (8-tap Kaiser-Bessel kernel and its
+ * derivative), writes Wx, and reassigns into an LDS-resident tile of Tx in ascending row
+ * order -- Wx is never read back and no bin map is written for those rows. The other
+ * rows keep the block / exact kernels; the tile kernel reads their Wx and bin map back.
+ * ssqueezepy_amd/_tiles.py documents the decomposition and builds the tables (host
+ * arrays, copied). Must follow ssq_cwt_plan_set_blocks, before the first execute.
+ * Replaces, for those rows, _cwt.py:167-177 (ifft of Psih*xh, and of its 1j*xi multiple)
+ * together with ssqueezing.py:122-146 -> algos.py:859-953 (the reassignment loop). */
+typedef struct {
+    int32_t        n_segs;
+    const int32_t* segs;         /* n_segs x 8: kind (0 read back, 1 interpolate), first step, */
+                                 /* steps, log2 R, weight-table offset (phases), intermediate  */
+                                 /* stride per signal, L - 1, class offset (complex entries)   */
+    int32_t        n_steps;
+    const int32_t* rows;         /* 4 n_steps x 4: row (-1 none), offset in class, kc, theta   */
+                                 /* (float bits) = 2 pi kc / (m dt)                            */
+    const void*    ltw;          /* complex64 [4 n_steps][16]: exp(2i pi kc c / m)             */
+    const void*    twm;          /* complex64 [m]: exp(2i pi p / m)                            */
+    const void*    wtab;         /* float32 [n_phases][16]: phi at 8 taps, phi' / (R dt)       */
+    int64_t        n_phases;
+    const void*    tbank;        /* float32: band values / (phi_hat m) of the interpolated rows */
+    int64_t        n_tbank;
+    int32_t        n_irows;
+    const int64_t* irows;        /* n_irows x 8: row, lo, K, kc, L, tbank offset, class, index in class */
+    int32_t        n_classes;
+    const int64_t* classes;      /* n_classes x 4: L, rows, entries per signal before it, log2 R */
+    int64_t        u_total;      /* complex entries of the intermediate per signal             */
+    int64_t        n_items_tile[5]; /* per L': leading block items that remain (rows read back) */
+    int32_t        n_exact_tile;    /* leading exact rows that remain (all of them today)      */
+} ssq_cwt_tiles_desc;
+
+int  ssq_cwt_plan_set_tiles(ssq_cwt_plan* plan, const ssq_cwt_tiles_desc* desc);
+
 /* Per-stage timing with HIP events on the execute stream (measurement aid, off by
  * default; execute synchronises when it is on). `stage_ms[4]` receives the time
  * accumulated since the last reset: 0 = pad + forward FFT + block spectra, 1 = block

@@ -16,10 +16,11 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc
+from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc, CwtTilesDesc
 from . import algos
 from ._bank import banded_bank
 from ._blocks import plan_blocks, L_MIN
+from ._tiles import plan_tiles
 from .padding import pad_geometry, PADTYPES
 from .scales import process_scales, _process_fs_and_t
 from .wavelets import Wavelet
@@ -75,6 +76,8 @@ class CwtPlan():
         self._pad_src = None
         self._ssq_key = None
         self.block_rows = 0
+        self.tile_rows = 0
+        self.dt = float(dt)
         if algo == 0 and os.environ.get('SSQ_CWT_ALGO', 'auto') != 'generic':
             self._try_blocks(wavelet, vals, off, lo)
 
@@ -113,6 +116,13 @@ class CwtPlan():
         ctw_off = np.ascontiguousarray(bp['ctw_off'], dtype=np.int64)
         ftw = np.ascontiguousarray(bp['ftw'], dtype=cdt)
         gen = np.ascontiguousarray(bp['generic_rows'], dtype=np.int32)
+        # column-tile path of the fused ssq form (_tiles.py): rows it interpolates leave the
+        # block kernels when `Tx` is requested -- their items go to the end of each list
+        tp = None
+        if self.dtype == 'float32' and os.environ.get('SSQ_CWT_TILES', '1') != '0':
+            tp = plan_tiles(vals, off, lo, self.M, self.N, self.n1, self.dt, rows[:, 0] >= 0,
+                            self.group, row_scale=self._bank[3])
+        n_items_tile = [0] * 5
         keep = [cls, rows, pbank, pxi, ctw, ctw_off, ftw, gen]
         d = CwtBlocksDesc()
         d.n_classes = len(cls)
@@ -125,6 +135,10 @@ class CwtPlan():
             Lp = L_MIN << slot
             it = np.ascontiguousarray(bp['items'].get(Lp, np.zeros((0, 4))),
                                       dtype=np.int32)
+            if tp is not None and len(it):
+                stay = ~tp['interp_rows'][it[:, 0]]
+                it = np.ascontiguousarray(np.concatenate([it[stay], it[~stay]]))
+                n_items_tile[slot] = int(stay.sum())
             keep.append(it)
             d.items[slot] = it.ctypes.data if len(it) else None
             d.n_items[slot] = len(it)
@@ -133,7 +147,31 @@ class CwtPlan():
         d.n_generic = len(gen)
         check(self.lib.ssq_cwt_plan_set_blocks(self._h, ctypes.byref(d)))
         self.block_rows = int((rows[:, 0] >= 0).sum())
+        if tp is not None:
+            self._set_tiles(tp, n_items_tile, len(gen))
         self.block_plan = {k: bp[k] for k in ('classes', 'margins')}
+
+    def _set_tiles(self, tp, n_items_tile, n_exact):
+        c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        segs, rws = c(tp['segs'], np.int32), c(tp['rows'], np.int32)
+        ltw, twm = c(tp['ltw'], np.complex64), c(tp['twm'], np.complex64)
+        wtab, tbank = c(tp['wtab'], np.float32), c(tp['tbank'], np.float32)
+        irows, classes = c(tp['irows'], np.int64), c(tp['classes'], np.int64)
+        d = CwtTilesDesc()
+        d.n_segs, d.segs = len(segs), segs.ctypes.data
+        d.n_steps, d.rows = len(rws) // 4, rws.ctypes.data
+        d.ltw, d.twm = ltw.ctypes.data, twm.ctypes.data
+        d.wtab, d.n_phases = wtab.ctypes.data, len(wtab)
+        d.tbank, d.n_tbank = tbank.ctypes.data, len(tbank)
+        d.n_irows, d.irows = len(irows), irows.ctypes.data
+        d.n_classes, d.classes = len(classes), classes.ctypes.data
+        d.u_total = tp['u_total']
+        for slot in range(5):
+            d.n_items_tile[slot] = n_items_tile[slot]
+        d.n_exact_tile = int(n_exact)
+        check(self.lib.ssq_cwt_plan_set_tiles(self._h, ctypes.byref(d)))
+        self.tile_rows = int(tp['interp_rows'].sum())
+        self.tile_plan = {k: tp[k] for k in ('lgR', 'interp_rows', 'classes')}
 
     def __del__(self):
         h = getattr(self, '_h', None)

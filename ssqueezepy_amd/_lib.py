@@ -41,6 +41,14 @@ class CwtBlocksDesc(Structure):
                 ('n_generic', c_int64)]
 
 
+class CwtTilesDesc(Structure):
+    _fields_ = [('n_segs', c_int), ('segs', c_void_p), ('n_steps', c_int), ('rows', c_void_p),
+                ('ltw', c_void_p), ('twm', c_void_p), ('wtab', c_void_p), ('n_phases', c_int64),
+                ('tbank', c_void_p), ('n_tbank', c_int64), ('n_irows', c_int),
+                ('irows', c_void_p), ('n_classes', c_int), ('classes', c_void_p),
+                ('u_total', c_int64), ('n_items_tile', c_int64 * 5), ('n_exact_tile', c_int)]
+
+
 class StftDesc(Structure):
     _fields_ = [('dtype', c_int), ('padtype', c_int), ('n', c_int64),
                 ('n_fft', c_int64), ('hop_len', c_int64), ('modulated', c_int),
@@ -100,6 +108,7 @@ _PROTOS = {
     'ssq_cwt_execute': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_int, c_void_p]),
     'ssq_cwt_plan_set_blocks': (c_int, [c_void_p, POINTER(CwtBlocksDesc)]),
+    'ssq_cwt_plan_set_tiles': (c_int, [c_void_p, POINTER(CwtTilesDesc)]),
     'ssq_cwt_plan_timing': (c_int, [c_void_p, c_int, POINTER(c_double), POINTER(c_int64)]),
     'ssq_cwt_plan_group': (c_int, [c_void_p]),
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),

@@ -24,6 +24,7 @@ SOURCES = [
     ('ssq_kernels.hip', ['-ffp-contract=off']),
     ('ssq_cwt.hip', ['-ffp-contract=off']),
     ('ssq_cwt_blocks.hip', ['-ffp-contract=off']),
+    ('ssq_cwt_tiles.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
     ('ssq_inverse.hip', ['-ffp-contract=off']),
     ('ssq_ridge.hip', ['-ffp-contract=off']),

@@ -62,8 +62,10 @@ struct BlockPlan {
     // block spectra of all classes for the padded batch xp (max_batch x M)
     int spectra(const void* xp, int64_t batch, hipStream_t stream);
     // all block rows of signals sig .. sig+nsig-1; kidx holds nsig maps
+    // `limit`: per L' slot, run only the leading items (the tile path takes the other rows)
     int run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
-            const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream);
+            const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream,
+            const int64_t* limit = nullptr);
     // the same for a float64 plan (2048 points per 128-thread workgroup)
     int run64(int sig, int nsig, double* Wx, double* dWx, double* w, unsigned short* kidx,
               const double* row_scale, double dt, const SsqParams& sp, hipStream_t stream);

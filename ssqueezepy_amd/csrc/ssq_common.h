@@ -7,6 +7,27 @@
 #include <cstring>
 #include "../../include/ssq_hip.h"
 
+// make the compiler treat a value as lane-dependent (keeps a load of a lane-independent
+// address on the vector memory path)
+#ifndef SSQ_OPAQUE_V
+#define SSQ_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
+// Packed float32 multiply-add with one half of a register pair broadcast to both lanes of the
+// packed operation (v_pk_fma_f32 op_sel): acc.xy += w.xy * s.x  /  acc.xy += w.xy * s.y, and the
+// same for the multiply. hipcc materialises the broadcast with two v_mov per operand instead
+// (34 of 131 instructions of the tile kernel's inner row), hence the explicit forms; and
+// ds_bpermute_b32 with its immediate offset, which hipcc re-adds in a VGPR per use.
+#ifndef SSQ_PK_DEFINED
+typedef float ssq_f2 __attribute__((ext_vector_type(2)));
+#define SSQ_PK_MUL_LO(d, w, s) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(w), "v"(s))
+#define SSQ_PK_MUL_HI(d, w, s) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(w), "v"(s))
+#define SSQ_PK_FMA_LO(acc, w, s) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(s))
+#define SSQ_PK_FMA_HI(acc, w, s) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(s))
+#define SSQ_BPERMUTE_OFF(d, addr, v, off) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(d) : "v"(addr), "v"(v), "n"(off))
+#define SSQ_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 namespace ssq {
 
 void set_error(const char* fmt, ...);

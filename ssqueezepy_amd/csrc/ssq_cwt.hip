@@ -19,6 +19,7 @@
 #include "ssq_common.h"
 #include "ssq_fft.h"
 #include "ssq_blocks.h"
+#include "ssq_tiles.h"
 #include <algorithm>
 #include <map>
 #include <string>
@@ -149,6 +150,7 @@ struct ssq_cwt_plan {
     int32_t* all_rows = nullptr;          // identity list (rpadded output bypasses blocks)
     const int32_t* gen_rows_for(bool use_blocks) const { return use_blocks ? gen_rows : all_rows; }
     BlockPlan* blk = nullptr;
+    TilePlan* tile = nullptr;             // column-tile path of the fused ssq form (ssq_cwt_tiles.hip)
     bool executed = false;
     // optional per-stage HIP-event timing (bench.py reads it): 0 = pad + forward FFT +
     // block spectra, 1 = block rows, 2 = exact / generic rows, 3 = reassignment
@@ -239,6 +241,7 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     pl->fwd.destroy();
     for (auto& kv : pl->inv) kv.second.destroy();
     if (pl->blk) { pl->blk->destroy(); delete pl->blk; }
+    if (pl->tile) { pl->tile->destroy(); delete pl->tile; }
     for (hipEvent_t e : pl->tev) (void)hipEventDestroy(e);
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
                     pl->kidx, pl->cst, pl->gen_rows, pl->all_rows};
@@ -294,6 +297,22 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
         if (rc) return rc;
     }
     pl->algo = !pl->n_gen ? "blockzoom" : (b->exact_ok ? "blockzoom+fourstep" : "blockzoom+rocfft");
+    return 0;
+}
+
+int ssq_cwt_plan_set_tiles(ssq_cwt_plan* pl, const ssq_cwt_tiles_desc* td) {
+    SSQ_REQUIRE(pl && td, "ssq_cwt_plan_set_tiles: null pointer");
+    SSQ_REQUIRE(pl->blk && !pl->executed && !pl->tile,
+                "tile tables must be set once, after the block tables, before the first execute");
+    SSQ_REQUIRE(pl->d.dtype == SSQ_F32, "the tile path is float32 only");
+    for (int t = 0; t < 5; ++t)
+        SSQ_REQUIRE(td->n_items_tile[t] >= 0 && td->n_items_tile[t] <= pl->blk->n_items[t],
+                    "tile tables: bad block item count in slot %d", t);
+    auto* tp = new TilePlan();
+    int rc = tp->create(*td, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->group, pl->bytes);
+    if (rc) { tp->destroy(); delete tp; return rc; }
+    pl->tile = tp;
+    pl->algo += "+tiles";
     return 0;
 }
 
@@ -361,6 +380,9 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     auto mark = [&](size_t idx) { if (tm) (void)hipEventRecord(pl->tev[idx], stream); };
     const bool use_blocks = pl->blk && !rpadded;
     const int64_t n_gen = use_blocks ? pl->n_gen : na;
+    // fused ssq form on the column-tile path: block / exact kernels only for the rows the
+    // tile kernel reads back, no separate reassignment launch
+    const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4 && !pl->sp.cst_f64;
     if (use_blocks) {
         int rc = pl->blk->spectra(pl->xp, batch, stream);
         if (rc) return rc;
@@ -374,7 +396,8 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         if (use_blocks) {
             if constexpr (sizeof(T) == 4) {
                 int rc = pl->blk->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)w, kidx,
-                                      (const float*)pl->row_scale, d.dt, pl->sp, stream);
+                                      (const float*)pl->row_scale, d.dt, pl->sp, stream,
+                                      use_tiles ? pl->tile->n_items_tile : nullptr);
                 if (rc) return rc;
             } else {
                 int rc = pl->blk->run64((int)b0, ng, (double*)Wx, (double*)dWx, (double*)w, kidx,
@@ -426,7 +449,12 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         }
         }
         mark(2 + 4 * slot + 2);
-        if (Tx) {
+        if (use_tiles) {
+            int rc2 = pl->tile->spectra((int)b0, ng, pl->xh, stream);
+            if (rc2) return rc2;
+            rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->sp, stream);
+            if (rc2) return rc2;
+        } else if (Tx) {
             T* Wx_g = (T*)Wx + (size_t)b0 * na * out_cols * 2;
             T* w_g = w ? (T*)w + (size_t)b0 * na * out_cols : nullptr;
             T* Tx_g = (T*)Tx + (size_t)b0 * na * out_cols * 2;

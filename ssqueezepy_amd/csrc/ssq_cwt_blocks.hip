@@ -708,7 +708,8 @@ int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream) {
 }
 
 int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,
-                   const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream) {
+                   const float* row_scale, double dt, const SsqParams& sp, hipStream_t stream,
+                   const int64_t* limit) {
     BlockArgs A;
     A.rows = rows; A.classes = classes; A.pbank = (const float*)pbank; A.pxi = (const float*)pxi;
     A.ctw = (const c32*)ctw;
@@ -720,7 +721,7 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
     A.gamma = sp.gamma; A.sig = sig;
     int rc = 0;
 #define ZOOM(slot, L, G, R1, R2, R3)                                                              \
-    A.items = (const int4*)items[slot]; A.n_items = n_items[slot];                                 \
+    A.items = (const int4*)items[slot]; A.n_items = limit ? limit[slot] : n_items[slot];                                 \
     A.ftw = (const c32*)ftw + ftw_off[slot];                                                       \
     if ((rc = launch_zoom<L, G, R1, R2, R3>(A, sp, nsig, stream))) return rc;
     ZOOM(0, 128, 32, 16, 8, 1)

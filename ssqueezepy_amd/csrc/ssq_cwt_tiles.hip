@@ -1,0 +1,540 @@
+// ssq_cwt_tiles.hip -- the column-tile path of the fused ssq_cwt form (float32, gfx950).
+//
+// Math and planning: ssqueezepy_amd/_tiles.py. Two kernels:
+//
+//   tile_spectra_kernel   band of row i (K bins around bin kc of the M-grid) x spectrum of the
+//                         padded signal x compensated bank value -> baseband spectrum of
+//                         length L = M / R, zero outside the band; one batched rocFFT inverse
+//                         per decimation class turns it into the samples u_i[q] (plan-owned
+//                         intermediate, ~34 MB per signal at N=160k: L2 / Infinity-Cache food).
+//
+//   tile_kernel           one workgroup (4 wavefronts) = 64 columns x every row of one signal.
+//                         A wavefront owns 16 columns: its lanes are (column c, row slot r), 4 rows
+//                         per step, and its 16 columns x na bins of Tx live in LDS (na * 128 B
+//                         per wavefront, 150 KiB per workgroup at na = 300: one workgroup per
+//                         CU -- the LDS-resident tile is what removes the HBM round trip of Wx,
+//                         and it is also what bounds the kernel to one wavefront per SIMD, so all
+//                         loads are software-pipelined). Per step and lane:
+//                           interpolated rows: ONE 8-byte load of u_i (the 16 lanes of a row slot
+//                             hold a window of 16 consecutive samples; taps are fetched from the
+//                             neighbours with ds_bpermute), 8 taps x (phi, phi') real weights kept
+//                             in registers for the whole decimation class, modulation by
+//                             e^{2i pi kc n / M} = (tile twiddle) x (lane twiddle), Wx stored
+//                             (128-byte runs), phase transform + bin exactly as the other fused
+//                             kernels do (ssq_point_math.inl);
+//                           read-back rows: Wx and the 2-byte bin written by the block / exact
+//                             kernels.
+//                         Reassignment: ds_add_f32 into the wavefront's private tile, row slot after
+//                         row slot (exec-masked, in program order), i.e. in ascending row order
+//                         per cell -- the reference's summation order, so float sums are
+//                         bit-identical to the CPU loop (algos.py:859-953) on the same Wx / dWx.
+//                         No workgroup barrier, no global atomics; Tx is written once at the end.
+//
+// Compiled with -ffp-contract=off (bin indices); multiply-adds that may fuse are written as
+// explicit fmaf so every instantiation rounds identically.
+#include "ssq_common.h"
+#include "ssq_tiles.h"
+#include <algorithm>
+
+namespace ssq {
+
+#include "ssq_point_math.inl"
+
+constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
+constexpr int TILE_G = 4;         // rows per step
+constexpr int TILE_W = 8;         // taps
+
+struct TileArgs {
+    const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
+    const float2* ltw; const float2* twm; const float4* wtab; const float2* U;
+    const float* cst;
+    float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
+    int64_t N, na;
+    int nsteps, n1, mmask, sig0;
+    float inv_m;         // 1 / M
+    unsigned long long* trace;   // tuning aid (SSQ_TILE_TRACE): shader-clock stamps of one workgroup
+    int dbg;             // tuning aid (SSQ_TILE_DBG): 1 = no Wx store, 2 = no tile update, 4 = no bin arithmetic
+    double gamma;
+};
+
+__global__ __launch_bounds__(256) void tile_spectra_kernel(const float2* __restrict__ xh_all,
+                                                           int64_t xh_stride, int sig0,
+                                                           const TileIRow* __restrict__ irows,
+                                                           const float* __restrict__ tbank,
+                                                           float2* __restrict__ U) {
+    const TileIRow r = irows[blockIdx.y];
+    const int s = blockIdx.z;
+    const float2* xh = xh_all + (int64_t)(sig0 + s) * xh_stride;
+    float2* u = U + r.ubase + (int64_t)s * r.sig_stride;
+    const int half = r.L >> 1;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < r.L; p += gridDim.x * blockDim.x) {
+        const int kk = p < half ? p : p - r.L;            // signed baseband bin
+        const int t = r.kc + kk - r.lo;
+        float2 z = make_float2(0.f, 0.f);
+        if (t >= 0 && t < r.K) {
+            const float2 x = xh[r.lo + t];
+            const float b = tbank[r.tb_off + t];
+            z = make_float2(x.x * b, x.y * b);
+        }
+        u[p] = z;
+    }
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float lane_fetch(int byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// The tile of Tx (64 columns x na bins, + one scratch row for points that contribute
+// nothing) is shared by all NW wavefronts of the workgroup. A lane is a column, a wavefront
+// takes the steps (4 consecutive rows) of the row list round-robin: everything that depends
+// on the row alone -- descriptor, theta, tile twiddle, weight -- is wavefront-uniform (SGPRs,
+// scalar loads), loads and stores are 512-byte runs, and the arithmetic of different steps
+// runs concurrently on the SIMDs. Only the reassignment itself is ordered, by a ticket in
+// LDS: step g may update the tile once `turn == g` (acquire / release at workgroup scope
+// order the tile accesses around it), so every cell receives its contributions in
+// ascending row order -- the reference's -- and the float sums are bit-identical to the CPU
+// loop. Inside a step the four rows' cells are read together and chained in registers when
+// they coincide (same lane = same column: no cross-lane traffic), then written in row order.
+// (LDS float atomics were measured first: ds_add_f32 retires about one lane per 3-4 cycles
+// on gfx950; and a layout with a private 16-column tile per wavefront, lanes = 16 columns x 4
+// rows: per-lane descriptors and exec-masked row slots doubled the instruction count.)
+__device__ __forceinline__ void take_turn(const int* turn, int g) {
+    while (__atomic_load_n(turn, __ATOMIC_ACQUIRE) != g) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void pass_turn(int* turn, int g, int lane) {
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __atomic_store_n(turn, g + 1, __ATOMIC_RELEASE);
+}
+// T[cell[r]] += v[r], r = 0..3 in order; `cell` of a point without contribution is the
+// lane's scratch cell and its v is 0
+// `src[r]`: the latest earlier row of the step on the same cell, or -1 (computed before the
+// turn is taken: the comparisons do not depend on the tile)
+__device__ __forceinline__ void forward4(const int (&cell)[TILE_G], int (&src)[TILE_G]) {
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) {
+        src[r] = -1;
+#pragma unroll
+        for (int q = 0; q < r; ++q) if (cell[q] == cell[r]) src[r] = q;
+    }
+}
+__device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const float2 (&v)[TILE_G],
+                                        const int (&src)[TILE_G]) {
+    float2 t[TILE_G];
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) t[r] = T[cell[r]];
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) {
+#pragma unroll
+        for (int q = 0; q < r; ++q) if (src[r] == q) t[r] = t[q];
+        t[r].x += v[r].x; t[r].y += v[r].y;
+    }
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
+}
+
+// bin of a point the float32 screens could not decide (flipped as Tx wants it), or -1 when it
+// does not contribute: the exact double sequence of the CPU path. Kept out of line -- one
+// copy per kernel, ~0.05 % of the points.
+__device__ __attribute__((noinline)) int exact_bin(float2 W, float2 D, const SsqParams& sp, int omax, double gamma) {
+    if (!(mag_of(W.x, W.y) > gamma)) return -1;
+    const int ke = (int)bin_of_point_exact(D.x, D.y, W.x, W.y, sp, (int64_t)omax);
+    return sp.flipud ? omax - ke : ke;
+}
+
+// trace slot: [wave][16 steps][8 stamps]
+#define TILE_STAMP(j, k)                                                                        \
+    do { if (tr && (j) < 16 && c == 0) tr[((size_t)wv * 16 + (j)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int GRID, bool STORE_D, int NW>
+__global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int c = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s = blockIdx.y;
+    const int64_t N = A.N;
+    const int na = (int)A.na, omax = na - 1;
+    const int col0 = blockIdx.x * TILE_COLS;
+    const int col = col0 + c;
+    const bool colok = col < N;
+    const int colc = colok ? col : (int)N - 1;               // loads stay in range
+    float2* T = reinterpret_cast<float2*>(lds_raw);
+    int* turn = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
+    for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+    if (threadIdx.x == 0) *turn = 0;
+    __syncthreads();
+    const int scratch = na * TILE_COLS + c;
+    unsigned long long* tr = (A.trace && blockIdx.x == 700 && blockIdx.y == 1) ? A.trace : nullptr;
+    if (tr && threadIdx.x == 0) tr[16 * 16 * 8] = __builtin_amdgcn_s_memtime();
+
+    const unsigned nN = (unsigned)N;
+    const int64_t sigbase = (int64_t)(A.sig0 + s) * na * N;
+    float2* Wx = A.Wx + sigbase;
+    float2* dWx = STORE_D ? A.dWx + sigbase : nullptr;
+    const unsigned short* kidx = A.kidx + (int64_t)s * na * N;
+    const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
+    const float g2 = (float)(A.gamma * A.gamma);
+    const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
+    const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
+
+    // Step and row records, tile twiddles and the reassignment weight are the same for every
+    // lane. They are fetched with vector loads from a lane-independent address (one request
+    // per wavefront) rather than scalar loads: scalar and LDS operations share one counter
+    // (lgkmcnt) and scalar loads return out of order, so a scalar load in flight turns every
+    // wait for a ds_bpermute result into a full drain.
+    int vz = 0;
+    SSQ_OPAQUE_V(vz);
+    const int4* rows4 = reinterpret_cast<const int4*>(A.rows) + vz;
+    const int4* steps4 = reinterpret_cast<const int4*>(A.steps) + vz;
+    const float* cstv = A.cst + vz;
+
+    // This wavefront's steps: wv, wv + NW, ... -- consecutive steps of one wavefront are NW steps
+    // apart in the row list and usually of different decimation classes, so ONE software
+    // pipeline runs over all of them: records two steps ahead (they hold the addresses),
+    // samples / twiddles / interpolation weights one step ahead.
+    // (pairs of consecutive steps, wv-th pair of every NW: the ticket is taken once per pair)
+    const int npairs = (A.nsteps + 1) / 2;
+    const int mypairs = npairs > wv ? (npairs - wv + NW - 1) / NW : 0;
+    const int nmine = mypairs == 0 ? 0 : 2 * mypairs - ((2 * (wv + (mypairs - 1) * NW) + 1 >= A.nsteps) ? 1 : 0);
+    auto gstep = [&](int j) { const int jj = j < nmine ? j : nmine - 1; return 2 * (wv + (jj >> 1) * NW) + (jj & 1); };
+    int4 sa[2], sb[2], rec[2][TILE_G];        // step (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
+    auto load_rec = [&](int q, int j) {
+        const int g = gstep(j);
+        sa[q] = steps4[2 * g]; sb[q] = steps4[2 * g + 1];
+#pragma unroll
+        for (int r = 0; r < TILE_G; ++r) rec[q][r] = rows4[g * TILE_G + r];
+    };
+    float2 xu[2][TILE_G];
+    float xc[2][TILE_G], xt[2][TILE_G]; int xr[2][TILE_G], xkc[2][TILE_G]; unsigned short xk[2][TILE_G];
+    float4 xw[2][4]; int xkind[2], xbaddr[2], xwoff[2] = {-1, -1};
+    auto load = [&](int b, int q, int j) {
+        const int g = gstep(j);
+        const int kind = sa[q].x;
+        xkind[b] = kind;
+        if (kind == 0) {                                     // rows read back: Wx, bin
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) {
+                const int row = rec[q][r].x & 0xFFFF;
+                const unsigned o = (unsigned)row * nN + (unsigned)colc;
+                xr[b][r] = rec[q][r].x;
+                xu[b][r] = Wx[o];
+                xk[b][r] = kidx[o];
+                xc[b][r] = cstv[row];
+            }
+        } else {                                             // rows interpolated
+            const int lgR = sa[q].w;
+            // weights of the class: 64 B per lane and step, the largest stream of the kernel --
+            // the second step of a pair nearly always shares the first one's
+            const bool same = b == 1 && __builtin_amdgcn_readfirstlane(xkind[0]) != 0 &&
+                              __builtin_amdgcn_readfirstlane(xwoff[0]) == __builtin_amdgcn_readfirstlane(sb[q].x);
+            xwoff[b] = sb[q].x;
+            if (same) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xw[1][t] = xw[0][t];
+            } else {
+                const float4* wp = A.wtab + (int64_t)(sb[q].x + (nabs & ((1 << lgR) - 1))) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xw[b][t] = wp[t];
+            }
+            const int q0 = nabs >> lgR, qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
+            // the sample this lane holds (lanes past the widest window any lane needs repeat the last one)
+            const int wlast = (63 >> lgR) + TILE_W;
+            const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb[q].z);
+            xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
+            const float2* Ub = A.U + sb[q].w + (int64_t)s * sb[q].y;
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) {
+                const int4 d = rec[q][r];
+                xr[b][r] = d.x; xkc[b][r] = d.z; xt[b][r] = __int_as_float(d.w);
+                xu[b][r] = Ub[(unsigned)d.y + uidx];
+                xc[b][r] = cstv[d.x & 0xFFFF];
+            }
+        }
+    };
+    if (nmine > 0) { load_rec(0, 0); load_rec(1, 1); load(0, 0, 0); }
+    for (int j = 0; j < nmine; j += 2) {
+        int cells[2][TILE_G]; float2 vs[2][TILE_G];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (j + b >= nmine) break;
+            TILE_STAMP(j + b, 0);
+            load(b ^ 1, 1, j + b + 1);
+            sa[0] = sa[1]; sb[0] = sb[1];
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) rec[0][r] = rec[1][r];
+            load_rec(1, j + b + 2);
+            int (&cell)[TILE_G] = cells[b]; float2 (&v)[TILE_G] = vs[b];
+            TILE_STAMP(j + b, 1);
+            if (__builtin_amdgcn_readfirstlane(xkind[b]) == 0) {
+#pragma unroll
+                for (int r = 0; r < TILE_G; ++r) {
+                    const int kk = xk[b][r];
+                    const bool act = xr[b][r] >= 0 && colok && kk != 0xFFFF;
+                    cell[r] = act ? kk * TILE_COLS + c : scratch;
+                    v[r] = act ? make_float2(xu[b][r].x * xc[b][r], xu[b][r].y * xc[b][r]) : make_float2(0.f, 0.f);
+                }
+            } else {
+                ssq_f2 wt[TILE_W];                               // (phi_t, phi'_t / (R dt))
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    wt[2 * t].x = xw[b][t].x; wt[2 * t].y = xw[b][t].y;
+                    wt[2 * t + 1].x = xw[b][t].z; wt[2 * t + 1].y = xw[b][t].w;
+                }
+                const int baddr = xbaddr[b];
+                unsigned pend = 0;
+                float2 Wk[TILE_G], Dk[TILE_G];
+                // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary parts
+                // as two packed accumulators (a_re, a'_re), (a_im, a'_im) per row; two rows at a
+                // time, so that a wavefront has four independent accumulation chains in flight
+                ssq_f2 are2[TILE_G], aim2[TILE_G];
+#pragma unroll
+                for (int r0 = 0; r0 < TILE_G; r0 += 2) {
+                    int fr[2][TILE_W], fi[2][TILE_W];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ur = __float_as_int(xu[b][r0 + h].x), ui = __float_as_int(xu[b][r0 + h].y);
+                        SSQ_BPERMUTE_OFF(fr[h][0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[h][0], baddr, ui, 0);
+                        SSQ_BPERMUTE_OFF(fr[h][1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[h][1], baddr, ui, 4);
+                        SSQ_BPERMUTE_OFF(fr[h][2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[h][2], baddr, ui, 8);
+                        SSQ_BPERMUTE_OFF(fr[h][3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[h][3], baddr, ui, 12);
+                        SSQ_BPERMUTE_OFF(fr[h][4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[h][4], baddr, ui, 16);
+                        SSQ_BPERMUTE_OFF(fr[h][5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[h][5], baddr, ui, 20);
+                        SSQ_BPERMUTE_OFF(fr[h][6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[h][6], baddr, ui, 24);
+                        SSQ_BPERMUTE_OFF(fr[h][7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[h][7], baddr, ui, 28);
+                    }
+                    SSQ_LDS_WAIT();
+#pragma unroll
+                    for (int t = 0; t < TILE_W; ++t)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ssq_f2 sv; sv.x = __int_as_float(fr[h][t]); sv.y = __int_as_float(fi[h][t]);
+                            if (t == 0) { SSQ_PK_MUL_LO(are2[r0 + h], wt[0], sv); SSQ_PK_MUL_HI(aim2[r0 + h], wt[0], sv); }
+                            else { SSQ_PK_FMA_LO(are2[r0 + h], wt[t], sv); SSQ_PK_FMA_HI(aim2[r0 + h], wt[t], sv); }
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < TILE_G; ++r) {
+                    const float are = are2[r].x, aim = aim2[r].x;
+                    float dre = are2[r].y, dim = aim2[r].y;
+                    // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
+                    const float theta = xt[b][r];
+                    dre = __builtin_fmaf(-theta, aim, dre);
+                    dim = __builtin_fmaf(theta, are, dim);
+                    // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
+                    // (M <= 2^24), v_sin_f32 / v_cos_f32 take revolutions (measured on the
+                    // M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
+                    const float rev = (float)(((unsigned)xkc[b][r] * (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;
+                    const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+                    const float2 Wv = cmulf(tw, make_float2(are, aim));
+                    const float2 Dv = cmulf(tw, make_float2(dre, dim));
+                    // (rows that only pad a step repeat the previous row -- same address, same value --
+                    // and lanes past the last column repeat its point; neither contributes below)
+                    const int row = xr[b][r] & 0xFFFF;
+                    const bool pad = xr[b][r] < 0;
+                    const unsigned o = (unsigned)row * nN + (unsigned)colc;
+                    Wx[o] = Wv;
+                    if (STORE_D) dWx[o] = Dv;
+                    // phase transform and bin: as emit_point<LEAN> of the block kernels
+                    const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
+                    const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
+                    const bool above = m2 > m2hi, below = m2 < m2lo;
+                    const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+                    bool ok;
+                    const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
+                    const int kf = (kb ^ fx) + fa;
+                    const bool live = colok && !pad;
+                    // undecided by the float32 screens (rare): the exact double path, once per step
+                    if (live && !(below | (above & ok))) pend |= 1u << r;
+                    const bool act = above && live;
+                    cell[r] = act ? kf * TILE_COLS + c : scratch;
+                    v[r] = act ? make_float2(Wv.x * xc[b][r], Wv.y * xc[b][r]) : make_float2(0.f, 0.f);
+                    Wk[r] = Wv; Dk[r] = Dv;
+                }
+                if (__builtin_amdgcn_ballot_w64(pend != 0)) {
+#pragma unroll
+                    for (int r = 0; r < TILE_G; ++r)
+                        if (pend & (1u << r)) {
+                            const int kf = exact_bin(Wk[r], Dk[r], sp, omax, A.gamma);
+                            cell[r] = kf >= 0 ? kf * TILE_COLS + c : scratch;
+                            v[r] = kf >= 0 ? make_float2(Wk[r].x * xc[b][r], Wk[r].y * xc[b][r]) : make_float2(0.f, 0.f);
+                        }
+                }
+            }
+            TILE_STAMP(j + b, 2);
+        }
+        if (!(A.dbg & 2)) {
+            const int g = gstep(j);
+            const bool two = j + 1 < nmine;
+            int src[2][TILE_G];
+            forward4(cells[0], src[0]);
+            if (two) forward4(cells[1], src[1]);
+            // the wavefront that holds the turn is the critical path of the workgroup
+            __builtin_amdgcn_s_setprio(3);
+            take_turn(turn, g);
+            TILE_STAMP(j, 3);
+            update4(T, cells[0], vs[0], src[0]);
+            if (two) update4(T, cells[1], vs[1], src[1]);
+            pass_turn(turn, g + (two ? 1 : 0), c);
+            __builtin_amdgcn_s_setprio(0);
+            TILE_STAMP(j, 4);
+        } else if (vs[0][0].x == 12345.f) T[cells[0][0]].x = vs[0][1].x + vs[1][2].x + vs[1][3].x;
+    }
+    if (tr && c == 0) tr[16 * 16 * 8 + 1 + wv] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    float2* Tx = A.Tx + sigbase;
+    for (int k0 = wv; k0 < na; k0 += 8 * NW) {              // 8 rows in flight per wavefront
+        float2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = k0 + u * NW; t[u] = T[(k < na ? k : 0) * TILE_COLS + c]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * NW;
+            if (k < na && colok) Tx[(unsigned)k * nN + (unsigned)col] = t[u];
+        }
+    }
+    if (tr && c == 0) tr[16 * 16 * 8 + 20 + wv] = __builtin_amdgcn_s_memtime();
+}
+
+// ---------------------------------------------------------------------------- host side
+int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_, int group_,
+                     int64_t& bytes) {
+    M = M_; N = N_; n1 = n1_; na = na_; group = group_;
+    nsegs = d.n_segs; nsteps = d.n_steps; n_irows = d.n_irows; u_total = d.u_total;
+    SSQ_REQUIRE(nsegs >= 1 && nsteps >= 1 && n_irows >= 1 && d.n_classes >= 1, "empty tile tables");
+    SSQ_REQUIRE((size_t)(na + 1) * TILE_COLS * 8 + 16 <= 160 * 1024 && na * N < ((int64_t)1 << 29), "na = %lld: the Tx tile exceeds the LDS",
+                (long long)na);
+    SSQ_REQUIRE((int64_t)group * u_total < ((int64_t)1 << 31), "tile intermediates exceed 2^31 entries");
+    auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
+        SSQ_CHECK_HIP(hipMalloc(dst, nbytes ? nbytes : 1));
+        if (nbytes) SSQ_CHECK_HIP(hipMemcpy(*dst, src, nbytes, hipMemcpyHostToDevice));
+        bytes += (int64_t)nbytes;
+        return 0;
+    };
+    int rc;
+    static_assert(sizeof(TileSeg) == 32 && sizeof(TileRow) == 16 && sizeof(TileIRow) == 32, "table layout");
+    {   // one record per step (a wavefront's consecutive steps are usually of different segments)
+        std::vector<TileSeg> hs((size_t)nsteps);
+        const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
+        int64_t covered = 0;
+        for (int i = 0; i < nsegs; ++i) {
+            SSQ_REQUIRE(sg[i].first == covered && sg[i].nsteps >= 1 && sg[i].first + sg[i].nsteps <= nsteps,
+                        "tile segment %d does not continue the step list", i);
+            for (int t = 0; t < sg[i].nsteps; ++t) hs[(size_t)sg[i].first + t] = sg[i];
+            covered += sg[i].nsteps;
+        }
+        SSQ_REQUIRE(covered == nsteps, "tile segments cover %lld of %d steps", (long long)covered, nsteps);
+        if ((rc = up((void**)&steps, hs.data(), sizeof(TileSeg) * nsteps))) return rc;
+    }
+    if ((rc = up((void**)&rows, d.rows, sizeof(TileRow) * TILE_G * nsteps))) return rc;
+    if ((rc = up(&ltw, d.ltw, (size_t)8 * TILE_G * nsteps * TILE_COLS))) return rc;
+    if ((rc = up(&twm, d.twm, (size_t)8 * M))) return rc;
+    if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
+    if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
+    cls.resize(d.n_classes);
+    for (int c = 0; c < d.n_classes; ++c) {
+        cls[c] = {d.classes[4 * c], d.classes[4 * c + 1], d.classes[4 * c + 2]};
+        SSQ_REQUIRE(cls[c].L >= 2 && (cls[c].L & (cls[c].L - 1)) == 0 && cls[c].nrows >= 1, "bad tile class %d", c);
+        lmax = std::max(lmax, cls[c].L);
+    }
+    std::vector<TileIRow> hi((size_t)n_irows);
+    for (int r = 0; r < n_irows; ++r) {
+        const int64_t* q = d.irows + 8 * r;
+        const int c = (int)q[6];
+        SSQ_REQUIRE(c >= 0 && c < d.n_classes && q[4] == cls[c].L && q[2] >= 1 && 2 * q[2] <= q[4]
+                    && q[1] >= 0 && q[1] + q[2] <= M / 2 + 1 && q[5] >= 0 && q[5] + q[2] <= d.n_tbank,
+                    "bad tile row %d", r);
+        hi[r] = {(int32_t)q[0], (int32_t)q[1], (int32_t)q[2], (int32_t)q[3], (int32_t)q[4], (int32_t)q[5],
+                 (int32_t)((int64_t)group * cls[c].upre + q[7] * cls[c].L), (int32_t)(cls[c].nrows * cls[c].L)};
+    }
+    if ((rc = up((void**)&irows, hi.data(), sizeof(TileIRow) * n_irows))) return rc;
+    SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * group * u_total)); bytes += 8 * group * u_total;
+    SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * group * u_total));
+    for (size_t c = 0; c < cls.size(); ++c) {
+        FftPlan fp;
+        rc = fp.create(1, SSQ_F32, (size_t)cls[c].L, (size_t)(group * cls[c].nrows), 1.0);
+        if (rc) return rc;
+        bytes += (int64_t)fp.work_bytes;
+        ffts.push_back(fp);
+    }
+    for (int t = 0; t < 5; ++t) n_items_tile[t] = d.n_items_tile[t];
+    n_exact_tile = d.n_exact_tile;
+    return 0;
+}
+
+void TilePlan::destroy() {
+    for (auto& f : ffts) f.destroy();
+    ffts.clear();
+    void* ptrs[] = {steps, rows, irows, ltw, twm, wtab, tbank, U};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    steps = nullptr; rows = nullptr; irows = nullptr; ltw = twm = wtab = tbank = U = nullptr;
+}
+
+int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
+    const dim3 grid((unsigned)std::min<int64_t>((lmax + 255) / 256, 64), (unsigned)n_irows, (unsigned)nsig);
+    hipLaunchKernelGGL(tile_spectra_kernel, grid, dim3(256), 0, stream, (const float2*)xh_all, M / 2 + 1, sig,
+                       irows, (const float*)tbank, (float2*)U);
+    SSQ_LAUNCH_CHECK();
+    for (size_t c = 0; c < cls.size(); ++c) {
+        // the planned batch covers `group` signals; slots past nsig hold stale finite data
+        int rc = ffts[c].execute((float2*)U + (size_t)group * cls[c].upre, nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+template <int GRID, bool STORE_D, int NW>
+static int launch_tile_k(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream) {
+    auto kern = tile_kernel<GRID, STORE_D, NW>;
+    const size_t lds = (size_t)(na + 1) * TILE_COLS * 8 + 16;
+    SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid((unsigned)((N + TILE_COLS - 1) / TILE_COLS), (unsigned)nsig);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, A, sp);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+// wavefronts per workgroup: 8 by default (SSQ_TILE_K = 1 | 2 | 3 -> 4, 8, 12: tuning aid)
+template <int GRID, bool STORE_D>
+static int launch_tile(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream) {
+    static const int k = [] { const char* e = getenv("SSQ_TILE_K"); int v = e ? atoi(e) : 2; return v < 1 || v > 3 ? 2 : v; }();
+    if (k == 1) return launch_tile_k<GRID, STORE_D, 4>(A, sp, N, na, nsig, stream);
+    if (k == 3) return launch_tile_k<GRID, STORE_D, 12>(A, sp, N, na, nsig, stream);
+    return launch_tile_k<GRID, STORE_D, 8>(A, sp, N, na, nsig, stream);
+}
+
+int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
+                  const void* cst, const SsqParams& sp, hipStream_t stream) {
+    TileArgs A;
+    A.steps = steps; A.rows = rows; A.ltw = (const float2*)ltw; A.twm = (const float2*)twm;
+    A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = (const float*)cst;
+    A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
+    A.N = N; A.na = na; A.nsteps = nsteps; A.n1 = (int)n1; A.mmask = (int)(M - 1); A.sig0 = sig; A.inv_m = 1.0f / (float)M;
+    A.gamma = sp.gamma;
+    { const char* e = getenv("SSQ_TILE_DBG"); A.dbg = e ? atoi(e) : 0; }
+    static unsigned long long* trace_buf = nullptr;
+    const char* trace_path = getenv("SSQ_TILE_TRACE");
+    if (trace_path && !trace_buf) { SSQ_CHECK_HIP(hipMalloc((void**)&trace_buf, 8 * (16 * 16 * 8 + 64))); }
+    if (trace_buf) SSQ_CHECK_HIP(hipMemsetAsync(trace_buf, 0, 8 * (16 * 16 * 8 + 64), stream));
+    A.trace = trace_buf;
+    auto dump_trace = [&]() -> int {
+        if (!trace_buf) return 0;
+        SSQ_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h(16 * 16 * 8 + 64);
+        SSQ_CHECK_HIP(hipMemcpy(h.data(), trace_buf, 8 * h.size(), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        return 0;
+    };
+#define TILE_LAUNCH(G)                                                                      \
+    { int rc_ = dWx ? launch_tile<G, true>(A, sp, N, na, nsig, stream)                     \
+                    : launch_tile<G, false>(A, sp, N, na, nsig, stream);                   \
+      return rc_ ? rc_ : dump_trace(); }
+    if (sp.grid == SSQ_GRID_LOG) { TILE_LAUNCH(SSQ_GRID_LOG) }
+    if (sp.grid == SSQ_GRID_LOG_PIECEWISE) { TILE_LAUNCH(SSQ_GRID_LOG_PIECEWISE) }
+    TILE_LAUNCH(SSQ_GRID_LIN)
+#undef TILE_LAUNCH
+}
+
+}  // namespace ssq

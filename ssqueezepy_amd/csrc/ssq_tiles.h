@@ -1,0 +1,60 @@
+// ssq_tiles.h -- device tables and plan object of the column-tile path of the fused
+// ssq_cwt form (kernels in ssq_cwt_tiles.hip, host planning in _tiles.py).
+#pragma once
+#include "ssq_common.h"
+#include "ssq_fft.h"
+#include <vector>
+
+namespace ssq {
+
+// a run of steps of one kind (and, for interpolated rows, one decimation class)
+struct TileSeg {
+    int32_t kind;        // 0 = rows read back (Wx + bin map in HBM), 1 = rows interpolated
+    int32_t first;       // first step
+    int32_t nsteps;
+    int32_t lgR;         // log2 of the decimation R
+    int32_t wtab_off;    // first phase of the class in the weight table
+    int32_t sig_stride;  // complex entries between two signals' rows of the class
+    int32_t lmask;       // L - 1 (row length of the class, a power of two)
+    int32_t cls_base;    // complex entries before the class in the intermediate buffer
+};
+// one row of a step (4 per step; row < 0: none)
+struct TileRow {
+    int32_t row;
+    int32_t ubase;       // offset of the row's samples inside its class (signal 0)
+    int32_t kc;          // centre bin of the band on the M-point grid
+    float   theta;       // 2 pi kc / (M dt)
+};
+// one interpolated row as the spectra kernel sees it
+struct TileIRow {
+    int32_t row, lo, K, kc, L, tb_off;
+    int32_t ubase;       // complex entries: class offset + index in class * L (signal 0)
+    int32_t sig_stride;
+};
+
+struct TilePlan {
+    int64_t M = 0, N = 0, n1 = 0, na = 0;
+    int group = 1;
+    int nsegs = 0, nsteps = 0, n_irows = 0;
+    int64_t u_total = 0, lmax = 0;
+    TileSeg* steps = nullptr;               // the segment record of every step
+    TileRow* rows = nullptr; TileIRow* irows = nullptr;
+    void* ltw = nullptr; void* twm = nullptr; void* wtab = nullptr; void* tbank = nullptr;
+    void* U = nullptr;                      // group x u_total complex64
+    struct Cls { int64_t L, nrows, upre; };
+    std::vector<Cls> cls;
+    std::vector<FftPlan> ffts;              // one batched inverse per class
+    int64_t n_items_tile[5] = {0, 0, 0, 0, 0};
+    int n_exact_tile = 0;
+
+    int create(const ssq_cwt_tiles_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na, int group,
+               int64_t& bytes);
+    void destroy();
+    // intermediates of signals sig .. sig+nsig-1 (nsig <= group) from the spectra of the batch
+    int spectra(int sig, int nsig, const void* xh_all, hipStream_t stream);
+    // Wx of the interpolated rows, Tx of all rows (the other rows' Wx and bin map must be in place)
+    int run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
+            const void* cst, const SsqParams& sp, hipStream_t stream);
+};
+
+}  // namespace ssq

@@ -219,6 +219,22 @@ _FAMILIES = {'gmw': _make_gmw, 'morlet': _make_morlet, 'bump': _make_bump,
 
 
 # ------------------------------------------------------------------- Wavelet
+class _FnIdentity:
+    """Cache-key component for a user-supplied wavelet function: equal only to a key holding
+    the *same* function object, and it keeps that object alive, so that CPython cannot hand
+    its id() to a different function while a cached plan / design still refers to it."""
+    __slots__ = ('fn',)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __hash__(self):
+        return id(self.fn)
+
+    def __eq__(self, other):
+        return isinstance(other, _FnIdentity) and other.fn is self.fn
+
+
 class Wavelet():
     """Frequency-domain wavelet, sampled as ``psih(scale * xi)``.
 
@@ -322,7 +338,7 @@ class Wavelet():
     def key(self):
         """Hashable identity of the underlying function (plan-cache key)."""
         if self.family is None:
-            return ('fn', id(self.fn), self._dtype)
+            return ('fn', _FnIdentity(self.fn), self._dtype)
         return (self.family, self._dtype,
                 tuple(sorted((k, str(v)) for k, v in self.config.items())))
 

@@ -25,6 +25,17 @@ using std::isinf; using std::isnan; using std::min; using std::max;
 inline long long min(long long a, long b) { return a < b ? a : b; }
 inline long long max(long long a, int b) { return a > b ? a : b; }
 
+#define SSQ_OPAQUE_V(x) ((void)(x))
+// stand-ins of the inline-assembly forms of csrc/ssq_common.h
+inline int emu_ds_bpermute(int byte_addr, int v);
+#define SSQ_PK_DEFINED 1
+typedef float ssq_f2 __attribute__((ext_vector_type(2)));
+#define SSQ_PK_MUL_LO(d, w, s) do { (d).x = (w).x * (s).x; (d).y = (w).y * (s).x; } while (0)
+#define SSQ_PK_MUL_HI(d, w, s) do { (d).x = (w).x * (s).y; (d).y = (w).y * (s).y; } while (0)
+#define SSQ_PK_FMA_LO(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).x, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).x, (acc).y); } while (0)
+#define SSQ_PK_FMA_HI(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).y, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).y, (acc).y); } while (0)
+#define SSQ_BPERMUTE_OFF(d, addr, v, off) ((d) = emu_ds_bpermute((addr) + (off), (v)))
+#define SSQ_LDS_WAIT() ((void)0)
 #define __global__
 #define __device__
 #define __host__
@@ -87,7 +98,7 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 
 // ------------------------------------------------------------------ fibers
 namespace emu {
-enum Wait { RUNNABLE = 0, AT_WAVE = 1, AT_BLOCK = 2, FINISHED = 3 };
+enum Wait { RUNNABLE = 0, AT_WAVE = 1, AT_BLOCK = 2, FINISHED = 3, AT_SPIN = 4 };
 struct Fiber {
     ucontext_t ctx;
     void* stack = nullptr;
@@ -180,13 +191,13 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
                     // that is correct only in lockstep, without a wave_barrier, shows up)
                     const unsigned t = lanes_reversed ? hi - 1 - (i - lo) : i;
                     Fiber& f = w.fibers[t];
-                    if (f.wait == FINISHED || f.wait == AT_BLOCK) continue;
+                    if (f.wait == FINISHED || f.wait == AT_BLOCK || f.wait == AT_SPIN) continue;
                     resume(w, f);            // RUNNABLE or AT_WAVE: run to its next yield
                 }
                 for (unsigned t = lo; t < hi; ++t) {
                     const int s = w.fibers[t].wait;
                     if (s == AT_WAVE) at_wave = true;
-                    else if (s == AT_BLOCK) other = true;
+                    else if (s == AT_BLOCK || s == AT_SPIN) other = true;
                 }
                 if (!at_wave) break;
                 if (other) {
@@ -195,11 +206,15 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
                     abort();
                 }
             }
-            for (unsigned t = lo; t < hi; ++t) any_alive |= w.fibers[t].wait == AT_BLOCK;
+            for (unsigned t = lo; t < hi; ++t) any_alive |= w.fibers[t].wait == AT_BLOCK || w.fibers[t].wait == AT_SPIN;
         }
         if (!any_alive) break;
+        // wavefronts polling LDS for another wavefront's progress (s_sleep) run again first; the
+        // ones at __syncthreads wait until nobody is polling any more
+        bool spinning = false;
+        for (unsigned t = 0; t < nt; ++t) spinning |= w.fibers[t].wait == AT_SPIN;
         for (unsigned t = 0; t < nt; ++t)
-            if (w.fibers[t].wait == AT_BLOCK) w.fibers[t].wait = RUNNABLE;
+            if (w.fibers[t].wait == (spinning ? AT_SPIN : AT_BLOCK)) w.fibers[t].wait = RUNNABLE;
     }
 }
 }  // namespace emu
@@ -210,6 +225,9 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
 #define gridDim (emu::t_worker.gridDim_)
 
 inline void __syncthreads() { emu::yield(emu::AT_BLOCK); }
+// s_sleep inside a polling loop: let the other wavefronts of the workgroup run
+inline void emu_s_sleep(int) { emu::yield(emu::AT_SPIN); }
+#define __builtin_amdgcn_s_sleep emu_s_sleep
 
 // ---- wavefront-level operations. Every live lane of a wavefront executes the same sequence
 // of them (the kernels call them under wave-uniform control flow only). A lane publishes its
@@ -252,7 +270,30 @@ inline int emu_update_dpp(int old, int v, int ctrl, int, int, bool bound_ctrl) {
     return has ? wv.xchg[g % 3][lane - N] : (bound_ctrl ? 0 : old);
 }
 #define __builtin_amdgcn_update_dpp emu_update_dpp
+
+// ds_bpermute_b32: lane L reads the value lane (byte_addr / 4) % 64 contributed
+inline int emu_ds_bpermute(int byte_addr, int v) {
+    emu::Worker& w = emu::t_worker;
+    emu::Fiber* f = w.cur;
+    emu::Wave& wv = w.waves[f->tid / 64];
+    const unsigned g = f->gen++, lane = f->tid % 64;
+    wv.xchg[g % 3][lane] = v;
+    emu::yield(emu::AT_WAVE);
+    wv.votes[(g + 2) % 3] = 0;
+    return wv.xchg[g % 3][((unsigned)byte_addr / 4) % 64];
+}
+#define __builtin_amdgcn_ds_bpermute emu_ds_bpermute
+#define __builtin_amdgcn_readfirstlane(x) (x)     // used on wavefront-uniform values only
+// LDS float atomic (ds_add_f32): the work-items of a workgroup are fibers of ONE OS thread
+inline float atomicAdd(float* p, float v) { float old = *p; *p = old + v; return old; }
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_s_memtime() 0ull
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+// v_sin_f32 / v_cos_f32: argument in revolutions
+inline float emu_sinf_rev(float x) { return (float)sin(6.283185307179586 * (double)x); }
+inline float emu_cosf_rev(float x) { return (float)cos(6.283185307179586 * (double)x); }
+#define __builtin_amdgcn_sinf emu_sinf_rev
+#define __builtin_amdgcn_cosf emu_cosf_rev
 
 inline float __log2f(float x) { return log2f(x); }          // v_log_f32 (1 ulp)
 inline int __ffs(int x) { return __builtin_ffs(x); }

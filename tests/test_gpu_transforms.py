@@ -264,7 +264,12 @@ def test_full_size_properties(S):
     assert lin < 5e-6, lin
     xb = np.stack([x, y])
     Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales=scales)
-    assert torch.equal(Txb[0], Tx) and torch.equal(Wxb[1], Wy)
+    Ty, Wy2, *_ = S.ssq_cwt(y, wav, scales=scales)
+    assert torch.equal(Txb[0], Tx) and torch.equal(Wxb[0], Wx)
+    assert torch.equal(Txb[1], Ty) and torch.equal(Wxb[1], Wy2)
+    # `cwt` (block kernels for every row) and the fused `ssq_cwt` (column tiles: most rows
+    # interpolated from decimated samples) evaluate the same rows in two ways
+    assert (Wy2 - Wy).abs().max().item() <= 6e-6 * Wy.abs().max().item()
 
 
 def test_full_size_bin_map_exact(S, orc):
@@ -324,8 +329,9 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
     assert relmax(Wx2, r['Wx']) <= tol and relmax(dWx2, r['dWx']) <= tol
     assert relmax(Wx, Wx2) <= tol
     # get_w / batched through the block path
-    out = S.ssq_cwt(x, wav, scales='log', nv=nv, get_w=True, astensor=False)
-    assert np.array_equal(out[4], orc.phase_cwt(out[1], dWx, r['gamma'], typing=0))
+    out = S.ssq_cwt(x, wav, scales='log', nv=nv, get_w=True, get_dWx=True, astensor=False)
+    assert np.array_equal(out[4], orc.phase_cwt(out[1], out[5], r['gamma'], typing=0))
+    assert relmax(out[1], Wx) <= tol / 2      # two-step form: every row on the block kernels
     xb = np.stack([x, x[::-1].copy()])
     Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
     assert np.array_equal(Wxb[0], Wx) and np.array_equal(Txb[0], Tx)
