@@ -186,6 +186,14 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
         else:
             segs.append([KIND_READBACK, first, nsteps, 0, 0, 0, 0, 0])
         i = j
+    if (len(rowdesc) // RSUB) % 2:                # the kernel takes its ticket once per pair of steps
+        last = rowdesc[-1]
+        for _ in range(RSUB):
+            rowdesc.append([(last[0] & 0xFFFF) - 2 ** 31, last[1], last[2], last[3]])
+        if segs[-1][0] == KIND_READBACK:
+            segs[-1][2] += 1
+        else:
+            segs.append([KIND_READBACK, len(rowdesc) // RSUB - 1, 1, 0, 0, 0, 0, 0])
     rowdesc = np.asarray(rowdesc, dtype=np.int32)
     segs = np.asarray(segs, dtype=np.int32)
 

@@ -50,7 +50,7 @@ struct TileArgs {
     const float* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
     int64_t N, na;
-    int nsteps, n1, mmask, sig0;
+    int nsteps, n1, mmask, sig0, nsig;
     float inv_m;         // 1 / M
     unsigned long long* trace;   // tuning aid (SSQ_TILE_TRACE): shader-clock stamps of one workgroup
     int dbg;             // tuning aid (SSQ_TILE_DBG): 1 = no Wx store, 2 = no tile update, 4 = no bin arithmetic
@@ -149,57 +149,118 @@ __device__ __attribute__((noinline)) int exact_bin(float2 W, float2 D, const Ssq
 #define TILE_STAMP(j, k)                                                                        \
     do { if (tr && (j) < 16 && c == 0) tr[((size_t)wv * 16 + (j)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
+// what a step needs to know about its tile (64 columns of one signal of the launch group)
+struct TileCtx {
+    int tx, sg;              // tile along time, signal of the group
+    int colc, nabs, nabs0;   // column of the lane (clamped), its padded index, padded index of column 0
+    bool colok;
+    int64_t obase;           // element offset of the signal in Wx / dWx / Tx
+    int64_t kbase;           // ... in the bin map of the group
+};
+
 template <int GRID, bool STORE_D, int NW>
 __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int c = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int s = blockIdx.y;
     const int64_t N = A.N;
+    const unsigned nN = (unsigned)N;
     const int na = (int)A.na, omax = na - 1;
-    const int col0 = blockIdx.x * TILE_COLS;
-    const int col = col0 + c;
-    const bool colok = col < N;
-    const int colc = colok ? col : (int)N - 1;               // loads stay in range
     float2* T = reinterpret_cast<float2*>(lds_raw);
     int* turn = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
+    int* done = turn + 1;
     for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
-    if (threadIdx.x == 0) *turn = 0;
+    if (threadIdx.x == 0) { *turn = 0; *done = 0; }
     __syncthreads();
     const int scratch = na * TILE_COLS + c;
-    unsigned long long* tr = (A.trace && blockIdx.x == 700 && blockIdx.y == 1) ? A.trace : nullptr;
+
+    // The workgroup is persistent: it walks the tiles blockIdx.x, + gridDim.x, ... One
+    // workgroup fills a CU (the Tx tile), so nothing else hides the head of a tile (first
+    // loads, first pair of steps: ~17 k cycles before the first update) and its tail (the last
+    // updates, 150 KiB of Tx written out): a wavefront that has finished its steps of tile i
+    // therefore goes on with the loads and the arithmetic of tile i + 1 and meets the others
+    // again only at the ticket.
+    const int ntx = (int)((N + TILE_COLS - 1) / TILE_COLS);
+    const int ntot = ntx * A.nsig;
+    const int ntl = ntot > (int)blockIdx.x ? (ntot - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    auto ctx_of = [&](int tx, int sg) {
+        TileCtx t;
+        t.tx = tx; t.sg = sg;
+        const int col0 = tx * TILE_COLS, col = col0 + c;
+        t.colok = col < N;
+        t.colc = t.colok ? col : (int)N - 1;                 // loads stay in range
+        t.nabs = A.n1 + t.colc; t.nabs0 = A.n1 + col0;
+        t.obase = (int64_t)(A.sig0 + sg) * na * N;
+        t.kbase = (int64_t)sg * na * N;
+        return t;
+    };
+    auto advance = [&](TileCtx& t) {                         // the workgroup's next tile
+        int tx = t.tx + (int)gridDim.x, sg = t.sg;
+        while (tx >= ntx) { tx -= ntx; ++sg; }
+        t = ctx_of(tx, sg);
+    };
+    unsigned long long* tr = (A.trace && blockIdx.x == 100) ? A.trace : nullptr;
     if (tr && threadIdx.x == 0) tr[16 * 16 * 8] = __builtin_amdgcn_s_memtime();
 
-    const unsigned nN = (unsigned)N;
-    const int64_t sigbase = (int64_t)(A.sig0 + s) * na * N;
-    float2* Wx = A.Wx + sigbase;
-    float2* dWx = STORE_D ? A.dWx + sigbase : nullptr;
-    const unsigned short* kidx = A.kidx + (int64_t)s * na * N;
-    const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
 
-    // Step and row records, tile twiddles and the reassignment weight are the same for every
-    // lane. They are fetched with vector loads from a lane-independent address (one request
-    // per wavefront) rather than scalar loads: scalar and LDS operations share one counter
-    // (lgkmcnt) and scalar loads return out of order, so a scalar load in flight turns every
-    // wait for a ds_bpermute result into a full drain.
+    // Step and row records and the reassignment weight are the same for every lane. They are
+    // fetched with vector loads from a lane-independent address (one request per wavefront)
+    // rather than scalar loads: scalar and LDS operations share one counter (lgkmcnt) and
+    // scalar loads return out of order, so a scalar load in flight turns every wait for a
+    // ds_bpermute result into a full drain.
     int vz = 0;
     SSQ_OPAQUE_V(vz);
     const int4* rows4 = reinterpret_cast<const int4*>(A.rows) + vz;
     const int4* steps4 = reinterpret_cast<const int4*>(A.steps) + vz;
     const float* cstv = A.cst + vz;
 
-    // This wavefront's steps: wv, wv + NW, ... -- consecutive steps of one wavefront are NW steps
-    // apart in the row list and usually of different decimation classes, so ONE software
-    // pipeline runs over all of them: records two steps ahead (they hold the addresses),
-    // samples / twiddles / interpolation weights one step ahead.
-    // (pairs of consecutive steps, wv-th pair of every NW: the ticket is taken once per pair)
-    const int npairs = (A.nsteps + 1) / 2;
+    // This wavefront's steps of a tile: the wv-th pair of consecutive steps of every NW pairs
+    // (the step list has an even number of steps) -- the ticket is taken once per pair.
+    // Consecutive pairs of one wavefront are NW pairs apart in the row list and usually of
+    // different decimation classes, so ONE software pipeline runs over all of them, across
+    // tiles: records two steps ahead (they hold the addresses), samples and interpolation
+    // weights one step ahead.
+    const int npairs = A.nsteps / 2;
     const int mypairs = npairs > wv ? (npairs - wv + NW - 1) / NW : 0;
-    const int nmine = mypairs == 0 ? 0 : 2 * mypairs - ((2 * (wv + (mypairs - 1) * NW) + 1 >= A.nsteps) ? 1 : 0);
-    auto gstep = [&](int j) { const int jj = j < nmine ? j : nmine - 1; return 2 * (wv + (jj >> 1) * NW) + (jj & 1); };
+    const int nmine = 2 * mypairs;                           // steps per tile
+    const int jtot = nmine * ntl;
+    auto gstep = [&](int j) { return 2 * (wv + (j >> 1) * NW) + (j & 1); };
+    auto tbase = [&](int itl) { return itl * (npairs + 2); };   // ticket of the tile's first pair
+
+    // rows k = wv, wv + NW, ... of the finished tile go to Tx and are cleared; the last
+    // wavefront to finish opens the next tile's tickets
+    auto write_out = [&](const TileCtx& t, int itl) {
+        take_turn(turn, tbase(itl) + npairs);
+        float2* Tx = A.Tx + t.obase;
+        const int col = t.tx * TILE_COLS + c;
+        for (int k0 = wv; k0 < na; k0 += 8 * NW) {          // 8 rows in flight per wavefront
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int k = k0 + u * NW; v[u] = T[(k < na ? k : na) * TILE_COLS + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * NW;
+                if (k < na) {
+                    T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+                    if (t.colok) Tx[(unsigned)k * nN + (unsigned)col] = v[u];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (c == 0) {
+            const int before = __atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL);
+            if (before + 1 == NW * (itl + 1)) __atomic_store_n(turn, tbase(itl + 1), __ATOMIC_RELEASE);
+        }
+    };
+    if (nmine == 0) {                                        // more wavefronts than pairs of steps
+        TileCtx t = ctx_of((int)blockIdx.x % ntx, (int)blockIdx.x / ntx);
+        for (int itl = 0; itl < ntl; ++itl) { write_out(t, itl); advance(t); }
+        return;
+    }
+
     int4 sa[2], sb[2], rec[2][TILE_G];        // step (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
     auto load_rec = [&](int q, int j) {
         const int g = gstep(j);
@@ -210,15 +271,16 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     float2 xu[2][TILE_G];
     float xc[2][TILE_G], xt[2][TILE_G]; int xr[2][TILE_G], xkc[2][TILE_G]; unsigned short xk[2][TILE_G];
     float4 xw[2][4]; int xkind[2], xbaddr[2], xwoff[2] = {-1, -1};
-    auto load = [&](int b, int q, int j) {
-        const int g = gstep(j);
+    auto load = [&](int b, int q, const TileCtx& t) {
         const int kind = sa[q].x;
         xkind[b] = kind;
         if (kind == 0) {                                     // rows read back: Wx, bin
+            const float2* Wx = A.Wx + t.obase;
+            const unsigned short* kidx = A.kidx + t.kbase;
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) {
                 const int row = rec[q][r].x & 0xFFFF;
-                const unsigned o = (unsigned)row * nN + (unsigned)colc;
+                const unsigned o = (unsigned)row * nN + (unsigned)t.colc;
                 xr[b][r] = rec[q][r].x;
                 xu[b][r] = Wx[o];
                 xk[b][r] = kidx[o];
@@ -233,18 +295,18 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             xwoff[b] = sb[q].x;
             if (same) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xw[1][t] = xw[0][t];
+                for (int u = 0; u < 4; ++u) xw[1][u] = xw[0][u];
             } else {
-                const float4* wp = A.wtab + (int64_t)(sb[q].x + (nabs & ((1 << lgR) - 1))) * 4;
+                const float4* wp = A.wtab + (int64_t)(sb[q].x + (t.nabs & ((1 << lgR) - 1))) * 4;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) xw[b][t] = wp[t];
+                for (int u = 0; u < 4; ++u) xw[b][u] = wp[u];
             }
-            const int q0 = nabs >> lgR, qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
+            const int q0 = t.nabs >> lgR, qb = (t.nabs0 >> lgR) - (TILE_W / 2 - 1);
             // the sample this lane holds (lanes past the widest window any lane needs repeat the last one)
             const int wlast = (63 >> lgR) + TILE_W;
             const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb[q].z);
             xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
-            const float2* Ub = A.U + sb[q].w + (int64_t)s * sb[q].y;
+            const float2* Ub = A.U + sb[q].w + (int64_t)t.sg * sb[q].y;
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) {
                 const int4 d = rec[q][r];
@@ -254,29 +316,39 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             }
         }
     };
-    if (nmine > 0) { load_rec(0, 0); load_rec(1, 1); load(0, 0, 0); }
-    for (int j = 0; j < nmine; j += 2) {
+
+    TileCtx tc = ctx_of((int)blockIdx.x % ntx, (int)blockIdx.x / ntx);   // tile of the step computed
+    TileCtx tl = tc;                                                       // tile of the step loaded
+    TileCtx tp = tc;                                                       // previous tile (to write out)
+    int jl = 0, jc = 0, itl = 0;              // step inside the tile (loads / arithmetic), tile count
+    load_rec(0, 0); load_rec(1, 1 % nmine); load(0, 0, tl);
+    int jr = 2 % nmine;                       // step whose records are loaded next
+    if (++jl == nmine) { jl = 0; advance(tl); }
+    for (int jj = 0; jj < jtot; jj += 2) {
         int cells[2][TILE_G]; float2 vs[2][TILE_G];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            if (j + b >= nmine) break;
-            TILE_STAMP(j + b, 0);
-            load(b ^ 1, 1, j + b + 1);
+            if (tr && itl == 2) TILE_STAMP(jc + b, 0);
+            if (jj + b + 1 < jtot) load(b ^ 1, 1, tl);
+            if (++jl == nmine) { jl = 0; advance(tl); }
             sa[0] = sa[1]; sb[0] = sb[1];
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) rec[0][r] = rec[1][r];
-            load_rec(1, j + b + 2);
+            load_rec(1, jr);
+            if (++jr == nmine) jr = 0;
             int (&cell)[TILE_G] = cells[b]; float2 (&v)[TILE_G] = vs[b];
-            TILE_STAMP(j + b, 1);
+            if (tr && itl == 2) TILE_STAMP(jc + b, 1);
             if (__builtin_amdgcn_readfirstlane(xkind[b]) == 0) {
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
                     const int kk = xk[b][r];
-                    const bool act = xr[b][r] >= 0 && colok && kk != 0xFFFF;
+                    const bool act = xr[b][r] >= 0 && tc.colok && kk != 0xFFFF;
                     cell[r] = act ? kk * TILE_COLS + c : scratch;
                     v[r] = act ? make_float2(xu[b][r].x * xc[b][r], xu[b][r].y * xc[b][r]) : make_float2(0.f, 0.f);
                 }
             } else {
+                float2* Wx = A.Wx + tc.obase;
+                float2* dWx = STORE_D ? A.dWx + tc.obase : nullptr;
                 ssq_f2 wt[TILE_W];                               // (phi_t, phi'_t / (R dt))
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -326,7 +398,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
                     // (M <= 2^24), v_sin_f32 / v_cos_f32 take revolutions (measured on the
                     // M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
-                    const float rev = (float)(((unsigned)xkc[b][r] * (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;
+                    const float rev = (float)(((unsigned)xkc[b][r] * (unsigned)tc.nabs) & (unsigned)A.mmask) * A.inv_m;
                     const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
                     const float2 Wv = cmulf(tw, make_float2(are, aim));
                     const float2 Dv = cmulf(tw, make_float2(dre, dim));
@@ -334,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     // and lanes past the last column repeat its point; neither contributes below)
                     const int row = xr[b][r] & 0xFFFF;
                     const bool pad = xr[b][r] < 0;
-                    const unsigned o = (unsigned)row * nN + (unsigned)colc;
+                    const unsigned o = (unsigned)row * nN + (unsigned)tc.colc;
                     Wx[o] = Wv;
                     if (STORE_D) dWx[o] = Dv;
                     // phase transform and bin: as emit_point<LEAN> of the block kernels
@@ -345,7 +417,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     bool ok;
                     const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
                     const int kf = (kb ^ fx) + fa;
-                    const bool live = colok && !pad;
+                    const bool live = tc.colok && !pad;
                     // undecided by the float32 screens (rare): the exact double path, once per step
                     if (live && !(below | (above & ok))) pend |= 1u << r;
                     const bool act = above && live;
@@ -363,38 +435,28 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                         }
                 }
             }
-            TILE_STAMP(j + b, 2);
+            if (tr && itl == 2) TILE_STAMP(jc + b, 2);
         }
-        if (!(A.dbg & 2)) {
-            const int g = gstep(j);
-            const bool two = j + 1 < nmine;
-            int src[2][TILE_G];
-            forward4(cells[0], src[0]);
-            if (two) forward4(cells[1], src[1]);
-            // the wavefront that holds the turn is the critical path of the workgroup
-            __builtin_amdgcn_s_setprio(3);
-            take_turn(turn, g);
-            TILE_STAMP(j, 3);
-            update4(T, cells[0], vs[0], src[0]);
-            if (two) update4(T, cells[1], vs[1], src[1]);
-            pass_turn(turn, g + (two ? 1 : 0), c);
-            __builtin_amdgcn_s_setprio(0);
-            TILE_STAMP(j, 4);
-        } else if (vs[0][0].x == 12345.f) T[cells[0][0]].x = vs[0][1].x + vs[1][2].x + vs[1][3].x;
-    }
-    if (tr && c == 0) tr[16 * 16 * 8 + 1 + wv] = __builtin_amdgcn_s_memtime();
-    __syncthreads();
-    float2* Tx = A.Tx + sigbase;
-    for (int k0 = wv; k0 < na; k0 += 8 * NW) {              // 8 rows in flight per wavefront
-        float2 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const int k = k0 + u * NW; t[u] = T[(k < na ? k : 0) * TILE_COLS + c]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * NW;
-            if (k < na && colok) Tx[(unsigned)k * nN + (unsigned)col] = t[u];
+        // the pair's update, in ticket order (the previous tile is written out first)
+        int src[2][TILE_G];
+        forward4(cells[0], src[0]);
+        forward4(cells[1], src[1]);
+        if (jc == 0 && itl > 0) {
+            if (tr && itl == 2) TILE_STAMP(0, 5);
+            write_out(tp, itl - 1);
+            if (tr && itl == 2) TILE_STAMP(0, 6);
         }
+        const int g = tbase(itl) + (gstep(jc) >> 1);
+        take_turn(turn, g);
+        if (tr && itl == 2) TILE_STAMP(jc, 3);
+        update4(T, cells[0], vs[0], src[0]);
+        update4(T, cells[1], vs[1], src[1]);
+        pass_turn(turn, g, c);
+        if (tr && itl == 2) TILE_STAMP(jc, 4);
+        jc += 2;
+        if (jc == nmine) { jc = 0; ++itl; tp = tc; advance(tc); }
     }
+    write_out(tp, ntl - 1);
     if (tr && c == 0) tr[16 * 16 * 8 + 20 + wv] = __builtin_amdgcn_s_memtime();
 }
 
@@ -403,7 +465,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                      int64_t& bytes) {
     M = M_; N = N_; n1 = n1_; na = na_; group = group_;
     nsegs = d.n_segs; nsteps = d.n_steps; n_irows = d.n_irows; u_total = d.u_total;
-    SSQ_REQUIRE(nsegs >= 1 && nsteps >= 1 && n_irows >= 1 && d.n_classes >= 1, "empty tile tables");
+    SSQ_REQUIRE(nsegs >= 1 && nsteps >= 2 && nsteps % 2 == 0 && n_irows >= 1 && d.n_classes >= 1,
+                "empty tile tables or an odd number of steps");
     SSQ_REQUIRE((size_t)(na + 1) * TILE_COLS * 8 + 16 <= 160 * 1024 && na * N < ((int64_t)1 << 29), "na = %lld: the Tx tile exceeds the LDS",
                 (long long)na);
     SSQ_REQUIRE((int64_t)group * u_total < ((int64_t)1 << 31), "tile intermediates exceed 2^31 entries");
@@ -491,8 +554,17 @@ static int launch_tile_k(const TileArgs& A, const SsqParams& sp, int64_t N, int6
     const size_t lds = (size_t)(na + 1) * TILE_COLS * 8 + 16;
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const dim3 grid((unsigned)((N + TILE_COLS - 1) / TILE_COLS), (unsigned)nsig);
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, A, sp);
+    // persistent workgroups, one per CU (the tile fills the LDS)
+    static const int ncu = [] {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+        if (const char* e = getenv("SSQ_TILE_GRID")) return atoi(e) > 0 ? atoi(e) : pr.multiProcessorCount;
+        return pr.multiProcessorCount;
+    }();
+    const int64_t ntot = ((N + TILE_COLS - 1) / TILE_COLS) * nsig;
+    const dim3 grid((unsigned)std::min<int64_t>(ntot, ncu));
+    TileArgs B = A; B.nsig = nsig;
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }

@@ -74,9 +74,10 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* c) { *c = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->name, "host emulation"); strcpy(p->gcnArchName, "host");
-    p->multiProcessorCount = 1; p->totalGlobalMem = 0;
+    p->multiProcessorCount = 3; p->totalGlobalMem = 0;
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }
