@@ -1,0 +1,183 @@
+# -*- coding: utf-8 -*-
+"""BASELINE.json's configurations at FULL size against the CPU oracle -- the file sorts
+first so that these run before every other GPU test.
+
+The reference pins its GPU path at transform level by comparing it with its own CPU path on
+the same input (tests/fft_test.py:444-471). Here the CPU side is the oracle (oracle/: the
+reference's algorithm -- dense bank, full-length scipy.fft -- pinned bit for bit to fixtures
+generated from the reference), and the sizes are the benchmarked ones:
+
+  C2  ssq_cwt  N=160 000, 300 log scales, float32   Wx, dWx <= 1e-5 of the oracle's maximum
+  C5  ssq_cwt  N=1 048 576, 512 log scales, float64 Wx, dWx <= 1e-12, oracle in scale slabs
+  C3  ssq_stft N=160 000, n_fft=1024, hop=256, f32  Sx, dSx <= 1e-5
+  (C1 is the reference's own CPU plumbing case; its GPU counterpart is checked as `cwt` here.)
+
+`Tx` is an index computation on top of those: it is compared bit for bit with the oracle's
+reassignment of the device's own (Wx, dWx) -- every bin index and the summation order -- and
+through its assignment-invariant column sums with the oracle's end-to-end `Tx`.
+"""
+import os
+import numpy as np
+import pytest
+
+from conftest import compute_module, two_chirps
+from pipeline import oracle_ssq_stft, GRIDNAME
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def S():
+    yield from compute_module()
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if hasattr(t, 'detach') else np.asarray(t)
+
+
+def _workers():
+    return max(1, min(64, os.cpu_count() or 1))
+
+
+def _ssq_design(S, scales, N, wav):
+    from ssqueezepy_amd.scales import process_scales
+    from ssqueezepy_amd.ssqueezing import (_compute_associated_frequencies, ssq_grid_params,
+                                           ssq_const)
+    sc_ssq, st2, _, nv2 = process_scales(np.asarray(scales).squeeze(), N, get_params=True)
+    ssq_freqs = _compute_associated_frequencies(sc_ssq, N, wav, st2, 'peak', True, 1., 'cwt')
+    const = ssq_const('cwt', st2, nv2, sc_ssq, ssq_freqs)
+    grid, p = ssq_grid_params(ssq_freqs, True)
+    return ssq_freqs, const, GRIDNAME[grid], p
+
+
+def test_config2_ssq_cwt_full_size_vs_oracle(S, orc):
+    """C2, the benchmarked shape, through the benchmarked path (column tiles)."""
+    from ssqueezepy_amd import _cwt
+    from ssqueezepy_amd.padding import pad_geometry
+    N, na = 160000, 300
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    x = two_chirps(N, seed=0)
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True, astensor=False)
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+    if os.environ.get('SSQ_CWT_TILES', '1') != '0' and os.environ.get('SSQ_EMULATE') != '1':
+        assert 'tiles' in plan.algo and plan.tile_rows > 0.7 * na, plan.algo
+
+    # the reference's algorithm: dense (na, M) bank, two length-M inverse FFTs per row
+    sc32 = np.asarray(scales, dtype='float32')
+    M, n1, _ = pad_geometry(N)
+    Psih = wav(scale=sc32, N=M, nohalf=False)
+    xi = wav.xifn(1., M).reshape(-1)
+    Wr, dWr = orc.cwt(x, Psih, xi, 1., n1, N, derivative=True, workers=_workers())
+    del Psih
+    assert Wx.shape == Wr.shape == (na, N) and Wx.dtype == np.complex64
+    eW = np.abs(Wx - Wr).max(axis=1) / np.abs(Wr).max()
+    eD = np.abs(dWx - dWr).max(axis=1) / np.abs(dWr).max()
+    assert eW.max() <= 1e-5 and eD.max() <= 1e-5, (eW.max(), int(eW.argmax()), eD.max(), int(eD.argmax()))
+
+    ssq_freqs, const, grid, p = _ssq_design(S, sc32, N, wav)
+    assert np.array_equal(sf, ssq_freqs[::-1])
+    gamma = 10 * np.finfo(np.float32).eps
+    # every bin index and the summation order, on the device's own (Wx, dWx)
+    ref = orc.ssqueeze(Wx, dWx, grid, p, const, gamma, True, typing=0, parallel=True)
+    assert np.array_equal(Tx, ref)
+    # the oracle end to end: sum_k Tx[k, j] does not depend on the bin a point lands in
+    Tr = orc.ssqueeze(Wr, dWr, grid, p, const, gamma, True, typing=0, parallel=True)
+    cs, cr = Tx.sum(0), Tr.sum(0)
+    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    # ... and the two maps agree except where a 1e-6 difference of Wx moves a point across a
+    # bin boundary
+    moved = np.abs(Tx - Tr).sum() / np.abs(Tr).sum()
+    assert moved <= 2e-2, moved
+
+    # the same rows through `cwt` (block kernels for every row)
+    W2, _, dW2 = S.cwt(x, wav, scales=scales, derivative=True, astensor=False)
+    assert np.abs(W2 - Wr).max() <= 1e-5 * np.abs(Wr).max()
+    assert np.abs(dW2 - dWr).max() <= 1e-5 * np.abs(dWr).max()
+
+
+def test_config5_ssq_cwt_float64_long_vs_oracle(S, orc):
+    """C5: float64, N = 2^20, 512 scales; the oracle is evaluated in slabs of 32 scales
+    (a dense (512, 2^21) complex128 product would be 17 GB per array)."""
+    import torch
+    from ssqueezepy_amd import _cwt
+    from ssqueezepy_amd.padding import pad_geometry
+    import scipy.fft as sfft
+    N, na = 1 << 20, 512
+    wav = S.Wavelet(('gmw', {'dtype': 'float64'}))
+    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    x = two_chirps(N, seed=5)
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True)
+    assert tuple(Wx.shape) == (na, N) and Wx.dtype == torch.complex128
+    sc64 = np.asarray(scales, dtype='float64').reshape(-1)
+    M, n1, n2 = pad_geometry(N)
+    xp = np.pad(x.astype(np.float64), (n1, n2), mode='reflect')
+    xh = sfft.fft(xp, workers=_workers())
+    xi = wav.xifn(1., M).reshape(-1)
+    wmax = float(torch.abs(Wx).max()); dmax = float(torch.abs(dWx).max())
+    worst = [0.0, 0.0]
+    slab = 32
+    for r0 in range(0, na, slab):
+        Psih = wav(scale=sc64[r0:r0 + slab], N=M, nohalf=False)
+        prod = Psih * xh
+        Wr = sfft.ifft(prod, axis=-1, workers=_workers())[:, n1:n1 + N]
+        worst[0] = max(worst[0], np.abs(_np(Wx[r0:r0 + slab]) - Wr).max() / wmax)
+        prod *= (1j * xi / 1.)
+        dWr = sfft.ifft(prod, axis=-1, workers=_workers())[:, n1:n1 + N]
+        worst[1] = max(worst[1], np.abs(_np(dWx[r0:r0 + slab]) - dWr).max() / dmax)
+        del Psih, prod, Wr, dWr
+    assert worst[0] <= 1e-12 and worst[1] <= 1e-12, worst
+
+    # reassignment: columns are independent -- three column slabs, bit for bit
+    ssq_freqs, const, grid, p = _ssq_design(S, sc64, N, wav)
+    assert np.array_equal(sf, ssq_freqs[::-1])
+    gamma = 10 * np.finfo(np.float64).eps
+    for j0 in (0, N // 2 - 4096, N - 32768):
+        j1 = j0 + 32768
+        W = np.ascontiguousarray(_np(Wx[:, j0:j1])); D = np.ascontiguousarray(_np(dWx[:, j0:j1]))
+        ref = orc.ssqueeze(W, D, grid, p, const, gamma, True, typing=0, parallel=True)
+        assert np.array_equal(_np(Tx[:, j0:j1]), ref), j0
+    # assignment-invariant checksum over the whole transform
+    lhs, rhs = Tx.sum(0), (Wx * float(const)).sum(0)
+    assert float((lhs - rhs).abs().max()) <= 1e-12 * float(rhs.abs().max())
+
+
+def test_config3_ssq_stft_full_size_vs_oracle(S, orc):
+    """C3: ssq_stft N=160 000, n_fft=1024, hop=256, float32 (fused STFT kernel)."""
+    N = 160000
+    x = two_chirps(N, seed=3)
+    Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=1024, hop_len=256, dtype='float32',
+                                      get_dWx=True, astensor=False)
+    r = oracle_ssq_stft(orc, x, 'float32', n_fft=1024, hop_len=256)
+    assert Sx.shape == r['Sx'].shape == (513, N // 256)
+    assert np.abs(Sx - r['Sx']).max() <= 1e-5 * np.abs(r['Sx']).max()
+    assert np.abs(dSx - r['dSx']).max() <= 1e-5 * np.abs(r['dSx']).max()
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    _, p = ssq_grid_params(r['Sfs'], False)
+    ref = orc.ssqueeze(Sx, dSx, 'linear', p, r['Sfs'][1] - r['Sfs'][0], r['gamma'], False,
+                       Sfs=r['Sfs'], typing=0)
+    assert np.array_equal(Tx, ref)
+    cs, cr = Tx.sum(0), r['Tx'].sum(0)
+    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    # batched == single, as the bench runs it
+    xb = np.stack([x, two_chirps(N, seed=4)])
+    Tb, Sb, *_ = S.ssq_stft(xb, n_fft=1024, hop_len=256, dtype='float32', astensor=False)
+    assert np.array_equal(Tb[0], Tx) and np.array_equal(Sb[0], Sx)
+
+
+def test_config1_cwt_vs_oracle(S, orc):
+    """C1's shape (cwt('gmw'), N=10 000, 300 scales, float32) on the device."""
+    from ssqueezepy_amd.padding import pad_geometry
+    N, na = 10000, 300
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    x = two_chirps(N, seed=1)
+    Wx, sc, dWx = S.cwt(x, wav, scales=scales, derivative=True, astensor=False)
+    sc32 = np.asarray(scales, dtype='float32')
+    M, n1, _ = pad_geometry(N)
+    Wr, dWr = orc.cwt(x, wav(scale=sc32, N=M, nohalf=False), wav.xifn(1., M).reshape(-1),
+                      1., n1, N, derivative=True)
+    assert np.abs(Wx - Wr).max() <= 1e-5 * np.abs(Wr).max()
+    assert np.abs(dWx - dWr).max() <= 1e-5 * np.abs(dWr).max()
