@@ -55,6 +55,39 @@ def emulated():
     patch(torch.cuda, 'current_device', lambda: 0)
     patch(torch.Tensor, 'is_cuda', property(lambda self: True))
     patch(torch.Tensor, 'cuda', lambda self, *a, **k: self)
+    # On the GPU a device tensor cannot be handed to NumPy (np.asarray(t), t.numpy()) without
+    # .cpu(); here tensors live on the host, so that mistake would pass unnoticed (it cost round 1
+    # its GPU suite). Emulated tensors therefore refuse the conversion unless they went through
+    # .cpu() -- which hands out a flagged alias.
+    orig_numpy, orig_cpu = torch.Tensor.numpy, torch.Tensor.cpu
+
+    def guarded_numpy(self, *a, **k):
+        if not getattr(self, '_ssq_on_host', False):
+            raise TypeError("can't convert cuda:0 device type tensor to numpy. Use Tensor.cpu() "
+                            "to copy the tensor to host memory first. (emulated device tensor)")
+        return orig_numpy(self, *a, **k)
+
+    def to_host(self, *a, **k):
+        t = self.detach() if not self.requires_grad else self.view_as(self)
+        t._ssq_on_host = True
+        return t
+
+    host_inputs = (torch.from_numpy, torch.as_tensor, torch.tensor)
+
+    def flagged(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrap(*a, **k):
+            t = fn(*a, **k)
+            if isinstance(t, torch.Tensor) and k.get('device') is None:
+                t._ssq_on_host = True       # a tensor the caller built on the host stays a host tensor
+            return t
+        return wrap
+    patch(torch.Tensor, 'numpy', guarded_numpy)
+    patch(torch.Tensor, 'cpu', to_host)
+    for fn in host_inputs:
+        patch(torch, fn.__name__, flagged(fn))
     try:
         yield ssqueezepy_amd
     finally:

@@ -102,3 +102,28 @@ def test_cwt_autograd(S, monkeypatch):
     monkeypatch.setenv('SSQ_EMULATE', '1')        # the test places its tensors accordingly
     test_cwt_is_differentiable(S, 'float64', 'reflect', True)
     test_cwt_is_differentiable(S, 'float32', 'zero', False)
+
+
+def test_custom_wavelet_functions_do_not_share_cached_plans():
+    """Two different user-supplied wavelet functions created one after the other (CPython
+    reuses the id() of a freed function object) must not hit each other's cached plan or
+    design: the cache key holds the function itself (wavelets.py `key`)."""
+    from ssqueezepy_amd.wavelets import Wavelet
+    keys = []
+    for mu in (5., 6., 7.):
+        w = Wavelet(lambda om, mu=mu: np.exp(-(om - mu) ** 2))
+        keys.append(w.key())
+        del w
+    assert len(set(keys)) == 3 and keys[0] != keys[1] != keys[2]
+    f = lambda om: np.exp(-(om - 5.) ** 2)
+    assert Wavelet(f).key() == Wavelet(f).key()          # the same function: the same plan
+    import emu_backend
+    x = np.cos(2 * np.pi * 0.05 * np.arange(600)) + 0.3 * np.cos(2 * np.pi * 0.21 * np.arange(600))
+    outs = []
+    with emu_backend.emulated() as S:
+        for mu in (5., 9.):
+            def make(mu):
+                return lambda om: np.exp(-(om - mu) ** 2) * (om > 0)
+            Wx, sc = S.cwt(x, S.Wavelet(make(mu)), scales=2 ** np.arange(1, 6, 0.25), astensor=False)
+            outs.append(Wx)
+    assert outs[0].shape == outs[1].shape and np.abs(outs[0] - outs[1]).max() > 1e-3
