@@ -57,6 +57,9 @@ def cpu_baseline(N, na, seconds_budget=25.0):
     from ssqueezepy_amd.scales import process_scales
     import scipy.fft as sfft
     cores = os.cpu_count() or 1
+    # pocketfft's thread pool stops scaling long before 256 threads on a (300, 2^18) batch
+    # (round 1 ran it with workers = all cores: 0.83 s per transform); 64 is the knee
+    fft_workers = max(1, min(cores, 64))
     orc.lib()
     wav = Wavelet()
     scales = process_scales('log', N, wav, nv=32)[:na]
@@ -79,7 +82,7 @@ def cpu_baseline(N, na, seconds_budget=25.0):
     gamma = 10 * np.finfo(np.float32).eps
 
     def one():
-        Wx, dWx = orc.cwt(x, Psih, xi, 1., n1, N, derivative=True, workers=cores)
+        Wx, dWx = orc.cwt(x, Psih, xi, 1., n1, N, derivative=True, workers=fft_workers)
         return orc.ssqueeze(Wx, dWx, 'log', p, const, gamma, True, parallel=True)
 
     one()
@@ -92,8 +95,11 @@ def cpu_baseline(N, na, seconds_budget=25.0):
     return {"value": 1.0 / dt, "unit": "transforms/s", "cores": cores,
             "kind": "port",
             "sample": "%d ssq_cwt transforms of the same workload (N=%d, %d scales, "
-                      "float32; scipy.fft workers=%d + OpenMP loop nests; wavelet "
-                      "bank cached as in examples/benchmarks.py)" % (runs, N, na, cores)}
+                      "float32; scipy.fft workers=%d + OpenMP loop nests on %d cores; wavelet "
+                      "bank cached as in examples/benchmarks.py). kind 'port': the oracle's "
+                      "restatement of the reference's CPU algorithm -- ssqueezepy itself "
+                      "(numba, SSQ_PARALLEL=1) is not installable on the GPU box"
+                      % (runs, N, na, fft_workers, cores)}
 
 
 def main():
@@ -110,6 +116,23 @@ def main():
                          '(reported separately; `value` never includes it)')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU,
+    # torch.distributed.run, rendezvous on 127.0.0.1); under a launcher the ranks are already
+    # there and --gpus must agree with WORLD_SIZE
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+               '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+    if int(os.environ.get('WORLD_SIZE', 1)) != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get('WORLD_SIZE', '1')))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', 0))
@@ -122,6 +145,9 @@ def main():
         local_rank = 0
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if not os.environ.get('SSQ_BENCH_ONE_DEVICE'):
+            assert torch.cuda.device_count() >= world, \
+                "%d ranks but %d GPUs visible" % (world, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
@@ -224,7 +250,7 @@ def main():
                 traffic = json.load(fh).get('bytes_per_transform')
         line = {
             "metric": "ssq_cwt transforms/sec (N=160k, 300 scales, f32)",
-            "value": value, "unit": "transforms/s", "n_gpus": world,
+            "value": value, "unit": "transforms/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -248,13 +274,20 @@ def main():
                 "transforms_per_s": B * world / (gather_ms * 1e-3),
                 "gathered_bytes_per_rank": int((world - 1) * B * na * N * 8)}
         if stages:
-            # the single largest kernel is the reassignment (one launch per transform);
-            # it moves Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point
-            acc_bytes = na * N * 18
             line["stages_us_per_transform"] = stages
             grp = min(plan.group, B)
+            tiles = 'tiles' in plan.algo
+            if tiles:
+                # the column-tile kernel: writes Wx of the rows it interpolates and all of Tx,
+                # reads Wx + 2-byte bin of the rows the block / exact kernels left in HBM
+                kname = "ssq::tile_kernel"
+                acc_bytes = N * (plan.tile_rows * 8 + na * 8 + (na - plan.tile_rows) * 10)
+            else:
+                # the reassignment: Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point
+                kname = "ssq::accumulate_tile16_kernel"
+                acc_bytes = na * N * 18
             line["dominant_kernel"] = {
-                "name": "ssq::accumulate_tile16_kernel", "us": stages["reassignment_us"],
+                "name": kname, "us": stages["reassignment_us"],
                 "signals_per_launch": grp,
                 "us_per_launch": stages["reassignment_us"] * grp,
                 "bytes_moved": acc_bytes,

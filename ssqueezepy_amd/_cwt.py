@@ -330,10 +330,17 @@ class _CwtFunction(torch.autograd.Function):
 
 _PLAN_CACHE = {}
 _PLAN_CACHE_MAX = 8
+# plans hold their workspace outside torch's allocator (hipMalloc): bound the cache by bytes
+# too -- the oldest plans go first
+_PLAN_CACHE_MAX_BYTES = int(os.environ.get('SSQ_PLAN_CACHE_GB', '32')) << 30
 
 
 def clear_plan_cache():
+    """Drop every cached plan of this package -- CWT and STFT (the plans' device memory lives
+    outside torch's allocator; `torch.cuda.empty_cache()` does not reach it)."""
     _PLAN_CACHE.clear()
+    from . import _stft
+    _stft.clear_plan_cache()
 
 
 def get_cwt_plan(wavelet, scales, N, padtype, dt, l1_norm, batch, cache=True):
@@ -349,7 +356,10 @@ def get_cwt_plan(wavelet, scales, N, padtype, dt, l1_norm, batch, cache=True):
     plan = CwtPlan(wavelet, scales, N, padtype=padtype, dt=dt, l1_norm=l1_norm,
                    max_batch=batch)
     if cache:
-        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+        _PLAN_CACHE.pop(key, None)          # a smaller-batch plan of the same configuration
+        while _PLAN_CACHE and (len(_PLAN_CACHE) >= _PLAN_CACHE_MAX or
+                               sum(p.device_bytes for p in _PLAN_CACHE.values())
+                               + plan.device_bytes > _PLAN_CACHE_MAX_BYTES):
             _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
         _PLAN_CACHE[key] = plan
     return plan

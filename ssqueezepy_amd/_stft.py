@@ -216,6 +216,11 @@ class StftPlan():
 _PLAN_CACHE = {}
 
 
+def clear_plan_cache():
+    """Drop the cached STFT plans (their device workspace is freed with them)."""
+    _PLAN_CACHE.clear()
+
+
 def get_stft_plan(N, n_fft, hop_len, window, diff_window, fs, padtype, modulated,
                   dtype, batch):
     key = (int(N), int(n_fft), int(hop_len), np.asarray(window).tobytes(),
@@ -226,6 +231,7 @@ def get_stft_plan(N, n_fft, hop_len, window, diff_window, fs, padtype, modulated
         return plan
     plan = StftPlan(N, n_fft, hop_len, window, diff_window, fs, padtype, modulated,
                     dtype, batch)
+    _PLAN_CACHE.pop(key, None)
     if len(_PLAN_CACHE) >= 8:
         _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
     _PLAN_CACHE[key] = plan

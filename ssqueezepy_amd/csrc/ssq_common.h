@@ -5,6 +5,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <vector>
 #include "../../include/ssq_hip.h"
 
 // make the compiler treat a value as lane-dependent (keeps a load of a lane-independent
@@ -61,6 +63,48 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// A cached plan owns device workspaces that every execute reuses. Executes are asynchronous
+// and torch's side streams do not synchronise with each other, so two executes of one plan on
+// different streams (or from two host threads) would overwrite each other's workspace. `enter`
+// makes the new stream wait for the plan's previous execute (one event, recorded by `leave`);
+// the mutex serialises the host side for the duration of the enqueue.
+struct PlanOrder {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool used = false;
+    int enter(hipStream_t s) {
+        mu.lock();
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return 0; }
+        if (used && last != s) (void)hipStreamWaitEvent(s, ev, 0);
+        return 0;
+    }
+    void leave(hipStream_t s) {
+        if (ev) { (void)hipEventRecord(ev, s); used = true; last = s; }
+        mu.unlock();
+    }
+    void destroy() { if (ev) (void)hipEventDestroy(ev); ev = nullptr; }
+};
+// per-row reassignment weights on the device: a new buffer for every new content (an execute
+// already enqueued keeps reading the one it was given); all freed with the plan
+struct WeightVersions {
+    std::vector<void*> bufs;
+    int upload(void** current, const void* host, size_t bytes) {
+        void* p = nullptr;
+        if (bufs.size() >= 32) {                 // bounded: recycle after draining the device
+            (void)hipDeviceSynchronize();
+            for (size_t i = 0; i + 1 < bufs.size(); ++i) (void)hipFree(bufs[i]);
+            void* keep = bufs.back(); bufs.clear(); bufs.push_back(keep);
+        }
+        SSQ_CHECK_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        SSQ_CHECK_HIP(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice));
+        bufs.push_back(p);
+        *current = p;
+        return 0;
+    }
+    void destroy() { for (void* p : bufs) (void)hipFree(p); bufs.clear(); }
+};
 
 template <typename T> struct cplx { T re, im; };
 

@@ -142,7 +142,9 @@ struct ssq_cwt_plan {
     FftPlan fwd;                          // R2C, batch = max_batch
     std::map<int64_t, FftPlan> inv;       // C2C inverse keyed by transform count
     // ssq
-    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr;
+    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr;   // cst: the current entry of `weights`
+    WeightVersions weights;
+    PlanOrder order;
     std::string algo = "rocfft";
     // rows evaluated by the exact full-length path (all rows unless a block plan
     // took some over)
@@ -243,8 +245,10 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     if (pl->blk) { pl->blk->destroy(); delete pl->blk; }
     if (pl->tile) { pl->tile->destroy(); delete pl->tile; }
     for (hipEvent_t e : pl->tev) (void)hipEventDestroy(e);
+    pl->weights.destroy();
+    pl->order.destroy();
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
-                    pl->kidx, pl->cst, pl->gen_rows, pl->all_rows};
+                    pl->kidx, pl->gen_rows, pl->all_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -253,6 +257,7 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
                          int cst_f64, int flipud, double gamma) {
     SSQ_REQUIRE(pl && params && cst, "ssq_cwt_plan_set_ssq: null pointer");
     SSQ_REQUIRE(grid >= SSQ_GRID_LOG && grid <= SSQ_GRID_LIN, "unknown grid kind %d", grid);
+    // (kernels receive SsqParams by value at launch: an execute already enqueued keeps its own)
     for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
     pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
     pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
@@ -266,8 +271,9 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     }
     finalize_params(pl->sp);
     size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
-    if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->d.na * 8));
-    SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, bytes, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(pl->order.mu);
+    int rc = pl->weights.upload(&pl->cst, cst, bytes);
+    if (rc) return rc;
     pl->have_ssq = true;
     return 0;
 }
@@ -371,8 +377,8 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
 
     pl->executed = true;
     const bool tm = pl->timing;
-    if (tm && pl->tev.size() < (size_t)(2 + 4 * batch)) {
-        size_t need = (size_t)(2 + 4 * batch);
+    if (tm && pl->tev.size() < (size_t)(2 + 6 * batch)) {
+        size_t need = (size_t)(2 + 6 * batch);
         while (pl->tev.size() < need) {
             hipEvent_t e; SSQ_CHECK_HIP(hipEventCreate(&e)); pl->tev.push_back(e);
         }
@@ -391,6 +397,12 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     int64_t slot = 0;                                   // timing slot = launch group
     for (int64_t b0 = 0; b0 < batch; b0 += pl->group, ++slot) {
         const int ng = (int)std::min<int64_t>(pl->group, batch - b0);
+        if (use_tiles) {            // decimated samples of the interpolated rows: counted with stage 0
+            mark(2 + 4 * batch + 2 * slot);
+            int rc2 = pl->tile->spectra((int)b0, ng, pl->xh, stream);
+            if (rc2) return rc2;
+            mark(2 + 4 * batch + 2 * slot + 1);
+        }
         mark(2 + 4 * slot);
         unsigned short* kidx = (Tx && !w) ? pl->kidx : nullptr;
         if (use_blocks) {
@@ -450,9 +462,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         }
         mark(2 + 4 * slot + 2);
         if (use_tiles) {
-            int rc2 = pl->tile->spectra((int)b0, ng, pl->xh, stream);
-            if (rc2) return rc2;
-            rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->sp, stream);
+            int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->sp, stream);
             if (rc2) return rc2;
         } else if (Tx) {
             T* Wx_g = (T*)Wx + (size_t)b0 * na * out_cols * 2;
@@ -470,6 +480,10 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         SSQ_CHECK_HIP(hipEventSynchronize(pl->tev[2 + 4 * (nslots - 1) + 3]));
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, pl->tev[0], pl->tev[1]); pl->stage_ms[0] += ms;
+        for (int64_t b = 0; use_tiles && b < nslots; ++b) {
+            (void)hipEventElapsedTime(&ms, pl->tev[2 + 4 * batch + 2 * b], pl->tev[2 + 4 * batch + 2 * b + 1]);
+            pl->stage_ms[0] += ms;
+        }
         for (int64_t b = 0; b < nslots; ++b)
             for (int st = 0; st < 3; ++st) {
                 (void)hipEventElapsedTime(&ms, pl->tev[2 + 4 * b + st], pl->tev[2 + 4 * b + st + 1]);
@@ -492,9 +506,12 @@ int ssq_cwt_execute(ssq_cwt_plan* pl, const void* x, int64_t batch, void* Wx, vo
     SSQ_REQUIRE(!Tx || pl->have_ssq, "Tx requested but ssq parameters were not set");
     SSQ_REQUIRE(!w || pl->have_ssq, "w requested but ssq parameters (gamma) were not set");
     SSQ_REQUIRE(Wx, "Wx buffer is required");
-    if (pl->d.dtype == SSQ_F32)
-        return cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
-    return cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
+    pl->order.enter(as_stream(stream));
+    int rc = pl->d.dtype == SSQ_F32
+        ? cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream))
+        : cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
+    pl->order.leave(as_stream(stream));
+    return rc;
 }
 
 }  // extern "C"

@@ -148,15 +148,22 @@ __global__ __launch_bounds__(256) void real_part_kernel(const T* __restrict__ S,
 }
 
 static std::mutex g_icwt2_mu;
-static std::map<std::tuple<int, int64_t, int64_t>, std::pair<FftPlan, FftPlan>> g_icwt2_plans;
+static std::map<std::tuple<int, int64_t, int64_t, hipStream_t>, std::pair<FftPlan, FftPlan>> g_icwt2_plans;
 
 template <typename T>
 static int icwt2_t(int dtype, void* Wp, const void* psih, void* out, int64_t na, int64_t n,
                    hipStream_t stream) {
+    // plans (and their rocFFT work buffers) are per stream; the lock is held until everything
+    // is enqueued, so two host threads cannot interleave set_stream / execute on one plan
     std::pair<FftPlan, FftPlan>* pp = nullptr;
+    std::lock_guard<std::mutex> lock(g_icwt2_mu);
     {
-        std::lock_guard<std::mutex> lock(g_icwt2_mu);
-        auto key = std::make_tuple(dtype, na, n);
+        auto key = std::make_tuple(dtype, na, n, stream);
+        if (g_icwt2_plans.size() >= 16 && !g_icwt2_plans.count(key)) {
+            (void)hipDeviceSynchronize();
+            for (auto& kv : g_icwt2_plans) { kv.second.first.destroy(); kv.second.second.destroy(); }
+            g_icwt2_plans.clear();
+        }
         auto it = g_icwt2_plans.find(key);
         if (it == g_icwt2_plans.end()) {
             std::pair<FftPlan, FftPlan> pr;
@@ -212,15 +219,20 @@ __global__ __launch_bounds__(256) void unpad_rows_kernel(const T* __restrict__ F
 }
 
 static std::mutex g_trig_mu;
-static std::map<std::tuple<int, int64_t, int64_t>, std::pair<FftPlan, FftPlan>> g_trig_plans;
+static std::map<std::tuple<int, int64_t, int64_t, hipStream_t>, std::pair<FftPlan, FftPlan>> g_trig_plans;
 
 template <typename T>
 static int trigdiff_t(int dtype, void* Ap, const void* xi, double fs, void* out, int64_t rows,
                       int64_t n_up, int64_t n1, int64_t N, hipStream_t stream) {
     std::pair<FftPlan, FftPlan>* pp = nullptr;
+    std::lock_guard<std::mutex> lock(g_trig_mu);          // per-stream plans; held until enqueued
     {
-        std::lock_guard<std::mutex> lock(g_trig_mu);
-        auto key = std::make_tuple(dtype, rows, n_up);
+        auto key = std::make_tuple(dtype, rows, n_up, stream);
+        if (g_trig_plans.size() >= 16 && !g_trig_plans.count(key)) {
+            (void)hipDeviceSynchronize();
+            for (auto& kv : g_trig_plans) { kv.second.first.destroy(); kv.second.second.destroy(); }
+            g_trig_plans.clear();
+        }
         auto it = g_trig_plans.find(key);
         if (it == g_trig_plans.end()) {
             std::pair<FftPlan, FftPlan> pr;
@@ -252,11 +264,19 @@ struct IstftFft {
     rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr; void* work = nullptr;
 };
 static std::mutex g_istft_mu;
-static std::map<std::tuple<int, int64_t, int64_t>, IstftFft> g_istft_plans;
+static std::map<std::tuple<int, int64_t, int64_t, hipStream_t>, IstftFft> g_istft_plans;   // one work buffer per stream
 
-static int istft_plan(int dtype, int64_t n_fft, int64_t n_hops, IstftFft** out) {
-    std::lock_guard<std::mutex> lock(g_istft_mu);
-    auto key = std::make_tuple(dtype, n_fft, n_hops);
+// (the caller holds g_istft_mu until the transform is enqueued)
+static int istft_plan(int dtype, int64_t n_fft, int64_t n_hops, hipStream_t stream, IstftFft** out) {
+    auto key = std::make_tuple(dtype, n_fft, n_hops, stream);
+    if (g_istft_plans.size() >= 16 && !g_istft_plans.count(key)) {      // bounded cache
+        (void)hipDeviceSynchronize();
+        for (auto& kv : g_istft_plans) {
+            rocfft_execution_info_destroy(kv.second.info); rocfft_plan_destroy(kv.second.plan);
+            if (kv.second.work) (void)hipFree(kv.second.work);
+        }
+        g_istft_plans.clear();
+    }
     auto it = g_istft_plans.find(key);
     if (it == g_istft_plans.end()) {
         if (fft_global_setup()) return -4;
@@ -294,7 +314,8 @@ static int istft_t(int dtype, const void* Sx, const void* win_a, const void* win
                        n_hops, (int)(n_fft % 2 == 0));
     SSQ_LAUNCH_CHECK();
     IstftFft* f = nullptr;
-    int rc = istft_plan(dtype, n_fft, n_hops, &f);
+    std::unique_lock<std::mutex> lock(g_istft_mu);
+    int rc = istft_plan(dtype, n_fft, n_hops, stream, &f);
     if (!rc) {
         rocfft_execution_info_set_stream(f->info, stream);
         void* ins[1] = {St}; void* outs[1] = {frames};
@@ -302,6 +323,7 @@ static int istft_t(int dtype, const void* Sx, const void* win_a, const void* win
             set_error("rocfft_execute (istft) failed"); rc = -4;
         }
     }
+    lock.unlock();
     if (!rc) {
         const T tiny = sizeof(T) == 4 ? (T)1.17549435e-38f : (T)2.2250738585072014e-308;
         hipLaunchKernelGGL((istft_ola_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream,

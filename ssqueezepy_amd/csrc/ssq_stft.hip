@@ -195,7 +195,9 @@ struct ssq_stft_plan {
     StridedR2C fft;
     bool fused = false; void* ftw = nullptr;      // fused float32 path (power-of-two n_fft)
     unsigned short* kidx = nullptr;               // bin map of the fused ssq_stft form
-    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;
+    bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;   // current entries of
+    WeightVersions weights, freqs;                                                      // these
+    PlanOrder order;
 };
 
 extern "C" {
@@ -254,8 +256,9 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
 void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
     if (!pl) return;
     pl->fft.destroy();
+    pl->weights.destroy(); pl->freqs.destroy(); pl->order.destroy();
     void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
-                    pl->cst, pl->Sfs, pl->ftw, pl->kidx};
+                    pl->ftw, pl->kidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -277,10 +280,11 @@ int ssq_stft_plan_set_ssq(ssq_stft_plan* pl, const void* Sfs, int grid, const do
     }
     finalize_params(pl->sp);
     const int rs = pl->rsize();
-    if (!pl->cst) SSQ_CHECK_HIP(hipMalloc(&pl->cst, (size_t)pl->rows * 8));
-    if (!pl->Sfs) SSQ_CHECK_HIP(hipMalloc(&pl->Sfs, (size_t)pl->rows * 8));
-    SSQ_CHECK_HIP(hipMemcpy(pl->cst, cst, (size_t)pl->rows * ((cst_f64 || rs == 8) ? 8 : 4), hipMemcpyHostToDevice));
-    SSQ_CHECK_HIP(hipMemcpy(pl->Sfs, Sfs, (size_t)pl->rows * rs, hipMemcpyHostToDevice));
+    std::lock_guard<std::mutex> lock(pl->order.mu);
+    int rc = pl->weights.upload(&pl->cst, cst, (size_t)pl->rows * ((cst_f64 || rs == 8) ? 8 : 4));
+    if (rc) return rc;
+    rc = pl->freqs.upload(&pl->Sfs, Sfs, (size_t)pl->rows * rs);
+    if (rc) return rc;
     pl->have_ssq = true;
     return 0;
 }
@@ -376,7 +380,9 @@ extern "C" int ssq_stft_execute(ssq_stft_plan* pl, const void* x, int64_t batch,
     SSQ_REQUIRE(batch >= 1 && batch <= pl->d.max_batch, "batch %lld outside [1, %lld]",
                 (long long)batch, (long long)pl->d.max_batch);
     SSQ_REQUIRE(!(Tx || w) || pl->have_ssq, "Tx / w requested but ssq parameters were not set");
-    if (pl->d.dtype == SSQ_F32)
-        return stft_execute_t<float>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream));
-    return stft_execute_t<double>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream));
+    pl->order.enter(as_stream(stream));
+    int rc = pl->d.dtype == SSQ_F32 ? stft_execute_t<float>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream))
+                                    : stft_execute_t<double>(pl, x, batch, Sx, dSx, Tx, w, as_stream(stream));
+    pl->order.leave(as_stream(stream));
+    return rc;
 }

@@ -141,3 +141,36 @@ def test_fused_stft_every_size(S, orc, n_fft):
             _stft._PLAN_CACHE.clear()
         assert relmax(Sx2, ro['Sx']) <= 1e-5 and relmax(Sx, Sx2) <= 1e-5
         assert relmax(dSx, dSx2) <= 1e-5
+
+
+def test_plan_reuse_across_streams_and_parameter_changes(S):
+    """One cached plan, two non-blocking streams, reassignment parameters that alternate
+    between the calls: an execute must neither see the other's weights nor share its
+    workspace unordered (plan state was updated on the null stream)."""
+    import torch
+    x = two_chirps(30000, seed=7)
+    wav = S.Wavelet()
+    ref = {}
+    for fl in (True, False):
+        ref[fl] = S.ssq_cwt(x, wav, scales='log', nv=16, flipud=fl)[0].clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(6):
+        for st, fl in ((s1, True), (s2, False)):
+            with torch.cuda.stream(st):
+                outs.append((fl, S.ssq_cwt(x, wav, scales='log', nv=16, flipud=fl)[0]))
+    torch.cuda.synchronize()
+    for fl, T in outs:
+        assert torch.equal(T, ref[fl])
+    y = two_chirps(8192, seed=8)
+    r2 = {h: S.ssq_stft(y, n_fft=256, hop_len=h and 32 or 64)[0].clone() for h in (True, False)}
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(6):
+        for st, h in ((s1, True), (s2, False)):
+            with torch.cuda.stream(st):
+                outs.append((h, S.ssq_stft(y, n_fft=256, hop_len=h and 32 or 64)[0]))
+    torch.cuda.synchronize()
+    for h, T in outs:
+        assert torch.equal(T, r2[h])
