@@ -36,6 +36,7 @@ struct BlockPlan {
     void* pxi = nullptr;             // real (dtype)
     void* ctw = nullptr; void* ftw = nullptr;
     void* items[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<int32_t> h_items[5];   // host copy (row, block, c0, class)
     int64_t n_items[5] = {0, 0, 0, 0, 0};
     int64_t ftw_off[5] = {0, 0, 0, 0, 0};
     void* blocks = nullptr;          // gathered signal blocks of one class (real)
@@ -60,7 +61,8 @@ struct BlockPlan {
                int64_t max_batch, int64_t& bytes);
     void destroy();
     // block spectra of all classes for the padded batch xp (max_batch x M)
-    int spectra(const void* xp, int64_t batch, hipStream_t stream);
+    // `need`: per class, 0 = skip (no row of the launch uses it), or nullptr for all
+    int spectra(const void* xp, int64_t batch, hipStream_t stream, const unsigned char* need = nullptr);
     // all block rows of signals sig .. sig+nsig-1; kidx holds nsig maps
     // `limit`: per L' slot, run only the leading items (the tile path takes the other rows)
     int run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,

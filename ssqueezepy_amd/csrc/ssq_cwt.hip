@@ -317,6 +317,12 @@ int ssq_cwt_plan_set_tiles(ssq_cwt_plan* pl, const ssq_cwt_tiles_desc* td) {
     auto* tp = new TilePlan();
     int rc = tp->create(*td, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->group, pl->bytes);
     if (rc) { tp->destroy(); delete tp; return rc; }
+    tp->class_need.assign((size_t)pl->blk->nc, 0);
+    for (int t = 0; t < 5; ++t)
+        for (int64_t q = 0; q < td->n_items_tile[t]; ++q) {
+            const int c = pl->blk->h_items[t][4 * q + 3];
+            if (c >= 0 && c < pl->blk->nc) tp->class_need[(size_t)c] = 1;
+        }
     pl->tile = tp;
     pl->algo += "+tiles";
     return 0;
@@ -390,17 +396,27 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     // tile kernel reads back, no separate reassignment launch
     const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4 && !pl->sp.cst_f64;
     if (use_blocks) {
-        int rc = pl->blk->spectra(pl->xp, batch, stream);
+        int rc = pl->blk->spectra(pl->xp, batch, stream,
+                                  (pl->tile && Tx && !w && !rpadded && !pl->sp.cst_f64) ? pl->tile->class_need.data() : nullptr);
         if (rc) return rc;
     }
     mark(1);
     int64_t slot = 0;                                   // timing slot = launch group
     for (int64_t b0 = 0; b0 < batch; b0 += pl->group, ++slot) {
         const int ng = (int)std::min<int64_t>(pl->group, batch - b0);
+        const bool fork = use_tiles && pl->tile->side && !tm;
         if (use_tiles) {            // decimated samples of the interpolated rows: counted with stage 0
             mark(2 + 4 * batch + 2 * slot);
-            int rc2 = pl->tile->spectra((int)b0, ng, pl->xh, stream);
+            // (beside the block / exact kernels when not timing stage by stage; the fork also
+            // orders this group's samples behind the previous group's tile kernel)
+            hipStream_t ss = fork ? pl->tile->side : stream;
+            if (fork) {
+                SSQ_CHECK_HIP(hipEventRecord(pl->tile->ev_fork, stream));
+                SSQ_CHECK_HIP(hipStreamWaitEvent(ss, pl->tile->ev_fork, 0));
+            }
+            int rc2 = pl->tile->spectra((int)b0, ng, pl->xh, ss);
             if (rc2) return rc2;
+            if (fork) SSQ_CHECK_HIP(hipEventRecord(pl->tile->ev_join, ss));
             mark(2 + 4 * batch + 2 * slot + 1);
         }
         mark(2 + 4 * slot);
@@ -462,6 +478,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         }
         mark(2 + 4 * slot + 2);
         if (use_tiles) {
+            if (fork) SSQ_CHECK_HIP(hipStreamWaitEvent(stream, pl->tile->ev_join, 0));
             int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->sp, stream);
             if (rc2) return rc2;
         } else if (Tx) {

@@ -658,6 +658,7 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
         n_items[s] = d.n_items[s];
         ftw_off[s] = d.ftw_off[s];
         if ((rc = up((void**)&items[s], d.items[s], sizeof(int4) * (size_t)d.n_items[s]))) return rc;
+        if (d.n_items[s]) h_items[s].assign(d.items[s], d.items[s] + 4 * d.n_items[s]);
     }
     SSQ_CHECK_HIP(hipMalloc((void**)&xb, 2 * rs * (size_t)xb_total)); bytes += 2 * rs * xb_total;
     SSQ_CHECK_HIP(hipMalloc((void**)&blocks, rs * (size_t)blk_max)); bytes += rs * blk_max;
@@ -685,20 +686,33 @@ void BlockPlan::destroy() {
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
-int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream) {
+int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream, const unsigned char* need) {
     (void)batch;                                   // planned batch: stale rows are ignored later
+    // classes are gathered and transformed in runs of equal block length; with `need`, only
+    // the runs that hold a needed class (class indices are contiguous per run)
+    int c_lo = nc, c_hi = -1;
+    std::vector<char> run_on(ffts.size(), 1);
+    for (size_t f = 0; f < ffts.size(); ++f) {
+        const int a = fft_first[f], b = f + 1 < ffts.size() ? fft_first[f + 1] : nc;
+        bool on = !need;
+        for (int c = a; c < b && !on; ++c) on = need[c] != 0;
+        run_on[f] = on;
+        if (on) { c_lo = std::min(c_lo, a); c_hi = std::max(c_hi, b - 1); }
+    }
+    if (c_hi < c_lo) return 0;
     int64_t most = 0;
-    for (const auto& k : hcls) most = std::max<int64_t>(most, max_batch * k.nb * k.P);
-    dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 2048), (unsigned)nc);
+    for (int c = c_lo; c <= c_hi; ++c) most = std::max<int64_t>(most, max_batch * hcls[c].nb * hcls[c].P);
+    dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 2048), (unsigned)(c_hi - c_lo + 1));
     if (dtype == SSQ_F32)
         hipLaunchKernelGGL(gather_blocks_kernel<float>, grid, dim3(256), 0, stream, (const float*)xp,
-                           (float*)blocks, classes, M, n1, max_batch);
+                           (float*)blocks, classes + c_lo, M, n1, max_batch);
     else
         hipLaunchKernelGGL(gather_blocks_kernel<double>, grid, dim3(256), 0, stream, (const double*)xp,
-                           (double*)blocks, classes, M, n1, max_batch);
+                           (double*)blocks, classes + c_lo, M, n1, max_batch);
     SSQ_LAUNCH_CHECK();
     const size_t rs = dtype == SSQ_F32 ? 4 : 8;
     for (size_t f = 0; f < ffts.size(); ++f) {
+        if (!run_on[f]) continue;
         const BlockClassDev& k = hcls[fft_first[f]];
         int rc = ffts[f].execute((char*)blocks + (size_t)k.blk_off * rs,
                                  (char*)xb + (size_t)k.xb_off * 2 * rs, stream);

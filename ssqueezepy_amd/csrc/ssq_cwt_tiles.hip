@@ -524,10 +524,19 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     }
     for (int t = 0; t < 5; ++t) n_items_tile[t] = d.n_items_tile[t];
     n_exact_tile = d.n_exact_tile;
+    if (!getenv("SSQ_TILE_SERIAL")) {
+        SSQ_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     return 0;
 }
 
 void TilePlan::destroy() {
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); side = nullptr; }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
     void* ptrs[] = {steps, rows, irows, ltw, twm, wtab, tbank, U};

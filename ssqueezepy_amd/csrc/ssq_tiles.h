@@ -46,6 +46,10 @@ struct TilePlan {
     std::vector<FftPlan> ffts;              // one batched inverse per class
     int64_t n_items_tile[5] = {0, 0, 0, 0, 0};
     int n_exact_tile = 0;
+    std::vector<unsigned char> class_need;   // block classes the remaining block rows use
+    // the intermediates (a spectra kernel + small FFTs) run on a side stream, beside the block /
+    // exact kernels of the rows that are read back
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     int create(const ssq_cwt_tiles_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na, int group,
                int64_t& bytes);

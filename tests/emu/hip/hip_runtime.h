@@ -96,6 +96,9 @@ constexpr int hipEventDisableTiming = 2;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = (hipEvent_t)1; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+constexpr int hipStreamNonBlocking = 1;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
