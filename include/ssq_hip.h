@@ -271,8 +271,8 @@ int  ssq_cwt_plan_set_blocks(ssq_cwt_plan* plan, const ssq_cwt_blocks_desc* desc
  * decimation by R >= 4 are not transformed at full length at all. Their band is
  * inverse-transformed at length m / R into a plan-owned intermediate, and one kernel per
  * 64-column tile interpolates Wx / dWx from it (8-tap Kaiser-Bessel kernel and its
- * derivative), writes Wx, and reassigns into an LDS-resident tile of Tx in ascending row
- * order -- Wx is never read back and no bin map is written for those rows. The other
+ * derivative, modulation by hardware sin / cos of an exact phase), writes Wx, and reassigns
+ * into an LDS-resident tile of Tx in ascending row order -- Wx is never read back and no bin map is written for those rows. The other
  * rows keep the block / exact kernels; the tile kernel reads their Wx and bin map back.
  * ssqueezepy_amd/_tiles.py documents the decomposition and builds the tables (host
  * arrays, copied). Must follow ssq_cwt_plan_set_blocks, before the first execute.
@@ -284,11 +284,10 @@ typedef struct {
                                  /* steps, log2 R, weight-table offset (phases), intermediate  */
                                  /* stride per signal, L - 1, class offset (complex entries)   */
     int32_t        n_steps;
-    const int32_t* rows;         /* 4 n_steps x 4: row (-1 none), offset in class, kc, theta   */
-                                 /* (float bits) = 2 pi kc / (m dt)                            */
-    const void*    ltw;          /* complex64 [4 n_steps][16]: exp(2i pi kc c / m)             */
-    const void*    twm;          /* complex64 [m]: exp(2i pi p / m)                            */
-    const void*    wtab;         /* float32 [n_phases][16]: phi at 8 taps, phi' / (R dt)       */
+    const int32_t* rows;         /* 4 n_steps x 4: row (sign bit: repeats the previous row to  */
+                                 /* pad a step), offset in class, kc, theta = 2 pi kc / (m dt) */
+                                 /* (float bits). n_steps is even.                             */
+    const void*    wtab;         /* float32 [n_phases][16]: per tap, phi and phi' / (R dt)     */
     int64_t        n_phases;
     const void*    tbank;        /* float32: band values / (phi_hat m) of the interpolated rows */
     int64_t        n_tbank;

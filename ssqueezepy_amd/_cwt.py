@@ -154,13 +154,11 @@ class CwtPlan():
     def _set_tiles(self, tp, n_items_tile, n_exact):
         c = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
         segs, rws = c(tp['segs'], np.int32), c(tp['rows'], np.int32)
-        ltw, twm = c(tp['ltw'], np.complex64), c(tp['twm'], np.complex64)
         wtab, tbank = c(tp['wtab'], np.float32), c(tp['tbank'], np.float32)
         irows, classes = c(tp['irows'], np.int64), c(tp['classes'], np.int64)
         d = CwtTilesDesc()
         d.n_segs, d.segs = len(segs), segs.ctypes.data
         d.n_steps, d.rows = len(rws) // 4, rws.ctypes.data
-        d.ltw, d.twm = ltw.ctypes.data, twm.ctypes.data
         d.wtab, d.n_phases = wtab.ctypes.data, len(wtab)
         d.tbank, d.n_tbank = tbank.ctypes.data, len(tbank)
         d.n_irows, d.irows = len(irows), irows.ctypes.data

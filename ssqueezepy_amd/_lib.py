@@ -43,7 +43,7 @@ class CwtBlocksDesc(Structure):
 
 class CwtTilesDesc(Structure):
     _fields_ = [('n_segs', c_int), ('segs', c_void_p), ('n_steps', c_int), ('rows', c_void_p),
-                ('ltw', c_void_p), ('twm', c_void_p), ('wtab', c_void_p), ('n_phases', c_int64),
+                ('wtab', c_void_p), ('n_phases', c_int64),
                 ('tbank', c_void_p), ('n_tbank', c_int64), ('n_irows', c_int),
                 ('irows', c_void_p), ('n_classes', c_int), ('classes', c_void_p),
                 ('u_total', c_int64), ('n_items_tile', c_int64 * 5), ('n_exact_tile', c_int)]

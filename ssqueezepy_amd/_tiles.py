@@ -33,8 +33,8 @@ Rows that are not oversampled enough (R < R_MIN: the widest ~20 % of the bank) o
 whose band is cut by the Nyquist frequency keep the block / exact kernels, which leave
 `Wx` and a bin map in HBM; the tile kernel reads those rows back (`kind 0`).
 
-This module picks R_i per row, builds the compensated band values, the kernel tables and
-the twiddles, and the row / step / segment lists the kernel walks
+This module picks R_i per row, builds the compensated band values, the kernel tables, and
+the row / step / segment lists the kernel walks
 (`ssq_cwt_plan_set_tiles`, include/ssq_hip.h). Measured accuracy of the interpolation on
 the N=160k GMW bank: 2.7e-7 of max|Wx| (float32 samples and weights), 9e-7 of max|dWx|
 -- below the float32 FFT's own error (tests compare against the oracle at 1e-5).
@@ -197,12 +197,7 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
     rowdesc = np.asarray(rowdesc, dtype=np.int32)
     segs = np.asarray(segs, dtype=np.int32)
 
-    # ---- twiddles: e^{2i pi p / M} (tile base) and e^{2i pi kc c / M}, c < COLS (lane)
-    twm = np.exp(2j * np.pi * np.arange(M) / M).astype(np.complex64)
-    kc_desc = rowdesc[:, 2].astype(np.int64)
-    ltw = np.exp(2j * np.pi * ((kc_desc[:, None] * np.arange(COLS)[None, :]) % M) / M
-                 ).astype(np.complex64)
-    return dict(segs=segs, rows=rowdesc, ltw=ltw, twm=twm, wtab=wtab,
+    return dict(segs=segs, rows=rowdesc, wtab=wtab,
                 tbank=np.concatenate(tb), irows=irows.astype(np.int64),
                 classes=np.asarray(classes, dtype=np.int64), u_total=int(u_total),
                 interp_rows=interp, lgR=lgR)

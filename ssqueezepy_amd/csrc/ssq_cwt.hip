@@ -144,6 +144,7 @@ struct ssq_cwt_plan {
     // ssq
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr;   // cst: the current entry of `weights`
     WeightVersions weights;
+    float cst0 = 0.f;                     // first weight (all of them when sp.cst_uniform)
     PlanOrder order;
     std::string algo = "rocfft";
     // rows evaluated by the exact full-length path (all rows unless a block plan
@@ -272,6 +273,7 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     finalize_params(pl->sp);
     size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
     std::lock_guard<std::mutex> lock(pl->order.mu);
+    pl->cst0 = (cst_f64 || pl->d.dtype == SSQ_F64) ? (float)((const double*)cst)[0] : ((const float*)cst)[0];
     int rc = pl->weights.upload(&pl->cst, cst, bytes);
     if (rc) return rc;
     pl->have_ssq = true;
@@ -315,7 +317,7 @@ int ssq_cwt_plan_set_tiles(ssq_cwt_plan* pl, const ssq_cwt_tiles_desc* td) {
         SSQ_REQUIRE(td->n_items_tile[t] >= 0 && td->n_items_tile[t] <= pl->blk->n_items[t],
                     "tile tables: bad block item count in slot %d", t);
     auto* tp = new TilePlan();
-    int rc = tp->create(*td, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->group, pl->bytes);
+    int rc = tp->create(*td, pl->d.m, pl->d.n, pl->d.n1, pl->d.na, pl->group, pl->d.dt, pl->bytes);
     if (rc) { tp->destroy(); delete tp; return rc; }
     tp->class_need.assign((size_t)pl->blk->nc, 0);
     for (int t = 0; t < 5; ++t)
@@ -479,7 +481,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         mark(2 + 4 * slot + 2);
         if (use_tiles) {
             if (fork) SSQ_CHECK_HIP(hipStreamWaitEvent(stream, pl->tile->ev_join, 0));
-            int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->sp, stream);
+            int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->cst0, pl->sp, stream);
             if (rc2) return rc2;
         } else if (Tx) {
             T* Wx_g = (T*)Wx + (size_t)b0 * na * out_cols * 2;

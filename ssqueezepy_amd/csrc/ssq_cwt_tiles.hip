@@ -46,14 +46,15 @@ constexpr int TILE_W = 8;         // taps
 
 struct TileArgs {
     const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
-    const float2* ltw; const float2* twm; const float4* wtab; const float2* U;
+    const float4* wtab; const float2* U;
     const float* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
     int64_t N, na;
     int nsteps, n1, mmask, sig0, nsig;
     float inv_m;         // 1 / M
+    float theta_scale;   // 2 pi / (M dt): theta of a row = kc * theta_scale
+    float cst0;          // the reassignment weight when it is the same for every row
     unsigned long long* trace;   // tuning aid (SSQ_TILE_TRACE): shader-clock stamps of one workgroup
-    int dbg;             // tuning aid (SSQ_TILE_DBG): 1 = no Wx store, 2 = no tile update, 4 = no bin arithmetic
     double gamma;
 };
 
@@ -158,7 +159,7 @@ struct TileCtx {
     int64_t kbase;           // ... in the bin map of the group
 };
 
-template <int GRID, bool STORE_D, int NW>
+template <int GRID, bool STORE_D, int NW, bool CSTU>
 __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int c = threadIdx.x & 63;
@@ -261,58 +262,53 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         return;
     }
 
-    int4 sa[2], sb[2], rec[2][TILE_G];        // step (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
-    auto load_rec = [&](int q, int j) {
+    // Software pipeline over this wavefront's steps, across tiles. Registers decide how many
+    // wavefronts a SIMD holds (168 for three), so the pipeline keeps only what it must: the
+    // records of the NEXT step (loaded at the top of a step), the samples of the next step
+    // (loaded in the middle of a step, when the records have arrived); interpolation weights
+    // are fetched when the class changes (once per pair of steps, L2-resident), theta and the
+    // uniform reassignment weight are derived / passed as scalars.
+    int4 sa, sb, rec[TILE_G];                 // next step: (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
+    auto load_rec = [&](int j) {
         const int g = gstep(j);
-        sa[q] = steps4[2 * g]; sb[q] = steps4[2 * g + 1];
+        sa = steps4[2 * g]; sb = steps4[2 * g + 1];
 #pragma unroll
-        for (int r = 0; r < TILE_G; ++r) rec[q][r] = rows4[g * TILE_G + r];
+        for (int r = 0; r < TILE_G; ++r) rec[r] = rows4[g * TILE_G + r];
     };
     float2 xu[2][TILE_G];
-    float xc[2][TILE_G], xt[2][TILE_G]; int xr[2][TILE_G], xkc[2][TILE_G]; unsigned short xk[2][TILE_G];
-    float4 xw[2][4]; int xkind[2], xbaddr[2], xwoff[2] = {-1, -1};
-    auto load = [&](int b, int q, const TileCtx& t) {
-        const int kind = sa[q].x;
+    int xr[2][TILE_G], xkc[2][TILE_G]; unsigned short xk[2][TILE_G];
+    float xc[2][CSTU ? 1 : TILE_G];
+    int xkind[2], xbaddr[2], xwoff[2], xmask[2];
+    auto load = [&](int b, const TileCtx& t) {
+        const int kind = sa.x;
         xkind[b] = kind;
         if (kind == 0) {                                     // rows read back: Wx, bin
             const float2* Wx = A.Wx + t.obase;
             const unsigned short* kidx = A.kidx + t.kbase;
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) {
-                const int row = rec[q][r].x & 0xFFFF;
+                const int row = rec[r].x & 0xFFFF;
                 const unsigned o = (unsigned)row * nN + (unsigned)t.colc;
-                xr[b][r] = rec[q][r].x;
+                xr[b][r] = rec[r].x;
                 xu[b][r] = Wx[o];
                 xk[b][r] = kidx[o];
-                xc[b][r] = cstv[row];
+                if (!CSTU) xc[b][r] = cstv[row];
             }
         } else {                                             // rows interpolated
-            const int lgR = sa[q].w;
-            // weights of the class: 64 B per lane and step, the largest stream of the kernel --
-            // the second step of a pair nearly always shares the first one's
-            const bool same = b == 1 && __builtin_amdgcn_readfirstlane(xkind[0]) != 0 &&
-                              __builtin_amdgcn_readfirstlane(xwoff[0]) == __builtin_amdgcn_readfirstlane(sb[q].x);
-            xwoff[b] = sb[q].x;
-            if (same) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xw[1][u] = xw[0][u];
-            } else {
-                const float4* wp = A.wtab + (int64_t)(sb[q].x + (t.nabs & ((1 << lgR) - 1))) * 4;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) xw[b][u] = wp[u];
-            }
+            const int lgR = sa.w;
+            xwoff[b] = sb.x; xmask[b] = (1 << lgR) - 1;
             const int q0 = t.nabs >> lgR, qb = (t.nabs0 >> lgR) - (TILE_W / 2 - 1);
             // the sample this lane holds (lanes past the widest window any lane needs repeat the last one)
             const int wlast = (63 >> lgR) + TILE_W;
-            const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb[q].z);
+            const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb.z);
             xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
-            const float2* Ub = A.U + sb[q].w + (int64_t)t.sg * sb[q].y;
+            const float2* Ub = A.U + sb.w + (int64_t)t.sg * sb.y;
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) {
-                const int4 d = rec[q][r];
-                xr[b][r] = d.x; xkc[b][r] = d.z; xt[b][r] = __int_as_float(d.w);
+                const int4 d = rec[r];
+                xr[b][r] = d.x; xkc[b][r] = d.z;
                 xu[b][r] = Ub[(unsigned)d.y + uidx];
-                xc[b][r] = cstv[d.x & 0xFFFF];
+                if (!CSTU) xc[b][r] = cstv[d.x & 0xFFFF];
             }
         }
     };
@@ -321,78 +317,77 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     TileCtx tl = tc;                                                       // tile of the step loaded
     TileCtx tp = tc;                                                       // previous tile (to write out)
     int jl = 0, jc = 0, itl = 0;              // step inside the tile (loads / arithmetic), tile count
-    load_rec(0, 0); load_rec(1, 1 % nmine); load(0, 0, tl);
-    int jr = 2 % nmine;                       // step whose records are loaded next
+    load_rec(0); load(0, tl);
     if (++jl == nmine) { jl = 0; advance(tl); }
+    load_rec(jl);
+    ssq_f2 wt[TILE_W];                        // (phi_t, phi'_t / (R dt)) of the class in hand
+    int wt_off = -1, wt_phase = -1;
     for (int jj = 0; jj < jtot; jj += 2) {
         int cells[2][TILE_G]; float2 vs[2][TILE_G];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             if (tr && itl == 2) TILE_STAMP(jc + b, 0);
-            if (jj + b + 1 < jtot) load(b ^ 1, 1, tl);
-            if (++jl == nmine) { jl = 0; advance(tl); }
-            sa[0] = sa[1]; sb[0] = sb[1];
-#pragma unroll
-            for (int r = 0; r < TILE_G; ++r) rec[0][r] = rec[1][r];
-            load_rec(1, jr);
-            if (++jr == nmine) jr = 0;
             int (&cell)[TILE_G] = cells[b]; float2 (&v)[TILE_G] = vs[b];
-            if (tr && itl == 2) TILE_STAMP(jc + b, 1);
+            // the next step: its samples now (its records came in during the previous step),
+            // then the records of the one after
+            auto prefetch = [&]() {
+                if (jj + b + 1 < jtot) load(b ^ 1, tl);
+                if (++jl == nmine) { jl = 0; advance(tl); }
+                load_rec(jl);
+            };
             if (__builtin_amdgcn_readfirstlane(xkind[b]) == 0) {
+                prefetch();
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
                     const int kk = xk[b][r];
                     const bool act = xr[b][r] >= 0 && tc.colok && kk != 0xFFFF;
+                    const float cs = CSTU ? A.cst0 : xc[b][CSTU ? 0 : r];
                     cell[r] = act ? kk * TILE_COLS + c : scratch;
-                    v[r] = act ? make_float2(xu[b][r].x * xc[b][r], xu[b][r].y * xc[b][r]) : make_float2(0.f, 0.f);
+                    v[r] = act ? make_float2(xu[b][r].x * cs, xu[b][r].y * cs) : make_float2(0.f, 0.f);
                 }
             } else {
                 float2* Wx = A.Wx + tc.obase;
                 float2* dWx = STORE_D ? A.dWx + tc.obase : nullptr;
-                ssq_f2 wt[TILE_W];                               // (phi_t, phi'_t / (R dt))
+                const int phase = tc.nabs & xmask[b];
+                if (__builtin_amdgcn_readfirstlane(xwoff[b]) != wt_off || phase != wt_phase) {
+                    const float4* wp = A.wtab + (int64_t)(xwoff[b] + phase) * 4;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    wt[2 * t].x = xw[b][t].x; wt[2 * t].y = xw[b][t].y;
-                    wt[2 * t + 1].x = xw[b][t].z; wt[2 * t + 1].y = xw[b][t].w;
+                    for (int t = 0; t < 4; ++t) {
+                        const float4 q = wp[t];
+                        wt[2 * t].x = q.x; wt[2 * t].y = q.y; wt[2 * t + 1].x = q.z; wt[2 * t + 1].y = q.w;
+                    }
+                    wt_off = __builtin_amdgcn_readfirstlane(xwoff[b]); wt_phase = phase;
                 }
                 const int baddr = xbaddr[b];
-                unsigned pend = 0;
-                float2 Wk[TILE_G], Dk[TILE_G];
-                // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary parts
-                // as two packed accumulators (a_re, a'_re), (a_im, a'_im) per row; two rows at a
-                // time, so that a wavefront has four independent accumulation chains in flight
-                ssq_f2 are2[TILE_G], aim2[TILE_G];
-#pragma unroll
-                for (int r0 = 0; r0 < TILE_G; r0 += 2) {
-                    int fr[2][TILE_W], fi[2][TILE_W];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int ur = __float_as_int(xu[b][r0 + h].x), ui = __float_as_int(xu[b][r0 + h].y);
-                        SSQ_BPERMUTE_OFF(fr[h][0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[h][0], baddr, ui, 0);
-                        SSQ_BPERMUTE_OFF(fr[h][1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[h][1], baddr, ui, 4);
-                        SSQ_BPERMUTE_OFF(fr[h][2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[h][2], baddr, ui, 8);
-                        SSQ_BPERMUTE_OFF(fr[h][3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[h][3], baddr, ui, 12);
-                        SSQ_BPERMUTE_OFF(fr[h][4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[h][4], baddr, ui, 16);
-                        SSQ_BPERMUTE_OFF(fr[h][5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[h][5], baddr, ui, 20);
-                        SSQ_BPERMUTE_OFF(fr[h][6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[h][6], baddr, ui, 24);
-                        SSQ_BPERMUTE_OFF(fr[h][7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[h][7], baddr, ui, 28);
-                    }
-                    SSQ_LDS_WAIT();
-#pragma unroll
-                    for (int t = 0; t < TILE_W; ++t)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            ssq_f2 sv; sv.x = __int_as_float(fr[h][t]); sv.y = __int_as_float(fi[h][t]);
-                            if (t == 0) { SSQ_PK_MUL_LO(are2[r0 + h], wt[0], sv); SSQ_PK_MUL_HI(aim2[r0 + h], wt[0], sv); }
-                            else { SSQ_PK_FMA_LO(are2[r0 + h], wt[t], sv); SSQ_PK_FMA_HI(aim2[r0 + h], wt[t], sv); }
-                        }
-                }
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
-                    const float are = are2[r].x, aim = aim2[r].x;
-                    float dre = are2[r].y, dim = aim2[r].y;
-                    // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
-                    const float theta = xt[b][r];
+                    if (r == TILE_G / 2) prefetch();
+                    // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
+                    // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
+                    ssq_f2 are2, aim2;
+                    {
+                        int fr[TILE_W], fi[TILE_W];
+                        const int ur = __float_as_int(xu[b][r].x), ui = __float_as_int(xu[b][r].y);
+                        SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
+                        SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
+                        SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
+                        SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
+                        SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
+                        SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
+                        SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
+                        SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
+                        SSQ_LDS_WAIT();
+#pragma unroll
+                        for (int t = 0; t < TILE_W; ++t) {
+                            ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
+                            if (t == 0) { SSQ_PK_MUL_LO(are2, wt[0], sv); SSQ_PK_MUL_HI(aim2, wt[0], sv); }
+                            else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
+                        }
+                    }
+                    const float are = are2.x, aim = aim2.x;
+                    float dre = are2.y, dim = aim2.y;
+                    // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
+                    const float theta = (float)xkc[b][r] * A.theta_scale;
                     dre = __builtin_fmaf(-theta, aim, dre);
                     dim = __builtin_fmaf(theta, are, dim);
                     // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
@@ -416,23 +411,20 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
                     bool ok;
                     const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
-                    const int kf = (kb ^ fx) + fa;
+                    int kf = (kb ^ fx) + fa;
                     const bool live = tc.colok && !pad;
-                    // undecided by the float32 screens (rare): the exact double path, once per step
-                    if (live && !(below | (above & ok))) pend |= 1u << r;
-                    const bool act = above && live;
-                    cell[r] = act ? kf * TILE_COLS + c : scratch;
-                    v[r] = act ? make_float2(Wv.x * xc[b][r], Wv.y * xc[b][r]) : make_float2(0.f, 0.f);
-                    Wk[r] = Wv; Dk[r] = Dv;
-                }
-                if (__builtin_amdgcn_ballot_w64(pend != 0)) {
-#pragma unroll
-                    for (int r = 0; r < TILE_G; ++r)
-                        if (pend & (1u << r)) {
-                            const int kf = exact_bin(Wk[r], Dk[r], sp, omax, A.gamma);
-                            cell[r] = kf >= 0 ? kf * TILE_COLS + c : scratch;
-                            v[r] = kf >= 0 ? make_float2(Wk[r].x * xc[b][r], Wk[r].y * xc[b][r]) : make_float2(0.f, 0.f);
+                    bool act = above && live;
+                    // undecided by the float32 screens (~0.05 % of the points): the exact double path
+                    const bool und = live && !(below | (above & ok));
+                    if (__builtin_amdgcn_ballot_w64(und)) {
+                        if (und) {
+                            kf = exact_bin(Wv, Dv, sp, omax, A.gamma);
+                            act = kf >= 0;
                         }
+                    }
+                    const float cs = CSTU ? A.cst0 : xc[b][CSTU ? 0 : r];
+                    cell[r] = act ? kf * TILE_COLS + c : scratch;
+                    v[r] = act ? make_float2(Wv.x * cs, Wv.y * cs) : make_float2(0.f, 0.f);
                 }
             }
             if (tr && itl == 2) TILE_STAMP(jc + b, 2);
@@ -462,8 +454,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
 
 // ---------------------------------------------------------------------------- host side
 int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_, int group_,
-                     int64_t& bytes) {
-    M = M_; N = N_; n1 = n1_; na = na_; group = group_;
+                     double dt_, int64_t& bytes) {
+    M = M_; N = N_; n1 = n1_; na = na_; group = group_; dt = dt_;
     nsegs = d.n_segs; nsteps = d.n_steps; n_irows = d.n_irows; u_total = d.u_total;
     SSQ_REQUIRE(nsegs >= 1 && nsteps >= 2 && nsteps % 2 == 0 && n_irows >= 1 && d.n_classes >= 1,
                 "empty tile tables or an odd number of steps");
@@ -492,8 +484,6 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         if ((rc = up((void**)&steps, hs.data(), sizeof(TileSeg) * nsteps))) return rc;
     }
     if ((rc = up((void**)&rows, d.rows, sizeof(TileRow) * TILE_G * nsteps))) return rc;
-    if ((rc = up(&ltw, d.ltw, (size_t)8 * TILE_G * nsteps * TILE_COLS))) return rc;
-    if ((rc = up(&twm, d.twm, (size_t)8 * M))) return rc;
     if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
     if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
     cls.resize(d.n_classes);
@@ -539,9 +529,9 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, irows, ltw, twm, wtab, tbank, U};
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    steps = nullptr; rows = nullptr; irows = nullptr; ltw = twm = wtab = tbank = U = nullptr;
+    steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = nullptr;
 }
 
 int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
@@ -557,9 +547,16 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
     return 0;
 }
 
+template <int GRID, bool STORE_D, int NW, bool CSTU>
+static int launch_tile_c(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream);
 template <int GRID, bool STORE_D, int NW>
 static int launch_tile_k(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream) {
-    auto kern = tile_kernel<GRID, STORE_D, NW>;
+    if (sp.cst_uniform) return launch_tile_c<GRID, STORE_D, NW, true>(A, sp, N, na, nsig, stream);
+    return launch_tile_c<GRID, STORE_D, NW, false>(A, sp, N, na, nsig, stream);
+}
+template <int GRID, bool STORE_D, int NW, bool CSTU>
+static int launch_tile_c(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream) {
+    auto kern = tile_kernel<GRID, STORE_D, NW, CSTU>;
     const size_t lds = (size_t)(na + 1) * TILE_COLS * 8 + 16;
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -587,14 +584,14 @@ static int launch_tile(const TileArgs& A, const SsqParams& sp, int64_t N, int64_
 }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
-                  const void* cst, const SsqParams& sp, hipStream_t stream) {
+                  const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
     TileArgs A;
-    A.steps = steps; A.rows = rows; A.ltw = (const float2*)ltw; A.twm = (const float2*)twm;
+    A.steps = steps; A.rows = rows;
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = (const float*)cst;
     A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
     A.N = N; A.na = na; A.nsteps = nsteps; A.n1 = (int)n1; A.mmask = (int)(M - 1); A.sig0 = sig; A.inv_m = 1.0f / (float)M;
+    A.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); A.cst0 = cst0;
     A.gamma = sp.gamma;
-    { const char* e = getenv("SSQ_TILE_DBG"); A.dbg = e ? atoi(e) : 0; }
     static unsigned long long* trace_buf = nullptr;
     const char* trace_path = getenv("SSQ_TILE_TRACE");
     if (trace_path && !trace_buf) { SSQ_CHECK_HIP(hipMalloc((void**)&trace_buf, 8 * (16 * 16 * 8 + 64))); }

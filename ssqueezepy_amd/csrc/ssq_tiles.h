@@ -23,7 +23,7 @@ struct TileRow {
     int32_t row;
     int32_t ubase;       // offset of the row's samples inside its class (signal 0)
     int32_t kc;          // centre bin of the band on the M-point grid
-    float   theta;       // 2 pi kc / (M dt)
+    float   theta;       // 2 pi kc / (M dt) (informative: the kernel forms it as kc * 2 pi / (M dt))
 };
 // one interpolated row as the spectra kernel sees it
 struct TileIRow {
@@ -35,11 +35,12 @@ struct TileIRow {
 struct TilePlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0;
     int group = 1;
+    double dt = 1.0;
     int nsegs = 0, nsteps = 0, n_irows = 0;
     int64_t u_total = 0, lmax = 0;
     TileSeg* steps = nullptr;               // the segment record of every step
     TileRow* rows = nullptr; TileIRow* irows = nullptr;
-    void* ltw = nullptr; void* twm = nullptr; void* wtab = nullptr; void* tbank = nullptr;
+    void* wtab = nullptr; void* tbank = nullptr;
     void* U = nullptr;                      // group x u_total complex64
     struct Cls { int64_t L, nrows, upre; };
     std::vector<Cls> cls;
@@ -52,13 +53,13 @@ struct TilePlan {
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     int create(const ssq_cwt_tiles_desc& d, int64_t M, int64_t N, int64_t n1, int64_t na, int group,
-               int64_t& bytes);
+               double dt, int64_t& bytes);
     void destroy();
     // intermediates of signals sig .. sig+nsig-1 (nsig <= group) from the spectra of the batch
     int spectra(int sig, int nsig, const void* xh_all, hipStream_t stream);
     // Wx of the interpolated rows, Tx of all rows (the other rows' Wx and bin map must be in place)
     int run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
-            const void* cst, const SsqParams& sp, hipStream_t stream);
+            const void* cst, float cst0, const SsqParams& sp, hipStream_t stream);
 };
 
 }  // namespace ssq

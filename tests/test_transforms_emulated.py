@@ -127,3 +127,37 @@ def test_custom_wavelet_functions_do_not_share_cached_plans():
             Wx, sc = S.cwt(x, S.Wavelet(make(mu)), scales=2 ** np.arange(1, 6, 0.25), astensor=False)
             outs.append(Wx)
     assert outs[0].shape == outs[1].shape and np.abs(outs[0] - outs[1]).max() > 1e-3
+
+
+def test_tile_path_emulated_vs_oracle():
+    """The column-tile path of the fused ssq_cwt (persistent workgroups, ordered ticket
+    updates, several tiles per workgroup) under the emulator: Wx / dWx against the oracle,
+    Tx bit for bit against the oracle's reassignment of the device's own Wx / dWx, lean ==
+    full instantiation, batched == single; odd length (last tile partial) and both
+    exponential grids."""
+    import emu_backend
+    from oracle import oracle as orc
+    from pipeline import oracle_ssq_cwt, GRIDNAME
+    from conftest import two_chirps
+    with emu_backend.emulated() as S:
+        from ssqueezepy_amd import _cwt
+        for N, st in ((5003, 'log-piecewise'), (2500, 'log')):
+            x = two_chirps(N, seed=N)
+            wav = S.Wavelet()
+            _cwt.clear_plan_cache()
+            Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=st, nv=16, get_dWx=True, astensor=False)
+            plan = next(iter(_cwt._PLAN_CACHE.values()))
+            assert 'tiles' in plan.algo and plan.tile_rows > 0.5 * plan.na
+            r = oracle_ssq_cwt(orc, x, 'float32', scales=st, nv=16)
+            assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
+            assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()
+            ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
+                               True, typing=0)
+            assert np.array_equal(Tx, ref)
+            T2, W2, *_ = S.ssq_cwt(x, wav, scales=st, nv=16, astensor=False)
+            assert np.array_equal(T2, Tx) and np.array_equal(W2, Wx)
+        xb = np.stack([x, x[::-1].copy()])
+        Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales=st, nv=16, astensor=False)
+        assert np.array_equal(Tb[0], Tx) and np.array_equal(Wb[0], Wx)
+        T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales=st, nv=16, astensor=False)
+        assert np.array_equal(Tb[1], T1) and np.array_equal(Wb[1], W1)
