@@ -286,7 +286,7 @@ typedef struct {
     int32_t        n_steps;
     const int32_t* rows;         /* 4 n_steps x 4: row (sign bit: repeats the previous row to  */
                                  /* pad a step), offset in class, kc, theta = 2 pi kc / (m dt) */
-                                 /* (float bits). n_steps is even.                             */
+                                 /* (float bits). n_steps is a multiple of 2.                   */
     const void*    wtab;         /* float32 [n_phases][16]: per tap, phi and phi' / (R dt)     */
     int64_t        n_phases;
     const void*    tbank;        /* float32: band values / (phi_hat m) of the interpolated rows */

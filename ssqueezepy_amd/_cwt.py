@@ -20,7 +20,7 @@ from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc, CwtTilesDesc
 from . import algos
 from ._bank import banded_bank
 from ._blocks import plan_blocks, L_MIN
-from ._tiles import plan_tiles
+from ._tiles import plan_tiles, RSUB as _tiles_rsub
 from .padding import pad_geometry, PADTYPES
 from .scales import process_scales, _process_fs_and_t
 from .wavelets import Wavelet
@@ -158,7 +158,7 @@ class CwtPlan():
         irows, classes = c(tp['irows'], np.int64), c(tp['classes'], np.int64)
         d = CwtTilesDesc()
         d.n_segs, d.segs = len(segs), segs.ctypes.data
-        d.n_steps, d.rows = len(rws) // 4, rws.ctypes.data
+        d.n_steps, d.rows = len(rws) // _tiles_rsub, rws.ctypes.data
         d.wtab, d.n_phases = wtab.ctypes.data, len(wtab)
         d.tbank, d.n_tbank = tbank.ctypes.data, len(tbank)
         d.n_irows, d.irows = len(irows), irows.ctypes.data

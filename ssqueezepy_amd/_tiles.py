@@ -50,7 +50,8 @@ R_MIN = 4             # least decimation for which a row leaves the block kernel
 R_MAX = 4096
 L_MINLEN = 64         # shortest decimated row
 COLS = 64             # columns per workgroup of the tile kernel (one per lane)
-RSUB = 4              # rows per step
+RSUB = 4              # rows per step (TILE_G of the kernel)
+STEPS_PER_TICKET = 2  # the kernel takes its ticket once per this many consecutive steps
 KIND_READBACK, KIND_INTERP = 0, 1
 
 
@@ -186,7 +187,7 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
         else:
             segs.append([KIND_READBACK, first, nsteps, 0, 0, 0, 0, 0])
         i = j
-    if (len(rowdesc) // RSUB) % 2:                # the kernel takes its ticket once per pair of steps
+    while (len(rowdesc) // RSUB) % STEPS_PER_TICKET:       # whole groups of steps: pad with no-op steps
         last = rowdesc[-1]
         for _ in range(RSUB):
             rowdesc.append([(last[0] & 0xFFFF) - 2 ** 31, last[1], last[2], last[3]])

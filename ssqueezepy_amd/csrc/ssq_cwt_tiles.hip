@@ -41,7 +41,10 @@ namespace ssq {
 #include "ssq_point_math.inl"
 
 constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
-constexpr int TILE_G = 4;         // rows per step
+// rows per step x steps per ticket (a wavefront takes TILE_B consecutive steps). Measured on one
+// box (config 2, tile stage): 4 x 2 -> 330 us; 2 x 4 -> 361 us, with 8 or with 12 wavefronts alike
+constexpr int TILE_G = 4;
+constexpr int TILE_B = 2;
 constexpr int TILE_W = 8;         // taps
 
 struct TileArgs {
@@ -224,11 +227,11 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // different decimation classes, so ONE software pipeline runs over all of them, across
     // tiles: records two steps ahead (they hold the addresses), samples and interpolation
     // weights one step ahead.
-    const int npairs = A.nsteps / 2;
+    const int npairs = A.nsteps / TILE_B;                    // groups of TILE_B steps ("pairs" when it was 2)
     const int mypairs = npairs > wv ? (npairs - wv + NW - 1) / NW : 0;
-    const int nmine = 2 * mypairs;                           // steps per tile
+    const int nmine = TILE_B * mypairs;                      // steps per tile
     const int jtot = nmine * ntl;
-    auto gstep = [&](int j) { return 2 * (wv + (j >> 1) * NW) + (j & 1); };
+    auto gstep = [&](int j) { return TILE_B * (wv + (j / TILE_B) * NW) + (j % TILE_B); };
     auto tbase = [&](int itl) { return itl * (npairs + 2); };   // ticket of the tile's first pair
 
     // rows k = wv, wv + NW, ... of the finished tile go to Tx and are cleared; the last
@@ -322,16 +325,17 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     load_rec(jl);
     ssq_f2 wt[TILE_W];                        // (phi_t, phi'_t / (R dt)) of the class in hand
     int wt_off = -1, wt_phase = -1;
-    for (int jj = 0; jj < jtot; jj += 2) {
-        int cells[2][TILE_G]; float2 vs[2][TILE_G];
+    for (int jj = 0; jj < jtot; jj += TILE_B) {
+        int cells[TILE_B][TILE_G]; float2 vs[TILE_B][TILE_G];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            if (tr && itl == 2) TILE_STAMP(jc + b, 0);
-            int (&cell)[TILE_G] = cells[b]; float2 (&v)[TILE_G] = vs[b];
+        for (int st = 0; st < TILE_B; ++st) {
+            const int b = st & 1;                               // sample buffer of this step
+            if (tr && itl == 2) TILE_STAMP(jc + st, 0);
+            int (&cell)[TILE_G] = cells[st]; float2 (&v)[TILE_G] = vs[st];
             // the next step: its samples now (its records came in during the previous step),
             // then the records of the one after
             auto prefetch = [&]() {
-                if (jj + b + 1 < jtot) load(b ^ 1, tl);
+                if (jj + st + 1 < jtot) load(b ^ 1, tl);
                 if (++jl == nmine) { jl = 0; advance(tl); }
                 load_rec(jl);
             };
@@ -427,25 +431,25 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     v[r] = act ? make_float2(Wv.x * cs, Wv.y * cs) : make_float2(0.f, 0.f);
                 }
             }
-            if (tr && itl == 2) TILE_STAMP(jc + b, 2);
+            if (tr && itl == 2) TILE_STAMP(jc + st, 2);
         }
         // the pair's update, in ticket order (the previous tile is written out first)
-        int src[2][TILE_G];
-        forward4(cells[0], src[0]);
-        forward4(cells[1], src[1]);
+        int src[TILE_B][TILE_G];
+#pragma unroll
+        for (int st = 0; st < TILE_B; ++st) forward4(cells[st], src[st]);
         if (jc == 0 && itl > 0) {
             if (tr && itl == 2) TILE_STAMP(0, 5);
             write_out(tp, itl - 1);
             if (tr && itl == 2) TILE_STAMP(0, 6);
         }
-        const int g = tbase(itl) + (gstep(jc) >> 1);
+        const int g = tbase(itl) + gstep(jc) / TILE_B;
         take_turn(turn, g);
         if (tr && itl == 2) TILE_STAMP(jc, 3);
-        update4(T, cells[0], vs[0], src[0]);
-        update4(T, cells[1], vs[1], src[1]);
+#pragma unroll
+        for (int st = 0; st < TILE_B; ++st) update4(T, cells[st], vs[st], src[st]);
         pass_turn(turn, g, c);
         if (tr && itl == 2) TILE_STAMP(jc, 4);
-        jc += 2;
+        jc += TILE_B;
         if (jc == nmine) { jc = 0; ++itl; tp = tc; advance(tc); }
     }
     write_out(tp, ntl - 1);
@@ -457,8 +461,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                      double dt_, int64_t& bytes) {
     M = M_; N = N_; n1 = n1_; na = na_; group = group_; dt = dt_;
     nsegs = d.n_segs; nsteps = d.n_steps; n_irows = d.n_irows; u_total = d.u_total;
-    SSQ_REQUIRE(nsegs >= 1 && nsteps >= 2 && nsteps % 2 == 0 && n_irows >= 1 && d.n_classes >= 1,
-                "empty tile tables or an odd number of steps");
+    SSQ_REQUIRE(nsegs >= 1 && nsteps >= TILE_B && nsteps % TILE_B == 0 && n_irows >= 1 && d.n_classes >= 1,
+                "empty tile tables, or the number of steps is not a multiple of %d", TILE_B);
     SSQ_REQUIRE((size_t)(na + 1) * TILE_COLS * 8 + 16 <= 160 * 1024 && na * N < ((int64_t)1 << 29), "na = %lld: the Tx tile exceeds the LDS",
                 (long long)na);
     SSQ_REQUIRE((int64_t)group * u_total < ((int64_t)1 << 31), "tile intermediates exceed 2^31 entries");

@@ -30,7 +30,8 @@ def test_tile_tables_cover_every_row_once_in_order():
     wav, scales, M, n1, n2, vals, off, lo, bp, tp = _plan(6000, 16)
     na = len(scales)
     rows, segs = tp['rows'], tp['segs']
-    assert len(rows) % (2 * RSUB) == 0                       # an even number of steps
+    from ssqueezepy_amd._tiles import STEPS_PER_TICKET
+    assert len(rows) % (STEPS_PER_TICKET * RSUB) == 0        # whole groups of steps
     real = rows[rows[:, 0] >= 0, 0]
     assert np.array_equal(real, np.arange(na))               # ascending: the summation order
     pads = rows[rows[:, 0] < 0, 0]
