@@ -381,6 +381,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                         SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
                         SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                         SSQ_LDS_WAIT();
+                        if (tr && itl == 2 && r == 0) TILE_STAMP(jc + st, 1);
+                        if (tr && itl == 2 && r == 1) TILE_STAMP(jc + st, 7);
 #pragma unroll
                         for (int t = 0; t < TILE_W; ++t) {
                             ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
