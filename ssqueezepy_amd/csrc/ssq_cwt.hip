@@ -217,8 +217,9 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
     TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
     {
-        // default: up to 8 signals per launch, bin maps bounded to ~2 GiB
-        int64_t g = std::min<int64_t>(8, std::max<int64_t>(1, ((int64_t)1 << 30) / (d.na * d.n)));
+        // default: up to 16 signals per launch (measured at config 2: 16 -> +1 % over 8), bin maps
+        // bounded to ~2 GiB
+        int64_t g = std::min<int64_t>(16, std::max<int64_t>(1, ((int64_t)1 << 30) / (d.na * d.n)));
         if (const char* e = getenv("SSQ_CWT_GROUP")) g = atoi(e);
         pl->group = (int)std::max<int64_t>(1, std::min<int64_t>(g, pl->d.max_batch));
     }
