@@ -50,9 +50,11 @@ def main(n_cases=30, seed=0):
                 xb = np.stack([x, x[::-1].copy(), 2 * x])
                 Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales=st, nv=nv, padtype=pad, astensor=False)
                 ok = np.array_equal(Wb[0], Wx) and np.array_equal(Tb[0], Tx)
-                out = S.ssq_cwt(x, wav, scales=st, nv=nv, padtype=pad, get_w=True,
+                # (the two-step form runs every row on the block kernels: its own Wx / dWx)
+                out = S.ssq_cwt(x, wav, scales=st, nv=nv, padtype=pad, get_w=True, get_dWx=True,
                                 astensor=False)
-                ok = ok and np.array_equal(out[4], orc.phase_cwt(out[1], dWx, r['gamma'], typing=0))
+                ok = ok and np.array_equal(out[4], orc.phase_cwt(out[1], out[5], r['gamma'], typing=0))
+                ok = ok and relmax(out[1], r['Wx']) <= tol
             print('cwt ', dtype, fam, st, pad, 'N=%d nv=%d na=%d' % (N, nv, len(sc)),
                   'eW=%.1e eD=%.1e' % (eW, eD), 'OK' if ok else 'MISMATCH')
         else:
