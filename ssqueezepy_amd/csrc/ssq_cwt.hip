@@ -146,6 +146,7 @@ struct ssq_cwt_plan {
     WeightVersions weights;
     float cst0 = 0.f;                     // first weight (all of them when sp.cst_uniform)
     PlanOrder order;
+    GraphCache graphs;                    // replayed launches of small transforms
     std::string algo = "rocfft";
     // rows evaluated by the exact full-length path (all rows unless a block plan
     // took some over)
@@ -249,6 +250,7 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     for (hipEvent_t e : pl->tev) (void)hipEventDestroy(e);
     pl->weights.destroy();
     pl->order.destroy();
+    pl->graphs.destroy();
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
                     pl->kidx, pl->gen_rows, pl->all_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -526,11 +528,36 @@ int ssq_cwt_execute(ssq_cwt_plan* pl, const void* x, int64_t batch, void* Wx, vo
     SSQ_REQUIRE(!Tx || pl->have_ssq, "Tx requested but ssq parameters were not set");
     SSQ_REQUIRE(!w || pl->have_ssq, "w requested but ssq parameters (gamma) were not set");
     SSQ_REQUIRE(Wx, "Wx buffer is required");
-    pl->order.enter(as_stream(stream));
-    int rc = pl->d.dtype == SSQ_F32
-        ? cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream))
-        : cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, as_stream(stream));
-    pl->order.leave(as_stream(stream));
+    hipStream_t st = as_stream(stream);
+    pl->order.enter(st);
+    auto run_on = [&](hipStream_t q) {
+        return pl->d.dtype == SSQ_F32 ? cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, q)
+                                      : cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, q);
+    };
+    auto run = [&]() { return run_on(st); };
+    int rc;
+    // launch-bound sizes only (below ~64 MB of output the launches cost as much as the kernels)
+    const bool small = (double)batch * pl->d.na * pl->d.n * pl->csize() <= 64e6 && !pl->timing && pl->executed;
+    if (!small) rc = run();
+    else {
+        const SsqParams& sp = pl->sp;
+        uint64_t ph = 1469598103934665603ull;
+        for (size_t i = 0; i < sizeof(SsqParams); ++i) ph = (ph ^ ((const unsigned char*)&sp)[i]) * 1099511628211ull;
+        const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)x, (uint64_t)batch, (uint64_t)(uintptr_t)Wx,
+                                           (uint64_t)(uintptr_t)dWx, (uint64_t)(uintptr_t)Tx, (uint64_t)(uintptr_t)w,
+                                           (uint64_t)rpadded, (uint64_t)(uintptr_t)pl->cst, pl->have_ssq ? ph : 0,
+                                           (uint64_t)(uintptr_t)st};
+        bool capture = false, rerun = false; size_t slot = 0;
+        int g = pl->graphs.begin(key, st, &capture, &slot);
+        if (g == 1) rc = 0;
+        else if (!capture) rc = run();
+        else {                                   // record on the plan's capture stream, launch on `st`
+            rc = run_on(pl->graphs.cap);
+            rc = pl->graphs.finish(slot, st, rc, &rerun);
+            if (rerun) rc = run();
+        }
+    }
+    pl->order.leave(st);
     return rc;
 }
 

@@ -97,6 +97,14 @@ constexpr int hipEventDisableTiming = 2;
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, int) { *e = (hipEvent_t)1; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, int) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+typedef void* hipGraph_t; typedef void* hipGraphExec_t;
+constexpr int hipStreamCaptureModeRelaxed = 2;
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }      // no graphs under the emulator
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return 1; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 1; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 constexpr int hipStreamNonBlocking = 1;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

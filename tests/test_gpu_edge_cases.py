@@ -174,3 +174,35 @@ def test_plan_reuse_across_streams_and_parameter_changes(S):
     torch.cuda.synchronize()
     for h, T in outs:
         assert torch.equal(T, r2[h])
+
+
+def test_small_transforms_replay_their_launches(S):
+    """With SSQ_GRAPHS=1 launch-bound sizes are replayed from a hipGraph once a call repeats
+    with the same buffers (csrc/ssq_common.h: GraphCache; off by default -- replay measured
+    slower than eager launches): results must equal the eager ones, follow the contents of
+    the input buffer, and follow a change of parameters. (The switch is read once per process:
+    run this module with SSQ_GRAPHS=1 to exercise the replay; without it the same assertions
+    hold for the eager path.)"""
+    import torch
+    from ssqueezepy_amd import _cwt
+    N = 10000
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32)[:300]
+    x = torch.as_tensor(two_chirps(N, seed=2), dtype=torch.float32, device='cuda')
+    ref = S.cwt(x, wav, scales=scales)[0].clone()
+    for _ in range(8):                       # torch hands out the same two output buffers in turn
+        out = S.cwt(x, wav, scales=scales)[0]
+        assert torch.equal(out, ref)
+    x.copy_(torch.as_tensor(two_chirps(N, seed=5), dtype=torch.float32))
+    for _ in range(3):
+        out = S.cwt(x, wav, scales=scales)[0]
+    _cwt.clear_plan_cache()                  # a fresh plan: eager launches
+    assert torch.equal(out, S.cwt(x, wav, scales=scales)[0])
+    y = torch.as_tensor(two_chirps(4096, seed=9), dtype=torch.float32, device='cuda')
+    refs = {fl: S.ssq_cwt(y, wav, scales='log', nv=8, flipud=fl)[0].clone() for fl in (True, False)}
+    for _ in range(6):
+        for fl in (True, False):
+            assert torch.equal(S.ssq_cwt(y, wav, scales='log', nv=8, flipud=fl)[0], refs[fl])
+    r3 = S.ssq_stft(y, n_fft=256, hop_len=64)[0].clone()
+    for _ in range(6):
+        assert torch.equal(S.ssq_stft(y, n_fft=256, hop_len=64)[0], r3)
