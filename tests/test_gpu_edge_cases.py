@@ -206,3 +206,17 @@ def test_small_transforms_replay_their_launches(S):
     r3 = S.ssq_stft(y, n_fft=256, hop_len=64)[0].clone()
     for _ in range(6):
         assert torch.equal(S.ssq_stft(y, n_fft=256, hop_len=64)[0], r3)
+
+
+def test_batches_larger_than_a_launch_group(S):
+    """A batch is walked in launch groups (16 signals by default): the last, partial group and
+    the reuse of the group's workspaces (bin map, decimated samples of the tile path) between
+    groups must not leak from one signal into another."""
+    import torch
+    N, B = 6000, 21
+    wav = S.Wavelet()
+    xb = np.stack([two_chirps(N, seed=100 + s) for s in range(B)])
+    Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=16)
+    for s in (0, 7, 15, 16, 20):
+        T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=16)
+        assert torch.equal(Tb[s], T1) and torch.equal(Wb[s], W1), s

@@ -161,3 +161,18 @@ def test_tile_path_emulated_vs_oracle():
         assert np.array_equal(Tb[0], Tx) and np.array_equal(Wb[0], Wx)
         T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales=st, nv=16, astensor=False)
         assert np.array_equal(Tb[1], T1) and np.array_equal(Wb[1], W1)
+
+
+def test_tile_path_emulated_partial_launch_group():
+    """More signals than a launch group holds, under the emulator: the partial last group and
+    the workspaces reused between groups (see tests/test_gpu_edge_cases.py)."""
+    import emu_backend
+    from conftest import two_chirps
+    N, B = 2200, 18
+    xb = np.stack([two_chirps(N, seed=300 + s) for s in range(B)])
+    with emu_backend.emulated() as S:
+        wav = S.Wavelet()
+        Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=8, astensor=False)
+        for s in (0, 15, 16, 17):
+            T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=8, astensor=False)
+            assert np.array_equal(Tb[s], T1) and np.array_equal(Wb[s], W1), s
