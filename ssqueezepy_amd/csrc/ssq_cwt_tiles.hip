@@ -345,9 +345,9 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                 for (int r = 0; r < TILE_G; ++r) {
                     const int kk = xk[b][r];
                     const bool act = xr[b][r] >= 0 && tc.colok && kk != 0xFFFF;
-                    const float cs = CSTU ? A.cst0 : xc[b][CSTU ? 0 : r];
+                    const float cs = act ? (CSTU ? A.cst0 : xc[b][CSTU ? 0 : r]) : 0.f;
                     cell[r] = act ? kk * TILE_COLS + c : scratch;
-                    v[r] = act ? make_float2(xu[b][r].x * cs, xu[b][r].y * cs) : make_float2(0.f, 0.f);
+                    v[r] = make_float2(xu[b][r].x * cs, xu[b][r].y * cs);
                 }
             } else {
                 float2* Wx = A.Wx + tc.obase;
@@ -363,6 +363,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     wt_off = __builtin_amdgcn_readfirstlane(xwoff[b]); wt_phase = phase;
                 }
                 const int baddr = xbaddr[b];
+                unsigned pend = 0;
+                float2 Wk[TILE_G], Dk[TILE_G];
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
                     if (r == TILE_G / 2) prefetch();
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
                     // (M <= 2^24), v_sin_f32 / v_cos_f32 take revolutions (measured on the
                     // M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
-                    const float rev = (float)(((unsigned)xkc[b][r] * (unsigned)tc.nabs) & (unsigned)A.mmask) * A.inv_m;
+                    const float rev = (float)(__umul24((unsigned)xkc[b][r], (unsigned)tc.nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
                     const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
                     const float2 Wv = cmulf(tw, make_float2(are, aim));
                     const float2 Dv = cmulf(tw, make_float2(dre, dim));
@@ -417,20 +419,27 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
                     bool ok;
                     const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
-                    int kf = (kb ^ fx) + fa;
+                    const int kf = (kb ^ fx) + fa;
                     const bool live = tc.colok && !pad;
-                    bool act = above && live;
-                    // undecided by the float32 screens (~0.05 % of the points): the exact double path
-                    const bool und = live && !(below | (above & ok));
-                    if (__builtin_amdgcn_ballot_w64(und)) {
-                        if (und) {
-                            kf = exact_bin(Wv, Dv, sp, omax, A.gamma);
-                            act = kf >= 0;
-                        }
-                    }
-                    const float cs = CSTU ? A.cst0 : xc[b][CSTU ? 0 : r];
+                    const bool act = above && live;
+                    // undecided by the float32 screens (~0.05 % of the points): the exact double
+                    // path, looked at once per step
+                    if (live && !(below | (above & ok))) pend |= 1u << r;
+                    // (a point without contribution adds 0 * Wx to the lane's scratch cell)
+                    const float cs = act ? (CSTU ? A.cst0 : xc[b][CSTU ? 0 : r]) : 0.f;
                     cell[r] = act ? kf * TILE_COLS + c : scratch;
-                    v[r] = act ? make_float2(Wv.x * cs, Wv.y * cs) : make_float2(0.f, 0.f);
+                    v[r] = make_float2(Wv.x * cs, Wv.y * cs);
+                    Wk[r] = Wv; Dk[r] = Dv;
+                }
+                if (__builtin_amdgcn_ballot_w64(pend != 0)) {
+#pragma unroll
+                    for (int r = 0; r < TILE_G; ++r)
+                        if (pend & (1u << r)) {
+                            const int ke = exact_bin(Wk[r], Dk[r], sp, omax, A.gamma);
+                            const float cs = ke >= 0 ? (CSTU ? A.cst0 : xc[b][CSTU ? 0 : r]) : 0.f;
+                            cell[r] = ke >= 0 ? ke * TILE_COLS + c : scratch;
+                            v[r] = make_float2(Wk[r].x * cs, Wk[r].y * cs);
+                        }
                 }
             }
             if (tr && itl == 2) TILE_STAMP(jc + st, 2);
@@ -580,12 +589,12 @@ static int launch_tile_c(const TileArgs& A, const SsqParams& sp, int64_t N, int6
     SSQ_LAUNCH_CHECK();
     return 0;
 }
-// wavefronts per workgroup: 8 by default (SSQ_TILE_K = 1 | 2 | 3 -> 4, 8, 12: tuning aid)
+// wavefronts per workgroup: 8 by default (SSQ_TILE_K = 1 -> 4: tuning aid; 12 need more than the
+// 168 VGPRs three wavefronts per SIMD leave and measured no faster)
 template <int GRID, bool STORE_D>
 static int launch_tile(const TileArgs& A, const SsqParams& sp, int64_t N, int64_t na, int nsig, hipStream_t stream) {
     static const int k = [] { const char* e = getenv("SSQ_TILE_K"); int v = e ? atoi(e) : 2; return v < 1 || v > 3 ? 2 : v; }();
     if (k == 1) return launch_tile_k<GRID, STORE_D, 4>(A, sp, N, na, nsig, stream);
-    if (k == 3) return launch_tile_k<GRID, STORE_D, 12>(A, sp, N, na, nsig, stream);
     return launch_tile_k<GRID, STORE_D, 8>(A, sp, N, na, nsig, stream);
 }
 
