@@ -220,3 +220,18 @@ def test_batches_larger_than_a_launch_group(S):
     for s in (0, 7, 15, 16, 20):
         T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=16)
         assert torch.equal(Tb[s], T1) and torch.equal(Wb[s], W1), s
+
+
+def test_tile_path_with_few_scales_and_many_tiles(S, orc):
+    """Few scales (wavefronts of the tile kernel without a step of their own) and a length that
+    gives every persistent workgroup several tiles, the last one partial."""
+    from pipeline import oracle_ssq_cwt, GRIDNAME
+    for N, nv in ((70001, 2), (33333, 1)):
+        x = two_chirps(N, seed=N)
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, S.Wavelet(), scales='log', nv=nv, get_dWx=True,
+                                        astensor=False)
+        r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
+        assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
+        ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
+                           True, typing=0)
+        assert np.array_equal(Tx, ref)

@@ -176,3 +176,26 @@ def test_tile_path_emulated_partial_launch_group():
         for s in (0, 15, 16, 17):
             T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=8, astensor=False)
             assert np.array_equal(Tb[s], T1) and np.array_equal(Wb[s], W1), s
+
+
+def test_tile_path_emulated_fewer_steps_than_wavefronts():
+    """Very few scales: some wavefronts of the tile kernel have no step at all and only take
+    part in the write-out of each tile."""
+    import emu_backend
+    from oracle import oracle as orc
+    from pipeline import oracle_ssq_cwt, GRIDNAME
+    from conftest import two_chirps
+    with emu_backend.emulated() as S:
+        from ssqueezepy_amd import _cwt
+        for N, nv in ((4500, 2), (8000, 1)):
+            x = two_chirps(N, seed=N)
+            _cwt.clear_plan_cache()
+            Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, S.Wavelet(), scales='log', nv=nv, get_dWx=True,
+                                            astensor=False)
+            plan = next(iter(_cwt._PLAN_CACHE.values()))
+            assert 'tiles' in plan.algo and plan.na < 32
+            r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
+            assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
+            ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
+                               True, typing=0)
+            assert np.array_equal(Tx, ref)
