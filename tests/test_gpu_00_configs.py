@@ -181,3 +181,27 @@ def test_config1_cwt_vs_oracle(S, orc):
                       1., n1, N, derivative=True)
     assert np.abs(Wx - Wr).max() <= 1e-5 * np.abs(Wr).max()
     assert np.abs(dWx - dWr).max() <= 1e-5 * np.abs(dWr).max()
+
+
+def test_default_arguments_full_size_vs_oracle(S, orc):
+    """`ssq_cwt(x)` as a caller of the reference writes it (default 'log-piecewise' scales,
+    nv = 32: 293 rows at N = 160 000 -- the scale type of the reference's own benchmark,
+    examples/benchmarks.py:85) at full size, through the tile path."""
+    from ssqueezepy_amd import _cwt
+    from pipeline import oracle_ssq_cwt
+    N = 160000
+    x = two_chirps(N, seed=11)
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, get_dWx=True, astensor=False)
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+    if os.environ.get('SSQ_CWT_TILES', '1') != '0' and os.environ.get('SSQ_EMULATE') != '1':
+        assert 'tiles' in plan.algo
+    r = oracle_ssq_cwt(orc, x, 'float32', scales='log-piecewise')
+    assert np.array_equal(sf, r['ssq_freqs']) and np.array_equal(sc, r['scales'])
+    assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
+    assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()
+    ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'], True,
+                       typing=0, parallel=True)
+    assert np.array_equal(Tx, ref)
+    cs, cr = Tx.sum(0), r['Tx'].sum(0)
+    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
