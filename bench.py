@@ -17,12 +17,16 @@ Prints ONE JSON line on rank 0: transforms/s (whole job), ms per step, plus
   roofline     algorithmic HBM bytes (x in + Tx, Wx out = N*4 + 2*na*N*8 per
                transform) / measured time, against the 8 TB/s
                HBM3E peak. Measured with HIP events on the launch stream over the
-               timed region, for the whole transform (all of its kernels): the
-               pipeline has no single dominant kernel yet, so the whole-transform
-               figure is the honest one; per-kernel times are in profiles/.
-  cpu_baseline the CPU oracle pipeline (scipy.fft with all host cores + the OpenMP
-               C restatement of the reference's loop nests, oracle/) on ONE
-               transform of the same workload, same box, core count stated.
+               timed region, for the whole transform (all of its kernels); `traffic` is
+               the PMC figure of the same command (profiles/pmc_traffic.json).
+  dominant_kernel
+               the column-tile kernel (interpolation + reassignment, ~2/3 of the time):
+               its own bytes / its own time from the plan's HIP-event stage timing;
+               rocprofv3 --kernel-trace --stats of this command: profiles/r2*_kernel_stats.txt.
+  cpu_baseline the CPU oracle pipeline (scipy.fft on 64 threads + the OpenMP C
+               restatement of the reference's loop nests, oracle/) on a bounded sample of
+               the same workload, same box, core count stated (kind "port").
+`--gpus N` without a launcher starts the N ranks itself (torch.distributed.run).
 """
 import argparse
 import json
