@@ -42,7 +42,8 @@ namespace ssq {
 
 constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
 // rows per step x steps per ticket (a wavefront takes TILE_B consecutive steps). Measured on one
-// box (config 2, tile stage): 4 x 2 -> 330 us; 2 x 4 -> 361 us, with 8 or with 12 wavefronts alike
+// box (config 2, tile stage): 4 x 2 -> 330 us; 2 x 4 -> 361 us, with 8 or with 12 wavefronts alike;
+// 4 x 4 -> 413 us (20 tickets for 8 wavefronts: uneven shares, longer waits)
 constexpr int TILE_G = 4;
 constexpr int TILE_B = 2;
 constexpr int TILE_W = 8;         // taps
