@@ -114,6 +114,10 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='signals per GPU per step')
     ap.add_argument('--n', type=int, default=160000)
     ap.add_argument('--na', type=int, default=300)
+    ap.add_argument('--scales', default='log', choices=['log', 'log-piecewise'],
+                    help="'log' = BASELINE config 2 (the first --na of nv=32 log scales); "
+                         "'log-piecewise' = the reference's default scales (ssq_cwt(x) without "
+                         "arguments; float64 per-row reassignment weights; --na is ignored)")
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--gather-tx', action='store_true',
                     help='N > 1: also time one step followed by an all_gather of the full Tx '
@@ -163,7 +167,11 @@ def main():
     import ssqueezepy_amd as S
     N, na, B = args.n, args.na, args.batch
     wav = S.Wavelet()
-    scales = S.process_scales('log', N, wav, nv=32)[:na]
+    if args.scales == 'log':
+        scales = S.process_scales('log', N, wav, nv=32)[:na]
+    else:
+        scales = 'log-piecewise'
+        na = len(S.process_scales(scales, N, wav, nv=32))
     # weak scaling: the job's batch is B*world signals; rank r owns a contiguous block
     # (ssqueezepy_amd/sharding.py) -- its own signals, its own plan, no exchange
     from ssqueezepy_amd.sharding import shard_bounds, gather_summaries, signal_summary
@@ -259,8 +267,8 @@ def main():
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "ssq_cwt('gmw'), N=%d, %d log scales (nv=32), "
-                                   "float32, two-chirp+noise" % (N, na),
+            "config": {"workload": "ssq_cwt('gmw'), N=%d, %d %s scales (nv=32), "
+                                   "float32, two-chirp+noise" % (N, na, args.scales),
                        "signals_per_gpu_per_step": B,
                        "sharding": "independent signals per rank, no data-path "
                                    "collective; one all_gather of checksums",
@@ -297,7 +305,7 @@ def main():
                 "bytes_moved": acc_bytes,
                 "GBps": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9,
                 "frac_of_hbm_peak": acc_bytes / (stages["reassignment_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and not args.no_cpu:
+        if world == 1 and not args.no_cpu and args.scales == 'log':
             try:
                 line["cpu_baseline"] = cpu_baseline(N, na)
             except Exception as e:              # never lose the GPU number

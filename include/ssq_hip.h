@@ -286,7 +286,7 @@ typedef struct {
     int32_t        n_steps;
     const int32_t* rows;         /* 4 n_steps x 4: row (sign bit: repeats the previous row to  */
                                  /* pad a step), offset in class, kc, theta = 2 pi kc / (m dt) */
-                                 /* (float bits). n_steps is a multiple of 2.                   */
+                                 /* (float bits). The rows of a step are consecutive.           */
     const void*    wtab;         /* float32 [n_phases][16]: per tap, phi and phi' / (R dt)     */
     int64_t        n_phases;
     const void*    tbank;        /* float32: band values / (phi_hat m) of the interpolated rows */
@@ -297,7 +297,7 @@ typedef struct {
     const int64_t* classes;      /* n_classes x 4: L, rows, entries per signal before it, log2 R */
     int64_t        u_total;      /* complex entries of the intermediate per signal             */
     int64_t        n_items_tile[5]; /* per L': leading block items that remain (rows read back) */
-    int32_t        n_exact_tile;    /* leading exact rows that remain (all of them today)      */
+    int32_t        reserved;
 } ssq_cwt_tiles_desc;
 
 int  ssq_cwt_plan_set_tiles(ssq_cwt_plan* plan, const ssq_cwt_tiles_desc* desc);
@@ -312,6 +312,12 @@ int  ssq_cwt_plan_timing(ssq_cwt_plan* plan, int enable, double* stage_ms, int64
 /* signals a plan processes per kernel launch (its launch group; the batch is walked in
  * groups of this size) */
 int  ssq_cwt_plan_group(const ssq_cwt_plan* plan);
+
+/* What executed: the number of 64-column tiles the column-tile kernel has finished on this
+ * plan since its creation (0 without tile tables). Synchronises `stream`. An execute that took
+ * the tile path adds batch * ceil(n / 64); one that took the block path + separate reassignment
+ * adds nothing. (Tests assert on this rather than on the plan's `algo` label.) */
+int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
 
 /* bytes of device memory held by the plan (bank + workspace) */
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);

@@ -166,7 +166,6 @@ class CwtPlan():
         d.u_total = tp['u_total']
         for slot in range(5):
             d.n_items_tile[slot] = n_items_tile[slot]
-        d.n_exact_tile = int(n_exact)
         check(self.lib.ssq_cwt_plan_set_tiles(self._h, ctypes.byref(d)))
         self.tile_rows = int(tp['interp_rows'].sum())
         self.tile_plan = {k: tp[k] for k in ('lgR', 'interp_rows', 'classes')}
@@ -183,6 +182,11 @@ class CwtPlan():
     @property
     def algo(self):
         return self.lib.ssq_cwt_plan_algo(self._h).decode()
+
+    def tiles_done(self):
+        """64-column tiles the column-tile kernel has finished on this plan so far (what
+        actually executed, as opposed to what `algo` says was planned); synchronises."""
+        return int(self.lib.ssq_cwt_plan_tiles_done(self._h, algos.stream()))
 
     @property
     def device_bytes(self):

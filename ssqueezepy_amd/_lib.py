@@ -46,7 +46,7 @@ class CwtTilesDesc(Structure):
                 ('wtab', c_void_p), ('n_phases', c_int64),
                 ('tbank', c_void_p), ('n_tbank', c_int64), ('n_irows', c_int),
                 ('irows', c_void_p), ('n_classes', c_int), ('classes', c_void_p),
-                ('u_total', c_int64), ('n_items_tile', c_int64 * 5), ('n_exact_tile', c_int)]
+                ('u_total', c_int64), ('n_items_tile', c_int64 * 5), ('reserved', c_int)]
 
 
 class StftDesc(Structure):
@@ -113,6 +113,7 @@ _PROTOS = {
     'ssq_cwt_plan_group': (c_int, [c_void_p]),
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
+    'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),
     'ssq_stft_plan_destroy': (None, [c_void_p]),
     'ssq_stft_plan_set_ssq': (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double),

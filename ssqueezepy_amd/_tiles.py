@@ -51,7 +51,7 @@ R_MAX = 4096
 L_MINLEN = 64         # shortest decimated row
 COLS = 64             # columns per workgroup of the tile kernel (one per lane)
 RSUB = 4              # rows per step (TILE_G of the kernel)
-STEPS_PER_TICKET = 2  # the kernel takes its ticket once per this many consecutive steps
+STEPS_PER_TICKET = 1  # (steps are handed out one at a time)
 KIND_READBACK, KIND_INTERP = 0, 1
 
 

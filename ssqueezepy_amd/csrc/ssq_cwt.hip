@@ -261,7 +261,9 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
                          int cst_f64, int flipud, double gamma) {
     SSQ_REQUIRE(pl && params && cst, "ssq_cwt_plan_set_ssq: null pointer");
     SSQ_REQUIRE(grid >= SSQ_GRID_LOG && grid <= SSQ_GRID_LIN, "unknown grid kind %d", grid);
-    // (kernels receive SsqParams by value at launch: an execute already enqueued keeps its own)
+    // (kernels receive SsqParams by value at launch: an execute already enqueued keeps its own;
+    // the lock orders this update against an execute being enqueued by another host thread)
+    std::lock_guard<std::mutex> lock(pl->order.mu);
     for (int t = 0; t < 5; ++t) pl->sp.p[t] = params[t];
     pl->sp.grid = grid; pl->sp.flipud = flipud ? 1 : 0; pl->sp.gamma = gamma;
     pl->sp.cst_f64 = (cst_f64 && pl->d.dtype == SSQ_F32) ? 1 : 0;
@@ -275,7 +277,6 @@ int ssq_cwt_plan_set_ssq(ssq_cwt_plan* pl, int grid, const double* params, const
     }
     finalize_params(pl->sp);
     size_t bytes = (size_t)pl->d.na * ((cst_f64 || pl->d.dtype == SSQ_F64) ? 8 : 4);
-    std::lock_guard<std::mutex> lock(pl->order.mu);
     pl->cst0 = (cst_f64 || pl->d.dtype == SSQ_F64) ? (float)((const double*)cst)[0] : ((const float*)cst)[0];
     int rc = pl->weights.upload(&pl->cst, cst, bytes);
     if (rc) return rc;
@@ -346,6 +347,10 @@ int ssq_cwt_plan_timing(ssq_cwt_plan* pl, int enable, double* stage_ms, int64_t*
 }
 
 int ssq_cwt_plan_group(const ssq_cwt_plan* pl) { return pl ? pl->group : 0; }
+int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* pl, void* stream) {
+    if (!pl || !pl->tile) return 0;
+    return pl->tile->tiles_done(as_stream(stream));
+}
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* pl) { return pl ? pl->bytes : 0; }
 const char* ssq_cwt_plan_algo(const ssq_cwt_plan* pl) { return pl ? pl->algo.c_str() : ""; }
 
@@ -399,10 +404,9 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     const int64_t n_gen = use_blocks ? pl->n_gen : na;
     // fused ssq form on the column-tile path: block / exact kernels only for the rows the
     // tile kernel reads back, no separate reassignment launch
-    const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4 && !pl->sp.cst_f64;
+    const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4;
     if (use_blocks) {
-        int rc = pl->blk->spectra(pl->xp, batch, stream,
-                                  (pl->tile && Tx && !w && !rpadded && !pl->sp.cst_f64) ? pl->tile->class_need.data() : nullptr);
+        int rc = pl->blk->spectra(pl->xp, batch, stream, use_tiles ? pl->tile->class_need.data() : nullptr);
         if (rc) return rc;
     }
     mark(1);

@@ -38,15 +38,20 @@ struct TilePlan {
     double dt = 1.0;
     int nsegs = 0, nsteps = 0, n_irows = 0;
     int64_t u_total = 0, lmax = 0;
-    TileSeg* steps = nullptr;               // the segment record of every step
+    int npsteps = 0;                        // steps of interpolated rows (the producers' work list)
+    int ncu = 0;                            // persistent workgroups of the tile kernel (one per CU)
+    TileSeg* steps = nullptr;               // the segment record of every step (`first`: index among
+                                            // the producer steps, -1 for rows read back)
+    int32_t* psteps = nullptr;              // producer step -> step
     TileRow* rows = nullptr; TileIRow* irows = nullptr;
     void* wtab = nullptr; void* tbank = nullptr;
     void* U = nullptr;                      // group x u_total complex64
+    void* ring = nullptr;                   // bins of the producer steps in flight, per workgroup
+    unsigned long long* counters = nullptr; // [0]: tiles the kernel has finished since plan creation
     struct Cls { int64_t L, nrows, upre; };
     std::vector<Cls> cls;
     std::vector<FftPlan> ffts;              // one batched inverse per class
     int64_t n_items_tile[5] = {0, 0, 0, 0, 0};
-    int n_exact_tile = 0;
     std::vector<unsigned char> class_need;   // block classes the remaining block rows use
     // the intermediates (a spectra kernel + small FFTs) run on a side stream, beside the block /
     // exact kernels of the rows that are read back
@@ -60,6 +65,8 @@ struct TilePlan {
     // Wx of the interpolated rows, Tx of all rows (the other rows' Wx and bin map must be in place)
     int run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
             const void* cst, float cst0, const SsqParams& sp, hipStream_t stream);
+    // tiles finished by the tile kernel so far (synchronises `stream`): what actually ran
+    int64_t tiles_done(hipStream_t stream);
 };
 
 }  // namespace ssq

@@ -60,6 +60,7 @@ inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline double2 make_double2(double x, double y) { return double2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 // ------------------------------------------------------------------ runtime API ("device"
 // memory is host memory, streams and events are no-ops)
@@ -306,6 +307,8 @@ inline float atomicAdd(float* p, float v) { float old = *p; *p = old + v; return
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+// memory fences: the work-items of a workgroup are fibers of one OS thread
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 // v_sin_f32 / v_cos_f32: argument in revolutions
 inline float emu_sinf_rev(float x) { return (float)sin(6.283185307179586 * (double)x); }
 inline float emu_cosf_rev(float x) { return (float)cos(6.283185307179586 * (double)x); }

@@ -235,3 +235,75 @@ def test_tile_path_with_few_scales_and_many_tiles(S, orc):
         ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                            True, typing=0)
         assert np.array_equal(Tx, ref)
+
+
+def _tiles_of(N, B=1):
+    return B * ((N + 63) // 64)
+
+
+@pytest.mark.parametrize('case', ['log/linear', 'log/log-piecewise', 'log-piecewise', 'linear',
+                                  'log/f32-weights', 'log/f64-weights'])
+def test_tile_kernel_every_instantiation(S, orc, case):
+    """Every build of the column-tile kernel, at a length where the block path (M >= 4096) and
+    the tile (na <= 316) are both active: the three frequency-grid kinds x the three kinds of
+    reassignment weights (one float32; a float32 per row; a float64 per row -- the reference's
+    default 'log-piecewise' scales and its 'linear' scales, ssqueezing.py:126-128 ->
+    algos.py:66-79), with and without `dWx` stored. What is asserted on is what EXECUTED
+    (`plan.tiles_done()` counts the tiles the kernel finished), not the plan's label."""
+    import os
+    from ssqueezepy_amd import _cwt, _ssq_cwt
+    emulated = os.environ.get('SSQ_EMULATE') == '1'
+    N = 6100 if emulated else 20011
+    x = two_chirps(N, seed=7)
+    wav = S.Wavelet()
+    kw = dict(nv=16)
+    weights = None
+    if case == 'log/linear':
+        kw.update(scales='log', ssq_freqs='linear', maprange='maximal')
+    elif case == 'log/log-piecewise':
+        kw.update(scales='log', ssq_freqs='log-piecewise')
+    elif case == 'log-piecewise':
+        kw.update(scales='log-piecewise')
+    elif case == 'linear':
+        kw.update(scales='linear', nv=None)
+    else:
+        kw.update(scales='log')
+        weights = case.split('/')[1]
+    _cwt.clear_plan_cache()
+    _ssq_cwt._DESIGN_CACHE.clear()
+    if weights is None:
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, get_dWx=True, astensor=False, **kw)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        design = _ssq_cwt._ssq_design(wav, kw['scales'], kw['nv'] if kw['scales'] != 'linear' else 32,
+                                      N, 1., kw.get('ssq_freqs'), kw.get('maprange', 'peak'), True)
+        _, ssq_freqs, const, grid, params = design
+        assert np.array_equal(sf, ssq_freqs[::-1])
+        gamma = 10 * np.finfo(np.float32).eps
+        T2, W2, *_ = S.ssq_cwt(x, wav, astensor=False, **kw)
+        n_calls = 2
+    else:
+        # weights per row through the plan interface (the C ABI's `ssq_cwt_plan_set_ssq` with a
+        # vector): a float32 vector stays float32, a float64 one makes the sums go through double
+        import torch
+        design = _ssq_cwt._ssq_design(wav, 'log', 16, N, 1., None, 'peak', True)
+        scales_dt, ssq_freqs, _, grid, params = design
+        na = len(scales_dt.reshape(-1))
+        const = (np.log(2) / np.linspace(8, 32, na)).astype('float32' if weights.startswith('f32') else 'float64')
+        gamma = 10 * np.finfo(np.float32).eps
+        plan = _cwt.get_cwt_plan(wav, scales_dt, N, 'reflect', 1., True, 1)
+        plan.set_ssq(grid, params, const, True, gamma)
+        from ssqueezepy_amd import algos
+        xd = algos.to_device(x, torch.float32)
+        out = plan.execute(xd, want_dWx=True, want_Tx=True)
+        Tx, Wx, dWx = (out[k].cpu().numpy() for k in ('Tx', 'Wx', 'dWx'))
+        out = plan.execute(xd, want_Tx=True)
+        T2, W2 = out['Tx'].cpu().numpy(), out['Wx'].cpu().numpy()
+        n_calls = 2
+    if plan.tile_rows > 0:
+        assert plan.tiles_done() == n_calls * _tiles_of(N), (plan.tiles_done(), plan.algo)
+    if case != 'linear':
+        assert plan.tile_rows > 0.5 * plan.na, (plan.tile_rows, plan.na)
+    ref = orc.ssqueeze(Wx, dWx, GRIDNAME[grid], params, const, gamma, True, typing=0)
+    assert np.array_equal(Tx, ref)
+    # the lean build (no dWx stored) against the full one
+    assert np.array_equal(T2, Tx) and np.array_equal(W2, Wx)

@@ -147,7 +147,7 @@ def test_tile_path_emulated_vs_oracle():
             _cwt.clear_plan_cache()
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=st, nv=16, get_dWx=True, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
-            assert 'tiles' in plan.algo and plan.tile_rows > 0.5 * plan.na
+            assert plan.tile_rows > 0.5 * plan.na and plan.tiles_done() == (N + 63) // 64
             r = oracle_ssq_cwt(orc, x, 'float32', scales=st, nv=16)
             assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
             assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()
@@ -193,7 +193,7 @@ def test_tile_path_emulated_fewer_steps_than_wavefronts():
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, S.Wavelet(), scales='log', nv=nv, get_dWx=True,
                                             astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
-            assert 'tiles' in plan.algo and plan.na < 32
+            assert plan.tiles_done() == (N + 63) // 64 and plan.na < 32
             r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
             assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
             ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
