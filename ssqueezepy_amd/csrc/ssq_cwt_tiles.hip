@@ -53,7 +53,7 @@ constexpr int TILE_NOBIN = 0xFFFF;
 
 struct TileArgs {
     const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
-    const int* psteps;                               // producer step -> step
+    const TileSeg* psegs; const TileRow* prows;      // the same records, producer steps only (dense)
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
@@ -111,9 +111,10 @@ __device__ __forceinline__ void lds_store_relaxed(int* p, int v) {
 }
 
 // bin of a point the float32 screens could not decide (flipped as Tx wants it), or -1 when it
-// does not contribute: the exact double sequence of the CPU path. Kept out of line -- one
-// copy per kernel, ~0.05 % of the points.
-__device__ __attribute__((noinline)) int exact_bin(float2 W, float2 D, const SsqParams& sp, int omax, double gamma) {
+// does not contribute: the exact double sequence of the CPU path (~0.05 % of the points). Inline:
+// a call would put the parameters on the stack and make the compiler wait for every load in
+// flight at the join.
+__device__ __forceinline__ int exact_bin(float2 W, float2 D, const SsqParams& sp, int omax, double gamma) {
     if (!(mag_of(W.x, W.y) > gamma)) return -1;
     const int ke = (int)bin_of_point_exact(D.x, D.y, W.x, W.y, sp, (int64_t)omax);
     return sp.flipud ? omax - ke : ke;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         const int nst = A.nsteps;
         const int total = nst * ntl;
         struct USlot {
-            float2 W[TILE_G]; int kb[TILE_G];
+            float2 W[TILE_G]; unsigned short kb[TILE_G];   // (bins stay as loaded: a conversion here would wait for the load)
             float cf[TILE_G]; double cd[TILE_G];
             int nvalid, p, last_tx, last_sg; bool colok;
         };
@@ -253,44 +254,38 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         const double* cstd = (const double*)A.cst;
         constexpr int cstk = CSTK;
         TilePos lp = pos0;                                    // tile / step of the next load
-        int l_st = 0;
+        int l_st = 0, l_g = 0;
         TileCtx lt = ctx_of(lp.tx, lp.sg);
+        // Loads are issued unconditionally and in one sequence for both kinds of steps (past the
+        // last step: a repeat of valid addresses, marked empty): the compiler counts the loads in
+        // flight per path, and a path that skips some makes every wait a full drain.
         auto uload = [&](USlot& s) {
+            const bool real = l_g < total;
             const int2 e = L.steptab[l_st];
-            const int row0 = e.x & 0xFFFF, nvalid = (e.x >> 16) & 7, kind = e.x >> 20;
+            const int row0 = e.x & 0xFFFF, nvalid = real ? (e.x >> 16) & 7 : 0;
+            const bool interp = real && (e.x >> 20) != 0;
             s.nvalid = nvalid; s.colok = lt.colok;
-            s.last_tx = (l_st == nst - 1) ? lp.tx : -1; s.last_sg = lp.sg;
+            s.last_tx = (real && l_st == nst - 1) ? lp.tx : -1; s.last_sg = lp.sg;
+            const int p = lp.itl * nps + e.y;
+            s.p = interp ? p : -1;
+            const int slot = p & (TILE_RING - 1);
+            if (interp) while (lds_load_acquire(&L.flags[slot]) != p + 1) __builtin_amdgcn_s_sleep(1);
             const float2* Wx = A.Wx + lt.obase;
-            if (kind == 0) {
-                s.p = -1;
-                const unsigned short* kidx = A.kidx + lt.kbase;
+            // bins: from the ring (interpolated rows) or from the bin map (rows read back)
+            const unsigned short* bsrc = interp ? ring + (size_t)slot * (TILE_G * TILE_COLS) + c
+                                                : A.kidx + lt.kbase + (unsigned)lt.colc;
+            const unsigned bstr = interp ? TILE_COLS : nN;
+            const unsigned brow0 = interp ? 0u : (unsigned)row0;
 #pragma unroll
-                for (int r = 0; r < TILE_G; ++r) {
-                    const int row = row0 + (r < nvalid ? r : nvalid - 1);
-                    const unsigned o = (unsigned)row * nN + (unsigned)lt.colc;
-                    s.W[r] = Wx[o]; s.kb[r] = kidx[o];
-                }
-            } else {
-                const int p = lp.itl * nps + e.y;
-                s.p = p;
-                const int slot = p & (TILE_RING - 1);
-                while (lds_load_acquire(&L.flags[slot]) != p + 1) __builtin_amdgcn_s_sleep(1);
-                const unsigned short* rb = ring + (size_t)slot * (TILE_G * TILE_COLS) + c;
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) {
-                    const int row = row0 + (r < nvalid ? r : nvalid - 1);
-                    s.W[r] = Wx[(unsigned)row * nN + (unsigned)lt.colc];
-                    s.kb[r] = rb[r * TILE_COLS];
-                }
+            for (int r = 0; r < TILE_G; ++r) {
+                const int rr = r < nvalid ? r : (nvalid > 0 ? nvalid - 1 : 0);
+                s.W[r] = Wx[(unsigned)(row0 + rr) * nN + (unsigned)lt.colc];
+                s.kb[r] = bsrc[(brow0 + (unsigned)rr) * bstr];
+                if (cstk == 1) s.cf[r] = cstf[row0 + rr];
+                if (cstk == 2) s.cd[r] = cstd[row0 + rr];
             }
-            if (cstk == 1) {
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) s.cf[r] = cstf[row0 + (r < nvalid ? r : nvalid - 1)];
-            } else if (cstk == 2) {
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) s.cd[r] = cstd[row0 + (r < nvalid ? r : nvalid - 1)];
-            }
-            if (++l_st == nst) { l_st = 0; next_tile(lp); if (lp.itl < ntl) lt = ctx_of(lp.tx, lp.sg); }
+            ++l_g;
+            if (real && ++l_st == nst) { l_st = 0; next_tile(lp); if (lp.itl < ntl) lt = ctx_of(lp.tx, lp.sg); }
         };
         // the finished tile goes to Tx and is cleared
         auto write_out = [&](int tx, int sg) {
@@ -344,17 +339,11 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             if (s.last_tx >= 0) write_out(s.last_tx, s.last_sg);
         };
         USlot sl[TILE_D];
-        int loaded = 0;
 #pragma unroll
-        for (int k = 0; k < TILE_D; ++k) if (loaded < total) { uload(sl[k]); ++loaded; }
+        for (int k = 0; k < TILE_D; ++k) uload(sl[k]);
         for (int g0 = 0; g0 < total; g0 += TILE_D) {
 #pragma unroll
-            for (int k = 0; k < TILE_D; ++k) {
-                if (g0 + k < total) {
-                    uprocess(sl[k]);
-                    if (loaded < total) { uload(sl[k]); ++loaded; }
-                }
-            }
+            for (int k = 0; k < TILE_D; ++k) { uprocess(sl[k]); uload(sl[k]); }
         }
         return;
     }
@@ -374,8 +363,12 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         // (lane 0's value for everybody; as a bpermute so that the CPU emulation of the kernels,
         // where readfirstlane is the identity, sees a real broadcast)
         t.p = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ds_bpermute(0, p));
-        if (t.p < ptotal) while (t.p >= (gp.itl + 1) * nps) next_tile(gp);
-        t.ps = t.p - gp.itl * nps; t.tx = gp.tx; t.sg = gp.sg;
+        // (a ticket past the end repeats the position of the last one: its loads are issued all
+        // the same -- valid addresses, results unused -- so that the number of loads in flight
+        // does not depend on the path taken)
+        const bool real = t.p < ptotal;
+        if (real) while (t.p >= (gp.itl + 1) * nps) next_tile(gp);
+        t.ps = real ? t.p - gp.itl * nps : 0; t.tx = gp.tx; t.sg = gp.sg;
         return t;
     };
 
@@ -385,15 +378,14 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // scalar load in flight turns every wait for a ds_bpermute result into a full drain.
     int vz = 0;
     SSQ_OPAQUE_V(vz);
-    const int4* rows4 = reinterpret_cast<const int4*>(A.rows) + vz;
-    const int4* steps4 = reinterpret_cast<const int4*>(A.steps) + vz;
-    const int* pst = A.psteps + vz;
+    const int4* rows4 = reinterpret_cast<const int4*>(A.prows) + vz;
+    const int4* steps4 = reinterpret_cast<const int4*>(A.psegs) + vz;
 
     // Software pipeline over this wavefront's tickets: the records of a step are fetched while
     // the step before it is computed, its samples half a step ahead.
     int4 sa, sb, rec[TILE_G];                 // next step: (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
     auto load_rec = [&](const Ticket& k) {
-        const int g = __builtin_amdgcn_readfirstlane(pst[k.ps]);
+        const int g = k.ps;
         sa = steps4[2 * g]; sb = steps4[2 * g + 1];
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) rec[r] = rows4[g * TILE_G + r];
@@ -426,24 +418,27 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     if (kc_.p >= ptotal) return;
     load_rec(kc_); load(B0{}, kc_);
     Ticket kn = grab();                       // the step whose samples are loaded next
-    if (kn.p < ptotal) load_rec(kn);
-    ssq_f2 wt[TILE_W];                        // (phi_t, phi'_t / (R dt)) of the class in hand
-    int wt_off = -1, wt_phase = -1;
+    load_rec(kn);
+    // (phi_t, phi'_t / (R dt)) of the step in hand: fetched for the next step when the last taps of
+    // this one are done -- unconditionally (64 bytes per lane from an L1 / L2-resident table): a
+    // load under a condition would make the compiler drain all loads at the join
+    ssq_f2 wt[TILE_W];
+    auto load_wt = [&](auto BB, const Ticket& k) {
+        constexpr int b = decltype(BB)::value;
+        const TileCtx t = ctx_of(k.tx, k.sg);
+        const float4* wp = A.wtab + (int64_t)(xwoff[b] + (t.nabs & xmask[b])) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = wp[q];
+            wt[2 * q].x = v.x; wt[2 * q].y = v.y; wt[2 * q + 1].x = v.z; wt[2 * q + 1].y = v.w;
+        }
+    };
+    load_wt(B0{}, kc_);
     auto step = [&](auto BB, auto BN) {
         constexpr int b = decltype(BB)::value;
         const TileCtx tc = ctx_of(kc_.tx, kc_.sg);
         float2* Wx = A.Wx + tc.obase;
         float2* dWx = STORE_D ? A.dWx + tc.obase : nullptr;
-        const int phase = tc.nabs & xmask[b];
-        if (__builtin_amdgcn_readfirstlane(xwoff[b]) != wt_off || phase != wt_phase) {
-            const float4* wp = A.wtab + (int64_t)(xwoff[b] + phase) * 4;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 q = wp[t];
-                wt[2 * t].x = q.x; wt[2 * t].y = q.y; wt[2 * t + 1].x = q.z; wt[2 * t + 1].y = q.w;
-            }
-            wt_off = __builtin_amdgcn_readfirstlane(xwoff[b]); wt_phase = phase;
-        }
         const int baddr = xbaddr[b];
         int kout[TILE_G];
         Ticket knn; knn.p = ptotal; knn.ps = 0; knn.tx = 0; knn.sg = 0;
@@ -452,9 +447,9 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             if (r == TILE_G / 2) {
                 // the next step: its samples now (its records came in during the first rows), then
                 // a ticket and the records of the one after
-                if (kn.p < ptotal) load(BN, kn);
+                load(BN, kn);
                 knn = grab();
-                if (knn.p < ptotal) load_rec(knn);
+                load_rec(knn);
             }
             // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
             // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
@@ -478,6 +473,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
                 }
             }
+            if (r == TILE_G - 1) load_wt(BN, kn);
             const float are = are2.x, aim = aim2.x;
             float dre = are2.y, dim = aim2.y;
             // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
@@ -596,7 +592,15 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         SSQ_REQUIRE(!hp.empty(), "tile tables without interpolated rows");
         npsteps = (int)hp.size();
         if ((rc = up((void**)&steps, hs.data(), sizeof(TileSeg) * nsteps))) return rc;
-        if ((rc = up((void**)&psteps, hp.data(), sizeof(int32_t) * hp.size()))) return rc;
+        // the producers' own dense copies of the records (no indirection in their pipeline)
+        std::vector<TileSeg> hps(hp.size());
+        std::vector<TileRow> hpr(hp.size() * TILE_G);
+        for (size_t i = 0; i < hp.size(); ++i) {
+            hps[i] = hs[(size_t)hp[i]];
+            for (int r = 0; r < TILE_G; ++r) hpr[i * TILE_G + r] = rw[(size_t)hp[i] * TILE_G + r];
+        }
+        if ((rc = up((void**)&psegs, hps.data(), sizeof(TileSeg) * hps.size()))) return rc;
+        if ((rc = up((void**)&prows, hpr.data(), sizeof(TileRow) * hpr.size()))) return rc;
     }
     if ((rc = up((void**)&rows, d.rows, sizeof(TileRow) * TILE_G * nsteps))) return rc;
     if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
@@ -649,9 +653,9 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, psteps, irows, wtab, tbank, U, ring, counters};
+    void* ptrs[] = {steps, rows, psegs, prows, irows, wtab, tbank, U, ring, counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    steps = nullptr; rows = nullptr; psteps = nullptr; irows = nullptr; wtab = tbank = U = ring = nullptr;
+    steps = nullptr; rows = nullptr; psegs = nullptr; prows = nullptr; irows = nullptr; wtab = tbank = U = ring = nullptr;
     counters = nullptr;
 }
 
@@ -705,7 +709,7 @@ static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
     TileArgs A;
-    A.steps = steps; A.rows = rows; A.psteps = psteps;
+    A.steps = steps; A.rows = rows; A.psegs = psegs; A.prows = prows;
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = cst;
     A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
     A.ring = (unsigned short*)ring;

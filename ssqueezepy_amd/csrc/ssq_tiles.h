@@ -42,7 +42,7 @@ struct TilePlan {
     int ncu = 0;                            // persistent workgroups of the tile kernel (one per CU)
     TileSeg* steps = nullptr;               // the segment record of every step (`first`: index among
                                             // the producer steps, -1 for rows read back)
-    int32_t* psteps = nullptr;              // producer step -> step
+    TileSeg* psegs = nullptr; TileRow* prows = nullptr;   // records of the producer steps only (dense)
     TileRow* rows = nullptr; TileIRow* irows = nullptr;
     void* wtab = nullptr; void* tbank = nullptr;
     void* U = nullptr;                      // group x u_total complex64

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 call A: tile-path parity first, then the bench under the tuning switches (one box)
 cd /root/repo; export TMPDIR=/tmp
-O=gpurun_out/r3a; mkdir -p $O
+O=gpurun_out/${RUNTAG:-r3a}; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_00_configs.py tests/test_gpu_edge_cases.py tests/test_gpu_transforms.py -x -q -m gpu \
    -k "config2 or default_arguments or every_instantiation or few_scales or launch_group or lean or full_size" > $O/pytest_tiles.log 2>&1
 tail -5 $O/pytest_tiles.log
