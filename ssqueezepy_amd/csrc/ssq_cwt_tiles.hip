@@ -48,8 +48,17 @@ constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
 constexpr int TILE_G = 4;         // rows per step
 constexpr int TILE_W = 8;         // taps
 constexpr int TILE_RING = 128;    // producer steps whose bins may be in flight (power of two)
-constexpr int TILE_D = 4;         // steps of loads the updater keeps in flight
+#ifndef SSQ_TILE_DEPTH
+#define SSQ_TILE_DEPTH 4
+#endif
+constexpr int TILE_D = SSQ_TILE_DEPTH;   // steps of loads the updater keeps in flight
+// tuning experiments (A/B builds, tools/ab_variant.sh): 1 = the updater skips the rows read back,
+// 2 = the updater runs at high priority, 4 = the producers skip their arithmetic (WRONG RESULTS with 1, 4)
+#ifndef SSQ_TILE_EXP
+#define SSQ_TILE_EXP 0
+#endif
 constexpr int TILE_NOBIN = 0xFFFF;
+constexpr int TILE_NU = 4;        // updater wavefronts per workgroup (16 columns each)
 
 struct TileArgs {
     const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
@@ -65,6 +74,7 @@ struct TileArgs {
     float theta_scale;   // 2 pi / (M dt): theta of a row = kc * theta_scale
     float cst0;          // the reassignment weight when it is the same for every row
     unsigned long long* counters;   // [0] += tiles finished by the updater (what actually ran)
+    unsigned long long* trace;      // tuning aid (SSQ_TILE_TRACE): shader-clock stamps of one workgroup
     double gamma;
 };
 
@@ -120,6 +130,13 @@ __device__ __forceinline__ int exact_bin(float2 W, float2 D, const SsqParams& sp
     return sp.flipud ? omax - ke : ke;
 }
 
+// trace (tuning aid): [wavefront][step of the traced tile, < 128][4 stamps], then 64 extra words
+constexpr int TRACE_STEPS = 128, TRACE_WORDS = 16 * TRACE_STEPS * 4 + 64;
+#define TILE_STAMP(on, wave, j, k)                                                               \
+    do { if (tr && (on) && (j) < TRACE_STEPS && c == 0)                                        \
+             tr[((size_t)(wave) * TRACE_STEPS + (j)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int TRACE_TILE = 2;
+
 // what a step needs to know about its tile (64 columns of one signal of the launch group)
 struct TileCtx {
     int tx, sg;              // tile along time, signal of the group
@@ -129,61 +146,41 @@ struct TileCtx {
     int64_t kbase;           // ... in the bin map of the group
 };
 
-// ---- the reassignment of one step (4 rows) into the tile, in row order. `cell` of a point
-// without contribution is the lane's scratch cell and its term is 0. Rows of a step that hit the
-// same cell are chained in registers (same lane = same column: no cross-lane traffic).
-__device__ __forceinline__ void forward4(const int (&cell)[TILE_G], int (&src)[TILE_G]) {
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) {
-        src[r] = -1;
-#pragma unroll
-        for (int q = 0; q < r; ++q) if (cell[q] == cell[r]) src[r] = q;
-    }
+// the additive term of one point and how it is folded into a cell, in the CPU path's arithmetic:
+// float32 data with a float64 weight vector accumulates through double (algos.py:66-79)
+template <bool CST64> struct TileTerm {
+    using type = float;
+    static __device__ __forceinline__ float make(float z, float w) { return z * w; }
+    static __device__ __forceinline__ float fold(float o, float t) { return o + t; }
+};
+template <> struct TileTerm<true> {
+    using type = double;
+    static __device__ __forceinline__ double make(float z, double w) { return (double)z * w; }
+    static __device__ __forceinline__ float fold(float o, double t) { return (float)((double)o + t); }
+};
+// v_mov_b32_dpp quad_perm: lanes without a source keep `old`
+template <int CTRL> __device__ __forceinline__ int tile_dpp(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
 }
-// float weights: T += v (v = Wx * const rounded to float first, as the CPU loop does)
-__device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const float2 (&v)[TILE_G]) {
-    int src[TILE_G];
-    forward4(cell, src);
-    float2 t[TILE_G];
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) t[r] = T[cell[r]];
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) {
-#pragma unroll
-        for (int q = 0; q < r; ++q) if (src[r] == q) t[r] = t[q];
-        t[r].x += v[r].x; t[r].y += v[r].y;
-    }
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
+template <int CTRL> __device__ __forceinline__ float tile_dpp(float old, float v) {
+    return __int_as_float(tile_dpp<CTRL>(__float_as_int(old), __float_as_int(v)));
 }
-// float64 weight vector with float32 data: the CPU path accumulates through double
-// (algos.py:66-79 -> Tx[k] += Wx * const with a float64 `const`): T = float(double(T) + double(Wx) * c)
-__device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const double2 (&v)[TILE_G]) {
-    int src[TILE_G];
-    forward4(cell, src);
-    float2 t[TILE_G];
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) t[r] = T[cell[r]];
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) {
-#pragma unroll
-        for (int q = 0; q < r; ++q) if (src[r] == q) t[r] = t[q];
-        t[r].x = (float)((double)t[r].x + v[r].x); t[r].y = (float)((double)t[r].y + v[r].y);
-    }
-#pragma unroll
-    for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
+template <int CTRL> __device__ __forceinline__ double tile_dpp(double old, double v) {
+    const int lo = tile_dpp<CTRL>(__double2loint(old), __double2loint(v));
+    const int hi = tile_dpp<CTRL>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // LDS of a workgroup: the tile, then the control words, the flags and the step table
 struct TileLds {
-    float2* T;          // (na + 1) x 64 cells (the last row: scratch)
+    float2* T;          // na x 64 cells: per updater wavefront [bin][16 columns]
     int* next;          // producer ticket counter
-    int* upd_done;      // producer steps the updater has consumed
+    int* upd_done;      // [TILE_NU]: producer steps each updater has consumed
     int* flags;         // [TILE_RING]: p + 1 once producer step p is in memory
     int2* steptab;      // [nsteps]: row0 | nvalid << 16 | kind << 20, producer index in the tile
 };
 __host__ __device__ inline size_t tile_lds_bytes(int64_t na, int nsteps) {
-    return (size_t)(na + 1) * TILE_COLS * 8 + 16 + 4 * TILE_RING + 8 * (size_t)nsteps;
+    return (size_t)na * TILE_COLS * 8 + 32 + 4 * TILE_RING + 8 * (size_t)nsteps;
 }
 
 template <int GRID, bool STORE_D, int NW, int CSTK>
@@ -196,13 +193,13 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     const int na = (int)A.na, omax = na - 1;
     TileLds L;
     L.T = reinterpret_cast<float2*>(lds_raw);
-    L.next = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
-    L.upd_done = L.next + 1;
-    L.flags = L.next + 4;
+    L.next = reinterpret_cast<int*>(lds_raw + (size_t)na * TILE_COLS * 8);
+    L.upd_done = L.next + 4;                                 // 16-byte aligned: read as one int4
+    L.flags = L.next + 8;
     L.steptab = reinterpret_cast<int2*>(L.flags + TILE_RING);
     float2* T = L.T;
-    for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
-    if (threadIdx.x < 4) L.next[threadIdx.x] = 0;
+    for (int k = wv; k < na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+    if (threadIdx.x < 8) L.next[threadIdx.x] = 0;
     for (int k = threadIdx.x; k < TILE_RING; k += 64 * NW) L.flags[k] = 0;
     for (int st = threadIdx.x; st < A.nsteps; st += 64 * NW) {
         // rows of a step are consecutive (checked by the host); padding rows carry the sign bit
@@ -212,7 +209,6 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         L.steptab[st] = make_int2(row0 | (nvalid << 16) | (A.steps[st].kind << 20), A.steps[st].first);
     }
     __syncthreads();
-    const int scratch = na * TILE_COLS + c;
 
     // The workgroup is persistent: it walks the tiles blockIdx.x, + gridDim.x, ... of the launch
     // group (tile = 64 columns of one signal); positions advance monotonically, so the
@@ -239,106 +235,138 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         while (q.tx >= ntx) { q.tx -= ntx; ++q.sg; }
     };
     const int nps = A.npsteps;
+    unsigned long long* tr = (A.trace && (int)blockIdx.x == (100 < (int)gridDim.x ? 100 : (int)gridDim.x - 1)) ? A.trace : nullptr;
     unsigned short* ring = A.ring + (size_t)blockIdx.x * TILE_RING * TILE_G * TILE_COLS;
 
-    if (wv == 0) {
-        // ------------------------------------------------------------------ the updater
+    if (wv < TILE_NU) {
+        // ------------------------------------------------------------------ the updaters
+        // Wavefront u owns columns 16 u .. 16 u + 15 of the tile: its lanes are (column cl, row rl
+        // of the step), lane = 4 cl + rl, so the four rows of a step that belong to one column
+        // are a DPP quad. Per step: one 8-byte load of Wx and one 2-byte load of the bin per lane
+        // (128-byte / 32-byte runs per row), several steps in flight; the cell is read once, the
+        // terms of the lower rows of the quad that hit the same cell are folded in -- in ascending
+        // row order -- with quad_perm moves, and only the highest row of a cell writes it back.
+        const int u = wv;
+        const int cl = c >> 2, rl = c & 3;
+        float2* slab = T + (size_t)u * na * 16;               // [bin][16 columns], columns skewed by the bin
+        int* my_done = L.upd_done + u;
         const int nst = A.nsteps;
         const int total = nst * ntl;
-        struct USlot {
-            float2 W[TILE_G]; unsigned short kb[TILE_G];   // (bins stay as loaded: a conversion here would wait for the load)
-            float cf[TILE_G]; double cd[TILE_G];
-            int nvalid, p, last_tx, last_sg; bool colok;
+        struct USlot {                                        // per lane: one point of the step
+            float2 W; unsigned short kb;                      // (bins stay as loaded: a conversion here would wait for the load)
+            float cf; double cd;
+            int nvalid, p, last_tx, last_sg, trk; bool colok; // wave-uniform
         };
         const float* cstf = (const float*)A.cst;
         const double* cstd = (const double*)A.cst;
         constexpr int cstk = CSTK;
         TilePos lp = pos0;                                    // tile / step of the next load
         int l_st = 0, l_g = 0;
-        TileCtx lt = ctx_of(lp.tx, lp.sg);
+        // the lane's column in the tile at hand
+        auto lane_col = [&](int tx, bool& ok) {
+            const int col = tx * TILE_COLS + u * 16 + cl;
+            ok = col < N;
+            return ok ? col : (int)N - 1;
+        };
+        bool l_ok; int l_col = lane_col(lp.tx, l_ok);
         // Loads are issued unconditionally and in one sequence for both kinds of steps (past the
         // last step: a repeat of valid addresses, marked empty): the compiler counts the loads in
         // flight per path, and a path that skips some makes every wait a full drain.
         auto uload = [&](USlot& s) {
             const bool real = l_g < total;
             const int2 e = L.steptab[l_st];
-            const int row0 = e.x & 0xFFFF, nvalid = real ? (e.x >> 16) & 7 : 0;
-            const bool interp = real && (e.x >> 20) != 0;
-            s.nvalid = nvalid; s.colok = lt.colok;
+            const int ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
+            const bool interp = real && (ex >> 20) != 0;
+            const int row0 = ex & 0xFFFF, nvalid = (real && (interp || !(SSQ_TILE_EXP & 1))) ? (ex >> 16) & 7 : 0;
+            s.nvalid = nvalid; s.colok = l_ok; s.trk = (real && lp.itl == TRACE_TILE && u == 0) ? l_st : -1;
             s.last_tx = (real && l_st == nst - 1) ? lp.tx : -1; s.last_sg = lp.sg;
-            const int p = lp.itl * nps + e.y;
+            const int p = lp.itl * nps + ey;
             s.p = interp ? p : -1;
             const int slot = p & (TILE_RING - 1);
             if (interp) while (lds_load_acquire(&L.flags[slot]) != p + 1) __builtin_amdgcn_s_sleep(1);
-            const float2* Wx = A.Wx + lt.obase;
+            TILE_STAMP(s.trk >= 0, 0, s.trk, 2);
+            const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
+            const unsigned off = (unsigned)(row0 + rr) * nN + (unsigned)l_col;
+            const float2* Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
+            s.W = Wx[off];
             // bins: from the ring (interpolated rows) or from the bin map (rows read back)
-            const unsigned short* bsrc = interp ? ring + (size_t)slot * (TILE_G * TILE_COLS) + c
-                                                : A.kidx + lt.kbase + (unsigned)lt.colc;
-            const unsigned bstr = interp ? TILE_COLS : nN;
-            const unsigned brow0 = interp ? 0u : (unsigned)row0;
-#pragma unroll
-            for (int r = 0; r < TILE_G; ++r) {
-                const int rr = r < nvalid ? r : (nvalid > 0 ? nvalid - 1 : 0);
-                s.W[r] = Wx[(unsigned)(row0 + rr) * nN + (unsigned)lt.colc];
-                s.kb[r] = bsrc[(brow0 + (unsigned)rr) * bstr];
-                if (cstk == 1) s.cf[r] = cstf[row0 + rr];
-                if (cstk == 2) s.cd[r] = cstd[row0 + rr];
-            }
+            const unsigned short* bsrc = interp ? ring + (size_t)slot * (TILE_G * TILE_COLS) + (rr * TILE_COLS + u * 16 + cl)
+                                                : A.kidx + (int64_t)lp.sg * na * N + off;
+            s.kb = *bsrc;
+            if (cstk == 1) s.cf = cstf[row0 + rr];
+            if (cstk == 2) s.cd = cstd[row0 + rr];
+            TILE_STAMP(s.trk >= 0, 0, s.trk, 3);
             ++l_g;
-            if (real && ++l_st == nst) { l_st = 0; next_tile(lp); if (lp.itl < ntl) lt = ctx_of(lp.tx, lp.sg); }
+            if (real && ++l_st == nst) { l_st = 0; next_tile(lp); if (lp.itl < ntl) l_col = lane_col(lp.tx, l_ok); }
         };
-        // the finished tile goes to Tx and is cleared
+        // the finished columns go to Tx and are cleared: 4 bins x 16 columns per instruction
         auto write_out = [&](int tx, int sg) {
-            const TileCtx t = ctx_of(tx, sg);
-            float2* Tx = A.Tx + t.obase;
-            const int col = t.tx * TILE_COLS + c;
-            for (int k0 = 0; k0 < na; k0 += 8) {                // 8 rows in flight
-                float2 v[8];
+            bool ok; const int col = lane_col(tx, ok);
+            float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
+            for (int k0 = 0; k0 < na; k0 += 4 * 4) {
+                float2 v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int k = k0 + u; v[u] = T[(k < na ? k : na) * TILE_COLS + c]; }
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + 4 * q + rl, kc = k < na ? k : na - 1;
+                    v[q] = slab[kc * 16 + ((cl + kc) & 15)];
+                }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + u;
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + 4 * q + rl;
                     if (k < na) {
-                        T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
-                        if (t.colok) Tx[(unsigned)k * nN + (unsigned)col] = v[u];
+                        slab[k * 16 + ((cl + k) & 15)] = make_float2(0.f, 0.f);
+                        if (ok) Tx[(unsigned)k * nN + (unsigned)col] = v[q];
                     }
                 }
             }
-            if (A.counters && c == 0)
+            // (cells are cleared by other lanes than the ones that read them next: on the GPU the
+            // wavefront runs in lockstep; the barrier makes that explicit for the CPU emulation)
+            __builtin_amdgcn_wave_barrier();
+            if (A.counters && c == 0 && u == 0)
                 __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
         };
+        using TM = TileTerm<CSTK == 2>;
+        using term_t = typename TM::type;
         auto uprocess = [&](const USlot& s) {
-            int cell[TILE_G];
-#pragma unroll
-            for (int r = 0; r < TILE_G; ++r) {
-                const bool act = r < s.nvalid && s.colok && s.kb[r] != TILE_NOBIN;
-                cell[r] = act ? s.kb[r] * TILE_COLS + c : scratch;
+            TILE_STAMP(s.trk >= 0, 0, s.trk, 0);
+            const int kb = s.kb;
+            const int k = (rl < s.nvalid && s.colok && kb != TILE_NOBIN) ? kb : -1;
+            term_t vr = term_t(0), vi = term_t(0);
+            float2 o = make_float2(0.f, 0.f);
+            float2* cell = slab;
+            if (k >= 0) {
+                if (cstk == 2) { vr = TM::make(s.W.x, s.cd); vi = TM::make(s.W.y, s.cd); }
+                else { const float cs = cstk == 1 ? s.cf : A.cst0; vr = TM::make(s.W.x, cs); vi = TM::make(s.W.y, cs); }
+                cell = slab + (k * 16 + ((cl + k) & 15));
+                o = *cell;
             }
-            if (cstk == 2) {
-                double2 v[TILE_G];
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) {
-                    const bool act = cell[r] != scratch;
-                    v[r].x = act ? (double)s.W[r].x * s.cd[r] : 0.0;
-                    v[r].y = act ? (double)s.W[r].y * s.cd[r] : 0.0;
-                }
-                update4(T, cell, v);
-            } else {
-                float2 v[TILE_G];
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) {
-                    const bool act = cell[r] != scratch;
-                    const float cs = act ? (cstk == 1 ? s.cf[r] : A.cst0) : 0.f;
-                    v[r] = make_float2(s.W[r].x * cs, s.W[r].y * cs);
-                }
-                update4(T, cell, v);
-            }
+            // lower rows of this column, ascending: quad lanes rl-3, rl-2, rl-1
+            // (quad_perm [0,0,0,0], [0,0,0,1], [0,0,1,2]); -1 never matches a valid bin
+            const int k3 = tile_dpp<0x00>(-1, k), k2 = tile_dpp<0x40>(-1, k), k1 = tile_dpp<0x90>(-1, k);
+            const term_t r3 = tile_dpp<0x00>(term_t(0), vr), i3 = tile_dpp<0x00>(term_t(0), vi);
+            const term_t r2 = tile_dpp<0x40>(term_t(0), vr), i2 = tile_dpp<0x40>(term_t(0), vi);
+            const term_t r1 = tile_dpp<0x90>(term_t(0), vr), i1 = tile_dpp<0x90>(term_t(0), vi);
+            if (rl >= 3 && k3 == k) { o.x = TM::fold(o.x, r3); o.y = TM::fold(o.y, i3); }
+            if (rl >= 2 && k2 == k) { o.x = TM::fold(o.x, r2); o.y = TM::fold(o.y, i2); }
+            if (rl >= 1 && k1 == k) { o.x = TM::fold(o.x, r1); o.y = TM::fold(o.y, i1); }
+            o.x = TM::fold(o.x, vr); o.y = TM::fold(o.y, vi);
+            // a higher row of the quad hitting the same cell writes it instead
+            // (quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3])
+            const int h1 = tile_dpp<0xF9>(-1, k), h2 = tile_dpp<0xFE>(-1, k), h3 = tile_dpp<0xFF>(-1, k);
+            const bool last = !((rl <= 2 && h1 == k) || (rl <= 1 && h2 == k) || (rl == 0 && h3 == k));
+            if (k >= 0 && last) *cell = o;
+            __builtin_amdgcn_wave_barrier();
             // (the ring slot of the step is free again: its bins were loaded long ago)
-            if (s.p >= 0 && c == 0) lds_store_relaxed(L.upd_done, s.p + 1);
-            if (s.last_tx >= 0) write_out(s.last_tx, s.last_sg);
+            if (s.p >= 0 && c == 0) lds_store_relaxed(my_done, s.p + 1);
+            TILE_STAMP(s.trk >= 0, 0, s.trk, 1);
+            if (s.last_tx >= 0) {
+                if (tr && s.trk >= 0 && c == 0) tr[16 * TRACE_STEPS * 4 + 1] = __builtin_amdgcn_s_memtime();
+                write_out(s.last_tx, s.last_sg);
+                if (tr && s.trk >= 0 && c == 0) tr[16 * TRACE_STEPS * 4 + 2] = __builtin_amdgcn_s_memtime();
+            }
         };
         USlot sl[TILE_D];
+        if (SSQ_TILE_EXP & 2) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int k = 0; k < TILE_D; ++k) uload(sl[k]);
         for (int g0 = 0; g0 < total; g0 += TILE_D) {
@@ -437,19 +465,23 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     auto step = [&](auto BB, auto BN) {
         constexpr int b = decltype(BB)::value;
         const TileCtx tc = ctx_of(kc_.tx, kc_.sg);
+        const bool trk = kc_.p / nps == TRACE_TILE && tr;
+        const int trj = kc_.ps;
+        TILE_STAMP(trk, wv, trj, 0);
         float2* Wx = A.Wx + tc.obase;
         float2* dWx = STORE_D ? A.dWx + tc.obase : nullptr;
         const int baddr = xbaddr[b];
         int kout[TILE_G];
         Ticket knn; knn.p = ptotal; knn.ps = 0; knn.tx = 0; knn.sg = 0;
 #pragma unroll
-        for (int r = 0; r < TILE_G; ++r) {
+        for (int r = 0; r < ((SSQ_TILE_EXP & 4) ? 0 : TILE_G); ++r) {
             if (r == TILE_G / 2) {
                 // the next step: its samples now (its records came in during the first rows), then
                 // a ticket and the records of the one after
                 load(BN, kn);
                 knn = grab();
                 load_rec(knn);
+                TILE_STAMP(trk, wv, trj, 1);
             }
             // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
             // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
@@ -514,17 +546,29 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                 }
             }
         }
+        if (SSQ_TILE_EXP & 4) {
+            load(BN, kn); knn = grab(); load_rec(knn); load_wt(BN, kn);
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) kout[r] = TILE_NOBIN;
+        }
         // hand the step to the updater: bins into the ring slot (free once the updater has
         // consumed step p - TILE_RING), then the flag behind a release (Wx and bins in memory)
         const int pc = kc_.p;
         const int slot = pc & (TILE_RING - 1);
-        while (lds_load_relaxed(L.upd_done) <= pc - TILE_RING) __builtin_amdgcn_s_sleep(1);
+        TILE_STAMP(trk, wv, trj, 2);
+        for (;;) {                                            // (the slowest of the updaters counts)
+            const int d0 = lds_load_relaxed(L.upd_done), d1 = lds_load_relaxed(L.upd_done + 1);
+            const int d2 = lds_load_relaxed(L.upd_done + 2), d3 = lds_load_relaxed(L.upd_done + 3);
+            if (min(min(d0, d1), min(d2, d3)) > pc - TILE_RING) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
         unsigned short* rb = ring + (size_t)slot * (TILE_G * TILE_COLS) + c;
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) rb[r * TILE_COLS] = (unsigned short)kout[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (c == 0) lds_store_relaxed(&L.flags[slot], pc + 1);
+        TILE_STAMP(trk, wv, trj, 3);
         kc_ = kn; kn = knn;
     };
     for (;;) {
@@ -719,9 +763,23 @@ int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const uns
     A.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); A.cst0 = cst0;
     A.counters = counters;
     A.gamma = sp.gamma;
+    static unsigned long long* trace_buf = nullptr;
+    const char* trace_path = getenv("SSQ_TILE_TRACE");
+    if (trace_path && !trace_buf) SSQ_CHECK_HIP(hipMalloc((void**)&trace_buf, 8 * TRACE_WORDS));
+    if (trace_buf) SSQ_CHECK_HIP(hipMemsetAsync(trace_buf, 0, 8 * TRACE_WORDS, stream));
+    A.trace = trace_buf;
+    auto dump_trace = [&]() -> int {
+        if (!trace_buf) return 0;
+        SSQ_CHECK_HIP(hipStreamSynchronize(stream));
+        std::vector<unsigned long long> h(TRACE_WORDS);
+        SSQ_CHECK_HIP(hipMemcpy(h.data(), trace_buf, 8 * h.size(), hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        return 0;
+    };
 #define TILE_LAUNCH(G)                                                                      \
-    return dWx ? launch_tile<G, true>(*this, A, sp, nsig, stream)                          \
-               : launch_tile<G, false>(*this, A, sp, nsig, stream);
+    { int rc_ = dWx ? launch_tile<G, true>(*this, A, sp, nsig, stream)                     \
+                    : launch_tile<G, false>(*this, A, sp, nsig, stream);                   \
+      return rc_ ? rc_ : dump_trace(); }
     if (sp.grid == SSQ_GRID_LOG) { TILE_LAUNCH(SSQ_GRID_LOG) }
     if (sp.grid == SSQ_GRID_LOG_PIECEWISE) { TILE_LAUNCH(SSQ_GRID_LOG_PIECEWISE) }
     TILE_LAUNCH(SSQ_GRID_LIN)

@@ -280,10 +280,12 @@ inline int emu_update_dpp(int old, int v, int ctrl, int, int, bool bound_ctrl) {
     emu::Wave& wv = w.waves[f->tid / 64];
     const unsigned g = f->gen++, lane = f->tid % 64;
     const int N = ctrl - 0x110;
-    if (N < 1 || N > 15) { fprintf(stderr, "emu: unsupported dpp_ctrl %#x\n", ctrl); abort(); }
+    const bool quad = ctrl >= 0 && ctrl <= 0xFF;              // quad_perm: lane L reads lane (L & ~3) + sel[L & 3]
+    if (!quad && (N < 1 || N > 15)) { fprintf(stderr, "emu: unsupported dpp_ctrl %#x\n", ctrl); abort(); }
     wv.xchg[g % 3][lane] = v;
     emu::yield(emu::AT_WAVE);
     wv.votes[(g + 2) % 3] = 0;
+    if (quad) return wv.xchg[g % 3][(lane & ~3u) + ((ctrl >> (2 * (lane & 3))) & 3)];
     const bool has = (int)(lane % 16) >= N;
     return has ? wv.xchg[g % 3][lane - N] : (bound_ctrl ? 0 : old);
 }
