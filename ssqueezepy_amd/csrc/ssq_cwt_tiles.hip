@@ -269,6 +269,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             return ok ? col : (int)N - 1;
         };
         bool l_ok; int l_col = lane_col(lp.tx, l_ok);
+        int l_sg = lp.sg;                                     // (stays at the last tile for the loads past the end)
         // Loads are issued unconditionally and in one sequence for both kinds of steps (past the
         // last step: a repeat of valid addresses, marked empty): the compiler counts the loads in
         // flight per path, and a path that skips some makes every wait a full drain.
@@ -287,17 +288,20 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             TILE_STAMP(s.trk >= 0, 0, s.trk, 2);
             const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
             const unsigned off = (unsigned)(row0 + rr) * nN + (unsigned)l_col;
-            const float2* Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
+            const float2* Wx = A.Wx + (int64_t)(A.sig0 + l_sg) * na * N;
             s.W = Wx[off];
             // bins: from the ring (interpolated rows) or from the bin map (rows read back)
             const unsigned short* bsrc = interp ? ring + (size_t)slot * (TILE_G * TILE_COLS) + (rr * TILE_COLS + u * 16 + cl)
-                                                : A.kidx + (int64_t)lp.sg * na * N + off;
+                                                : A.kidx + (int64_t)l_sg * na * N + off;
             s.kb = *bsrc;
             if (cstk == 1) s.cf = cstf[row0 + rr];
             if (cstk == 2) s.cd = cstd[row0 + rr];
             TILE_STAMP(s.trk >= 0, 0, s.trk, 3);
             ++l_g;
-            if (real && ++l_st == nst) { l_st = 0; next_tile(lp); if (lp.itl < ntl) l_col = lane_col(lp.tx, l_ok); }
+            if (real && ++l_st == nst) {
+                l_st = 0; next_tile(lp);
+                if (lp.itl < ntl) { l_col = lane_col(lp.tx, l_ok); l_sg = lp.sg; }
+            }
         };
         // the finished columns go to Tx and are cleared: 4 bins x 16 columns per instruction
         auto write_out = [&](int tx, int sg) {

@@ -21,6 +21,9 @@ def available():
 
 
 def build():
+    # SSQ_EMU_LIB: a build of the same sources made elsewhere (e.g. with -fsanitize=address)
+    if os.environ.get('SSQ_EMU_LIB'):
+        return os.environ['SSQ_EMU_LIB']
     subprocess.check_call(['make', '-C', EMU, '-s', '-j8'])
     return LIB
 
