@@ -57,12 +57,16 @@ constexpr int TILE_D = SSQ_TILE_DEPTH;   // steps of loads the updater keeps in 
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
+#ifndef SSQ_TILE_BPSLEEP
+#define SSQ_TILE_BPSLEEP 20     // x 64 clocks between two looks at the updaters' progress
+#endif
 constexpr int TILE_NOBIN = 0xFFFF;
 constexpr int TILE_NU = 4;        // updater wavefronts per workgroup (16 columns each)
 
 struct TileArgs {
     const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
     const TileSeg* psegs; const TileRow* prows;      // the same records, producer steps only (dense)
+    const int4* usegs; int nusegs;                   // the updaters' view: per segment (first row, rows, kind, producer steps before it)
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
@@ -176,11 +180,11 @@ struct TileLds {
     float2* T;          // na x 64 cells: per updater wavefront [bin][16 columns]
     int* next;          // producer ticket counter
     int* upd_done;      // [TILE_NU]: producer steps each updater has consumed
-    int* flags;         // [TILE_RING]: p + 1 once producer step p is in memory
-    int2* steptab;      // [nsteps]: row0 | nvalid << 16 | kind << 20, producer index in the tile
+    int* gcnt;          // [TILE_RING / 4]: producer steps finished, per group of 4 consecutive steps
+    int4* segtab;       // [nusegs]: first row, rows, kind, producer steps of the tile before the segment
 };
-__host__ __device__ inline size_t tile_lds_bytes(int64_t na, int nsteps) {
-    return (size_t)na * TILE_COLS * 8 + 32 + 4 * TILE_RING + 8 * (size_t)nsteps;
+__host__ __device__ inline size_t tile_lds_bytes(int64_t na, int nusegs) {
+    return (size_t)na * TILE_COLS * 8 + 32 + 4 * (TILE_RING / 4) + 16 * (size_t)nusegs;
 }
 
 template <int GRID, bool STORE_D, int NW, int CSTK>
@@ -195,19 +199,13 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     L.T = reinterpret_cast<float2*>(lds_raw);
     L.next = reinterpret_cast<int*>(lds_raw + (size_t)na * TILE_COLS * 8);
     L.upd_done = L.next + 4;                                 // 16-byte aligned: read as one int4
-    L.flags = L.next + 8;
-    L.steptab = reinterpret_cast<int2*>(L.flags + TILE_RING);
+    L.gcnt = L.next + 8;
+    L.segtab = reinterpret_cast<int4*>(L.gcnt + TILE_RING / 4);
     float2* T = L.T;
     for (int k = wv; k < na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
     if (threadIdx.x < 8) L.next[threadIdx.x] = 0;
-    for (int k = threadIdx.x; k < TILE_RING; k += 64 * NW) L.flags[k] = 0;
-    for (int st = threadIdx.x; st < A.nsteps; st += 64 * NW) {
-        // rows of a step are consecutive (checked by the host); padding rows carry the sign bit
-        int nvalid = 0;
-        for (int r = 0; r < TILE_G; ++r) nvalid += A.rows[st * TILE_G + r].row >= 0 ? 1 : 0;
-        const int row0 = A.rows[st * TILE_G].row & 0xFFFF;
-        L.steptab[st] = make_int2(row0 | (nvalid << 16) | (A.steps[st].kind << 20), A.steps[st].first);
-    }
+    for (int k = threadIdx.x; k < TILE_RING / 4; k += 64 * NW) L.gcnt[k] = 0;
+    for (int k = threadIdx.x; k < A.nusegs; k += 64 * NW) L.segtab[k] = A.usegs[k];
     __syncthreads();
 
     // The workgroup is persistent: it walks the tiles blockIdx.x, + gridDim.x, ... of the launch
@@ -248,78 +246,118 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         // row order -- with quad_perm moves, and only the highest row of a cell writes it back.
         const int u = wv;
         const int cl = c >> 2, rl = c & 3;
-        float2* slab = T + (size_t)u * na * 16;               // [bin][16 columns], columns skewed by the bin
+        float2* slab = T + (size_t)u * na * 16;               // [bin][16 columns]
         int* my_done = L.upd_done + u;
-        const int nst = A.nsteps;
-        const int total = nst * ntl;
+        const int nsg = A.nusegs;
+        // A single wavefront runs this loop for its 16 columns and its instruction stream is the
+        // critical path of the tile, so the loop is kept lean: a cursor over (tile, segment, row)
+        // advanced with a few scalar operations, addresses as a uniform base + a per-lane offset
+        // fixed for the tile, no per-step table reads, one flag look per 4 producer steps.
         struct USlot {                                        // per lane: one point of the step
             float2 W; unsigned short kb;                      // (bins stay as loaded: a conversion here would wait for the load)
             float cf; double cd;
-            int nvalid, p, last_tx, last_sg, trk; bool colok; // wave-uniform
+            int meta;                                         // wave-uniform: 1 = interpolated rows, 2 = last step of the tile, rows << 2
         };
         const float* cstf = (const float*)A.cst;
         const double* cstd = (const double*)A.cst;
         constexpr int cstk = CSTK;
-        TilePos lp = pos0;                                    // tile / step of the next load
-        int l_st = 0, l_g = 0;
-        // the lane's column in the tile at hand
-        auto lane_col = [&](int tx, bool& ok) {
+        auto lane_col = [&](int tx, bool& ok) {               // the lane's column in a tile
             const int col = tx * TILE_COLS + u * 16 + cl;
             ok = col < N;
             return ok ? col : (int)N - 1;
         };
-        bool l_ok; int l_col = lane_col(lp.tx, l_ok);
-        int l_sg = lp.sg;                                     // (stays at the last tile for the loads past the end)
-        // Loads are issued unconditionally and in one sequence for both kinds of steps (past the
-        // last step: a repeat of valid addresses, marked empty): the compiler counts the loads in
-        // flight per path, and a path that skips some makes every wait a full drain.
+        // ---- load side
+        TilePos lp = pos0;                                    // tile of the next load
+        bool l_ok;
+        int l_col = lane_col(lp.tx, l_ok);
+        unsigned l_off = (unsigned)rl * nN + (unsigned)l_col; // element offset of the lane's point in a step starting at row 0
+        const float2* l_Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
+        const unsigned short* l_kx = A.kidx + (int64_t)lp.sg * na * N;
+        const unsigned ring_lane = (unsigned)(rl * TILE_COLS + u * 16 + cl);
+        int l_seg = 0, l_row, l_left, l_kind, l_p;
+        {
+            const int4 sg0 = L.segtab[0];
+            l_row = __builtin_amdgcn_readfirstlane(sg0.x); l_left = __builtin_amdgcn_readfirstlane(sg0.y);
+            l_kind = __builtin_amdgcn_readfirstlane(sg0.z); l_p = __builtin_amdgcn_readfirstlane(sg0.w);
+        }
+        int l_waited = -1;                                    // last group of producer steps known complete
+        // Loads are issued unconditionally (past the last step: a repeat of the last addresses, marked
+        // empty): the compiler counts the loads in flight per path, and a path that skips some makes
+        // every wait a full drain.
         auto uload = [&](USlot& s) {
-            const bool real = l_g < total;
-            const int2 e = L.steptab[l_st];
-            const int ex = __builtin_amdgcn_readfirstlane(e.x), ey = __builtin_amdgcn_readfirstlane(e.y);
-            const bool interp = real && (ex >> 20) != 0;
-            const int row0 = ex & 0xFFFF, nvalid = (real && (interp || !(SSQ_TILE_EXP & 1))) ? (ex >> 16) & 7 : 0;
-            s.nvalid = nvalid; s.colok = l_ok; s.trk = (real && lp.itl == TRACE_TILE && u == 0) ? l_st : -1;
-            s.last_tx = (real && l_st == nst - 1) ? lp.tx : -1; s.last_sg = lp.sg;
-            const int p = lp.itl * nps + ey;
-            s.p = interp ? p : -1;
-            const int slot = p & (TILE_RING - 1);
-            if (interp) while (lds_load_acquire(&L.flags[slot]) != p + 1) __builtin_amdgcn_s_sleep(1);
-            TILE_STAMP(s.trk >= 0, 0, s.trk, 2);
-            const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
-            const unsigned off = (unsigned)(row0 + rr) * nN + (unsigned)l_col;
-            const float2* Wx = A.Wx + (int64_t)(A.sig0 + l_sg) * na * N;
-            s.W = Wx[off];
+            const bool real = lp.itl < ntl;
+            const int nvalid = real ? (l_left < TILE_G ? l_left : TILE_G) : 0;
+            const bool lastseg = l_left <= TILE_G;            // last step of the segment
+            const bool interp = real && l_kind != 0;
+            if (!(SSQ_TILE_EXP & 16) && interp && (l_p >> 2) > l_waited) {
+                // producer steps are waited for by groups of four (one counter per group)
+                const int g = l_p >> 2;
+                const int* f = L.gcnt + (g & (TILE_RING / 4 - 1));
+                const int want = 4 * ((g >> 5) + 1);          // (TILE_RING / 4 = 32 groups in the ring)
+                while (lds_load_acquire(f) < want) __builtin_amdgcn_s_sleep(1);
+                l_waited = g;
+            }
+            s.meta = (interp ? 1 : 0) | ((real && lastseg && l_seg == nsg - 1) ? 2 : 0) | (nvalid << 2);
+            // (a step with fewer than 4 rows repeats its last row in the idle lanes)
+            unsigned off = l_off + (unsigned)l_row * nN;
+            unsigned roff = ring_lane;
+            if (nvalid < TILE_G) {
+                const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
+                off = (unsigned)(l_row + rr) * nN + (unsigned)l_col;
+                roff = (unsigned)(rr * TILE_COLS + u * 16 + cl);
+            }
+            if (SSQ_TILE_EXP & 32) s.W = make_float2(0.f, 0.f); else s.W = l_Wx[off];
             // bins: from the ring (interpolated rows) or from the bin map (rows read back)
-            const unsigned short* bsrc = interp ? ring + (size_t)slot * (TILE_G * TILE_COLS) + (rr * TILE_COLS + u * 16 + cl)
-                                                : A.kidx + (int64_t)l_sg * na * N + off;
-            s.kb = *bsrc;
-            if (cstk == 1) s.cf = cstf[row0 + rr];
-            if (cstk == 2) s.cd = cstd[row0 + rr];
-            TILE_STAMP(s.trk >= 0, 0, s.trk, 3);
-            ++l_g;
-            if (real && ++l_st == nst) {
-                l_st = 0; next_tile(lp);
-                if (lp.itl < ntl) { l_col = lane_col(lp.tx, l_ok); l_sg = lp.sg; }
+            const unsigned short* bsrc = interp ? ring + (size_t)(l_p & (TILE_RING - 1)) * (TILE_G * TILE_COLS) + roff
+                                                : l_kx + off;
+            if (SSQ_TILE_EXP & 32) s.kb = (unsigned short)(off & 127); else s.kb = *bsrc;
+            if (cstk != 0) {
+                const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
+                if (cstk == 1) s.cf = cstf[l_row + rr];
+                if (cstk == 2) s.cd = cstd[l_row + rr];
+            }
+            if (real) {                                       // advance the cursor
+                l_row += TILE_G; l_left -= TILE_G; l_p += l_kind;
+                if (l_left <= 0) {
+                    if (++l_seg == nsg) {
+                        l_seg = 0; next_tile(lp);
+                        if (lp.itl < ntl) {
+                            l_col = lane_col(lp.tx, l_ok);
+                            l_off = (unsigned)rl * nN + (unsigned)l_col;
+                            l_Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
+                            l_kx = A.kidx + (int64_t)lp.sg * na * N;
+                        }
+                    }
+                    const int4 sg = L.segtab[l_seg];
+                    l_row = __builtin_amdgcn_readfirstlane(sg.x); l_left = __builtin_amdgcn_readfirstlane(sg.y);
+                    l_kind = __builtin_amdgcn_readfirstlane(sg.z);
+                    l_p = lp.itl * nps + __builtin_amdgcn_readfirstlane(sg.w);
+                }
             }
         };
+        // ---- update side
+        TilePos up = pos0;                                    // the tile being reassigned
+        bool u_ok; (void)lane_col(up.tx, u_ok);
+        int done = 0;                                         // producer steps consumed
         // the finished columns go to Tx and are cleared: 4 bins x 16 columns per instruction
-        auto write_out = [&](int tx, int sg) {
-            bool ok; const int col = lane_col(tx, ok);
-            float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
+        auto write_out = [&]() {
+            bool ok; const int col = lane_col(up.tx, ok);
+            float2* Tx = A.Tx + (int64_t)(A.sig0 + up.sg) * na * N;
+            const unsigned loff = (unsigned)rl * nN + (unsigned)col;
+            float2* cellp = slab + (rl * 16 + cl);
             for (int k0 = 0; k0 < na; k0 += 4 * 4) {
                 float2 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int k = k0 + 4 * q + rl, kc = k < na ? k : na - 1;
-                    v[q] = slab[kc * 16 + ((cl + kc) & 15)];
+                    const int kq = k0 + 4 * q;
+                    v[q] = cellp[(kq + rl < na ? kq : 0) * 16];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int k = k0 + 4 * q + rl;
-                    if (k < na) {
-                        slab[k * 16 + ((cl + k) & 15)] = make_float2(0.f, 0.f);
-                        if (ok) Tx[(unsigned)k * nN + (unsigned)col] = v[q];
+                    const int kq = k0 + 4 * q;
+                    if (kq + rl < na) {
+                        cellp[kq * 16] = make_float2(0.f, 0.f);
+                        if (ok && !(SSQ_TILE_EXP & 64)) Tx[loff + (unsigned)kq * nN] = v[q];
                     }
                 }
             }
@@ -328,21 +366,23 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             __builtin_amdgcn_wave_barrier();
             if (A.counters && c == 0 && u == 0)
                 __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+            next_tile(up);
+            if (up.itl < ntl) (void)lane_col(up.tx, u_ok);
         };
         using TM = TileTerm<CSTK == 2>;
         using term_t = typename TM::type;
         auto uprocess = [&](const USlot& s) {
-            TILE_STAMP(s.trk >= 0, 0, s.trk, 0);
+            if (SSQ_TILE_EXP & 128) { done += s.meta & 1; if ((s.meta & 1) && c == 0) lds_store_relaxed(my_done, done); if (s.meta & 2) write_out(); return; }
             const int kb = s.kb;
-            const int k = (rl < s.nvalid && s.colok && kb != TILE_NOBIN) ? kb : -1;
+            const int k = (u_ok && rl < (s.meta >> 2) && kb != TILE_NOBIN) ? kb : -1;
             term_t vr = term_t(0), vi = term_t(0);
             float2 o = make_float2(0.f, 0.f);
             float2* cell = slab;
             if (k >= 0) {
                 if (cstk == 2) { vr = TM::make(s.W.x, s.cd); vi = TM::make(s.W.y, s.cd); }
                 else { const float cs = cstk == 1 ? s.cf : A.cst0; vr = TM::make(s.W.x, cs); vi = TM::make(s.W.y, cs); }
-                cell = slab + (k * 16 + ((cl + k) & 15));
-                o = *cell;
+                cell = slab + (k * 16 + cl);
+                if (!(SSQ_TILE_EXP & 8)) o = *cell;
             }
             // lower rows of this column, ascending: quad lanes rl-3, rl-2, rl-1
             // (quad_perm [0,0,0,0], [0,0,0,1], [0,0,1,2]); -1 never matches a valid bin
@@ -358,17 +398,14 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             // (quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3])
             const int h1 = tile_dpp<0xF9>(-1, k), h2 = tile_dpp<0xFE>(-1, k), h3 = tile_dpp<0xFF>(-1, k);
             const bool last = !((rl <= 2 && h1 == k) || (rl <= 1 && h2 == k) || (rl == 0 && h3 == k));
-            if (k >= 0 && last) *cell = o;
+            if (k >= 0 && last && !(SSQ_TILE_EXP & 8)) *cell = o;
+            if ((SSQ_TILE_EXP & 8) && o.x == 123.f) *cell = o;
             __builtin_amdgcn_wave_barrier();
             // (the ring slot of the step is free again: its bins were loaded long ago)
-            if (s.p >= 0 && c == 0) lds_store_relaxed(my_done, s.p + 1);
-            TILE_STAMP(s.trk >= 0, 0, s.trk, 1);
-            if (s.last_tx >= 0) {
-                if (tr && s.trk >= 0 && c == 0) tr[16 * TRACE_STEPS * 4 + 1] = __builtin_amdgcn_s_memtime();
-                write_out(s.last_tx, s.last_sg);
-                if (tr && s.trk >= 0 && c == 0) tr[16 * TRACE_STEPS * 4 + 2] = __builtin_amdgcn_s_memtime();
-            }
+            if (s.meta & 1) { ++done; if (c == 0) lds_store_relaxed(my_done, done); }
+            if (s.meta & 2) write_out();
         };
+        const int total = A.nsteps * ntl;
         USlot sl[TILE_D];
         if (SSQ_TILE_EXP & 2) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -399,6 +436,9 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         // the same -- valid addresses, results unused -- so that the number of loads in flight
         // does not depend on the path taken)
         const bool real = t.p < ptotal;
+        // (the last group of four steps is completed by whoever draws the tickets that do not exist)
+        if (!real && t.p < ((ptotal + 3) & ~3) && c == 0)
+            __scoped_atomic_fetch_add(&L.gcnt[(t.p >> 2) & (TILE_RING / 4 - 1)], 1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
         if (real) while (t.p >= (gp.itl + 1) * nps) next_tile(gp);
         t.ps = real ? t.p - gp.itl * nps : 0; t.tx = gp.tx; t.sg = gp.sg;
         return t;
@@ -564,14 +604,17 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             const int d0 = lds_load_relaxed(L.upd_done), d1 = lds_load_relaxed(L.upd_done + 1);
             const int d2 = lds_load_relaxed(L.upd_done + 2), d3 = lds_load_relaxed(L.upd_done + 3);
             if (min(min(d0, d1), min(d2, d3)) > pc - TILE_RING) break;
-            __builtin_amdgcn_s_sleep(1);
+            // (a long sleep: the ring is two tiles deep, and a dozen wavefronts polling LDS in a
+            // tight loop take the LDS and the issue slots from the updaters they are waiting for)
+            __builtin_amdgcn_s_sleep(SSQ_TILE_BPSLEEP);
         }
         unsigned short* rb = ring + (size_t)slot * (TILE_G * TILE_COLS) + c;
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) rb[r * TILE_COLS] = (unsigned short)kout[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        if (c == 0) lds_store_relaxed(&L.flags[slot], pc + 1);
+        if (c == 0)
+            __scoped_atomic_fetch_add(&L.gcnt[(pc >> 2) & (TILE_RING / 4 - 1)], 1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
         TILE_STAMP(trk, wv, trj, 3);
         kc_ = kn; kn = knn;
     };
@@ -596,7 +639,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         ncu = pr.multiProcessorCount;
         if (const char* e = getenv("SSQ_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
     }
-    SSQ_REQUIRE(tile_lds_bytes(na, nsteps) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
+    SSQ_REQUIRE(tile_lds_bytes(na, nsegs) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
                 "na = %lld: the Tx tile exceeds the LDS", (long long)na);
     // the modulation phase kc * n mod M is formed with a 24-bit multiply and carried in a float
     SSQ_REQUIRE(M <= ((int64_t)1 << 24), "the tile path needs a padded length <= 2^24");
@@ -647,6 +690,19 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
             hps[i] = hs[(size_t)hp[i]];
             for (int r = 0; r < TILE_G; ++r) hpr[i * TILE_G + r] = rw[(size_t)hp[i] * TILE_G + r];
         }
+        // the updaters' view of the row list: per segment
+        std::vector<int32_t> hu((size_t)nsegs * 4);
+        for (int i = 0, pbefore = 0; i < nsegs; ++i) {
+            int nrows = 0;
+            for (int t = 0; t < sg[i].nsteps; ++t)
+                for (int r = 0; r < TILE_G; ++r) nrows += rw[((size_t)sg[i].first + t) * TILE_G + r].row >= 0 ? 1 : 0;
+            // (only the last step of a segment may be short: the kernel derives a step's rows from the segment)
+            SSQ_REQUIRE(nrows > (sg[i].nsteps - 1) * TILE_G, "tile segment %d: a short step inside the segment", i);
+            hu[4 * i] = rw[(size_t)sg[i].first * TILE_G].row; hu[4 * i + 1] = nrows;
+            hu[4 * i + 2] = sg[i].kind; hu[4 * i + 3] = pbefore;
+            if (sg[i].kind == 1) pbefore += sg[i].nsteps;
+        }
+        if ((rc = up((void**)&usegs, hu.data(), hu.size() * 4))) return rc;
         if ((rc = up((void**)&psegs, hps.data(), sizeof(TileSeg) * hps.size()))) return rc;
         if ((rc = up((void**)&prows, hpr.data(), sizeof(TileRow) * hpr.size()))) return rc;
     }
@@ -701,9 +757,9 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, psegs, prows, irows, wtab, tbank, U, ring, counters};
+    void* ptrs[] = {steps, rows, psegs, prows, usegs, irows, wtab, tbank, U, ring, counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    steps = nullptr; rows = nullptr; psegs = nullptr; prows = nullptr; irows = nullptr; wtab = tbank = U = ring = nullptr;
+    steps = nullptr; rows = nullptr; psegs = nullptr; prows = nullptr; usegs = nullptr; irows = nullptr; wtab = tbank = U = ring = nullptr;
     counters = nullptr;
 }
 
@@ -725,7 +781,7 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
 template <int GRID, bool STORE_D, int NW, int CSTK>
 static int launch_tile_c(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     auto kern = tile_kernel<GRID, STORE_D, NW, CSTK>;
-    const size_t lds = tile_lds_bytes(P.na, P.nsteps);
+    const size_t lds = tile_lds_bytes(P.na, P.nsegs);
     static bool attr_set = false;            // per instantiation
     if (!attr_set) {
         SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -758,6 +814,7 @@ int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const uns
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
     TileArgs A;
     A.steps = steps; A.rows = rows; A.psegs = psegs; A.prows = prows;
+    A.usegs = (const int4*)usegs; A.nusegs = nsegs;
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = cst;
     A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
     A.ring = (unsigned short*)ring;

@@ -43,6 +43,7 @@ struct TilePlan {
     TileSeg* steps = nullptr;               // the segment record of every step (`first`: index among
                                             // the producer steps, -1 for rows read back)
     TileSeg* psegs = nullptr; TileRow* prows = nullptr;   // records of the producer steps only (dense)
+    int32_t* usegs = nullptr;               // the updaters' segment table (4 ints per segment)
     TileRow* rows = nullptr; TileIRow* irows = nullptr;
     void* wtab = nullptr; void* tbank = nullptr;
     void* U = nullptr;                      // group x u_total complex64
