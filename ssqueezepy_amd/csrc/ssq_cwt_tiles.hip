@@ -61,7 +61,7 @@ constexpr int TILE_D = SSQ_TILE_DEPTH;   // steps of loads the updater keeps in 
 #define SSQ_TILE_BPSLEEP 20     // x 64 clocks between two looks at the updaters' progress
 #endif
 constexpr int TILE_NOBIN = 0xFFFF;
-constexpr int TILE_NU = 4;        // updater wavefronts per workgroup (16 columns each)
+constexpr int TILE_NU = 1;        // updater wavefronts per workgroup
 
 struct TileArgs {
     const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
@@ -175,16 +175,36 @@ template <int CTRL> __device__ __forceinline__ double tile_dpp(double old, doubl
     return __hiloint2double(hi, lo);
 }
 
+// ---- the reassignment of one step (4 rows) into the tile, in row order; lane = column. Rows of
+// a step that hit the same cell are chained in registers (same lane = same column: no cross-lane
+// traffic): the cells are read together, a row that hits the cell of an earlier row of the step
+// starts from that row's result, the cells are written back in row order.
+template <typename TM>
+__device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const typename TM::type (&vx)[TILE_G],
+                                        const typename TM::type (&vy)[TILE_G]) {
+    float2 t[TILE_G];
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) t[r] = T[cell[r]];
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) {
+#pragma unroll
+        for (int q = 0; q < r; ++q) if (cell[q] == cell[r]) t[r] = t[q];
+        t[r].x = TM::fold(t[r].x, vx[r]); t[r].y = TM::fold(t[r].y, vy[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
+}
+
 // LDS of a workgroup: the tile, then the control words, the flags and the step table
 struct TileLds {
-    float2* T;          // na x 64 cells: per updater wavefront [bin][16 columns]
+    float2* T;          // (na + 1) x 64 cells (the last row: scratch for points that contribute nothing)
     int* next;          // producer ticket counter
     int* upd_done;      // [TILE_NU]: producer steps each updater has consumed
     int* gcnt;          // [TILE_RING / 4]: producer steps finished, per group of 4 consecutive steps
     int4* segtab;       // [nusegs]: first row, rows, kind, producer steps of the tile before the segment
 };
 __host__ __device__ inline size_t tile_lds_bytes(int64_t na, int nusegs) {
-    return (size_t)na * TILE_COLS * 8 + 32 + 4 * (TILE_RING / 4) + 16 * (size_t)nusegs;
+    return (size_t)(na + 1) * TILE_COLS * 8 + 32 + 4 * (TILE_RING / 4) + 16 * (size_t)nusegs;
 }
 
 template <int GRID, bool STORE_D, int NW, int CSTK>
@@ -197,12 +217,12 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     const int na = (int)A.na, omax = na - 1;
     TileLds L;
     L.T = reinterpret_cast<float2*>(lds_raw);
-    L.next = reinterpret_cast<int*>(lds_raw + (size_t)na * TILE_COLS * 8);
+    L.next = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
     L.upd_done = L.next + 4;                                 // 16-byte aligned: read as one int4
     L.gcnt = L.next + 8;
     L.segtab = reinterpret_cast<int4*>(L.gcnt + TILE_RING / 4);
     float2* T = L.T;
-    for (int k = wv; k < na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+    for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
     if (threadIdx.x < 8) L.next[threadIdx.x] = 0;
     for (int k = threadIdx.x; k < TILE_RING / 4; k += 64 * NW) L.gcnt[k] = 0;
     for (int k = threadIdx.x; k < A.nusegs; k += 64 * NW) L.segtab[k] = A.usegs[k];
@@ -238,42 +258,34 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
 
     if (wv < TILE_NU) {
         // ------------------------------------------------------------------ the updaters
-        // Wavefront u owns columns 16 u .. 16 u + 15 of the tile: its lanes are (column cl, row rl
-        // of the step), lane = 4 cl + rl, so the four rows of a step that belong to one column
-        // are a DPP quad. Per step: one 8-byte load of Wx and one 2-byte load of the bin per lane
-        // (128-byte / 32-byte runs per row), several steps in flight; the cell is read once, the
-        // terms of the lower rows of the quad that hit the same cell are folded in -- in ascending
-        // row order -- with quad_perm moves, and only the highest row of a cell writes it back.
-        const int u = wv;
-        const int cl = c >> 2, rl = c & 3;
-        float2* slab = T + (size_t)u * na * 16;               // [bin][16 columns]
-        int* my_done = L.upd_done + u;
+        // One wavefront, lane = column, walks ALL rows of the tile in ascending order. Its
+        // instruction stream is the serial part of the tile, so it is kept lean: a cursor over
+        // (tile, segment, row) advanced with a few scalar operations, row addresses as a uniform
+        // pointer + the lane's column, no masks (a point that contributes nothing goes to a scratch
+        // row of the tile; lanes past the last column work on LDS columns that are never written
+        // out), one look at the producers' progress per 4 steps, several steps of loads in flight.
+        int* my_done = L.upd_done;
         const int nsg = A.nusegs;
-        // A single wavefront runs this loop for its 16 columns and its instruction stream is the
-        // critical path of the tile, so the loop is kept lean: a cursor over (tile, segment, row)
-        // advanced with a few scalar operations, addresses as a uniform base + a per-lane offset
-        // fixed for the tile, no per-step table reads, one flag look per 4 producer steps.
-        struct USlot {                                        // per lane: one point of the step
-            float2 W; unsigned short kb;                      // (bins stay as loaded: a conversion here would wait for the load)
-            float cf; double cd;
+        struct USlot {
+            float2 W[TILE_G]; unsigned short kb[TILE_G];      // (bins stay as loaded: a conversion here would wait for the load)
+            float cf[TILE_G]; double cd[TILE_G];
             int meta;                                         // wave-uniform: 1 = interpolated rows, 2 = last step of the tile, rows << 2
         };
         const float* cstf = (const float*)A.cst;
         const double* cstd = (const double*)A.cst;
         constexpr int cstk = CSTK;
         auto lane_col = [&](int tx, bool& ok) {               // the lane's column in a tile
-            const int col = tx * TILE_COLS + u * 16 + cl;
+            const int col = tx * TILE_COLS + c;
             ok = col < N;
             return ok ? col : (int)N - 1;
         };
         // ---- load side
         TilePos lp = pos0;                                    // tile of the next load
         bool l_ok;
-        int l_col = lane_col(lp.tx, l_ok);
-        unsigned l_off = (unsigned)rl * nN + (unsigned)l_col; // element offset of the lane's point in a step starting at row 0
-        const float2* l_Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
-        const unsigned short* l_kx = A.kidx + (int64_t)lp.sg * na * N;
-        const unsigned ring_lane = (unsigned)(rl * TILE_COLS + u * 16 + cl);
+        const unsigned N8 = nN * 8u, maxoff8 = (unsigned)(na - 1) * N8;
+        unsigned l_col8 = (unsigned)lane_col(lp.tx, l_ok) * 8u;
+        const char* l_Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N);
+        const char* l_kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)lp.sg * na * N);
         int l_seg = 0, l_row, l_left, l_kind, l_p;
         {
             const int4 sg0 = L.segtab[0];
@@ -287,7 +299,6 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         auto uload = [&](USlot& s) {
             const bool real = lp.itl < ntl;
             const int nvalid = real ? (l_left < TILE_G ? l_left : TILE_G) : 0;
-            const bool lastseg = l_left <= TILE_G;            // last step of the segment
             const bool interp = real && l_kind != 0;
             if (!(SSQ_TILE_EXP & 16) && interp && (l_p >> 2) > l_waited) {
                 // producer steps are waited for by groups of four (one counter per group)
@@ -297,24 +308,32 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                 while (lds_load_acquire(f) < want) __builtin_amdgcn_s_sleep(1);
                 l_waited = g;
             }
-            s.meta = (interp ? 1 : 0) | ((real && lastseg && l_seg == nsg - 1) ? 2 : 0) | (nvalid << 2);
-            // (a step with fewer than 4 rows repeats its last row in the idle lanes)
-            unsigned off = l_off + (unsigned)l_row * nN;
-            unsigned roff = ring_lane;
-            if (nvalid < TILE_G) {
-                const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
-                off = (unsigned)(l_row + rr) * nN + (unsigned)l_col;
-                roff = (unsigned)(rr * TILE_COLS + u * 16 + cl);
+            s.meta = (interp ? 1 : 0) | ((real && l_left <= TILE_G && l_seg == nsg - 1) ? 2 : 0) | (nvalid << 2);
+            // Addresses: a wave-uniform 64-bit base per tile + a 32-bit byte offset (na * N * 8 < 2^32),
+            // = (row * N + column) * 8, formed with one scalar and one vector addition per row. Rows
+            // past the end of a short step are clamped to the last row of the transform (their
+            // points go to the scratch row).
+            const unsigned base8 = (unsigned)l_row * N8;
+            const char* ringp = reinterpret_cast<const char*>(ring) + (size_t)(l_p & (TILE_RING - 1)) * (TILE_G * TILE_COLS * 2);
+            unsigned vo[TILE_G];
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) {
+                const unsigned o8 = min(base8 + (unsigned)r * N8, maxoff8);       // wave-uniform
+                vo[r] = o8 + l_col8;
+                s.W[r] = *reinterpret_cast<const float2*>(l_Wx8 + vo[r]);
+                if (cstk == 1) s.cf[r] = cstf[min(l_row + r, na - 1)];
+                if (cstk == 2) s.cd[r] = cstd[min(l_row + r, na - 1)];
             }
-            if (SSQ_TILE_EXP & 32) s.W = make_float2(0.f, 0.f); else s.W = l_Wx[off];
-            // bins: from the ring (interpolated rows) or from the bin map (rows read back)
-            const unsigned short* bsrc = interp ? ring + (size_t)(l_p & (TILE_RING - 1)) * (TILE_G * TILE_COLS) + roff
-                                                : l_kx + off;
-            if (SSQ_TILE_EXP & 32) s.kb = (unsigned short)(off & 127); else s.kb = *bsrc;
-            if (cstk != 0) {
-                const int rr = rl < nvalid ? rl : (nvalid > 0 ? nvalid - 1 : 0);
-                if (cstk == 1) s.cf = cstf[l_row + rr];
-                if (cstk == 2) s.cd = cstd[l_row + rr];
+            // bins: from the ring (interpolated rows; the producers fill all four rows of a slot) or
+            // from the bin map (rows read back)
+            if (interp) {
+#pragma unroll
+                for (int r = 0; r < TILE_G; ++r)
+                    s.kb[r] = *reinterpret_cast<const unsigned short*>(ringp + (unsigned)(c * 2 + r * TILE_COLS * 2));
+            } else {
+#pragma unroll
+                for (int r = 0; r < TILE_G; ++r)
+                    s.kb[r] = *reinterpret_cast<const unsigned short*>(l_kx8 + (vo[r] >> 2));
             }
             if (real) {                                       // advance the cursor
                 l_row += TILE_G; l_left -= TILE_G; l_p += l_kind;
@@ -322,10 +341,9 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     if (++l_seg == nsg) {
                         l_seg = 0; next_tile(lp);
                         if (lp.itl < ntl) {
-                            l_col = lane_col(lp.tx, l_ok);
-                            l_off = (unsigned)rl * nN + (unsigned)l_col;
-                            l_Wx = A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N;
-                            l_kx = A.kidx + (int64_t)lp.sg * na * N;
+                            l_col8 = (unsigned)lane_col(lp.tx, l_ok) * 8u;
+                            l_Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N);
+                            l_kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)lp.sg * na * N);
                         }
                     }
                     const int4 sg = L.segtab[l_seg];
@@ -337,77 +355,51 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         };
         // ---- update side
         TilePos up = pos0;                                    // the tile being reassigned
-        bool u_ok; (void)lane_col(up.tx, u_ok);
         int done = 0;                                         // producer steps consumed
-        // the finished columns go to Tx and are cleared: 4 bins x 16 columns per instruction
+        // the finished tile goes to Tx and is cleared
         auto write_out = [&]() {
-            bool ok; const int col = lane_col(up.tx, ok);
-            float2* Tx = A.Tx + (int64_t)(A.sig0 + up.sg) * na * N;
-            const unsigned loff = (unsigned)rl * nN + (unsigned)col;
-            float2* cellp = slab + (rl * 16 + cl);
-            for (int k0 = 0; k0 < na; k0 += 4 * 4) {
-                float2 v[4];
+            bool ok; const unsigned col8 = (unsigned)lane_col(up.tx, ok) * 8u;
+            char* Tx8 = reinterpret_cast<char*>(A.Tx + (int64_t)(A.sig0 + up.sg) * na * N);
+            for (int k0 = 0; k0 < na; k0 += 8) {              // 8 bins in flight
+                float2 v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kq = k0 + 4 * q;
-                    v[q] = cellp[(kq + rl < na ? kq : 0) * 16];
-                }
+                for (int q = 0; q < 8; ++q) v[q] = T[(k0 + q < na ? k0 + q : na) * TILE_COLS + c];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int kq = k0 + 4 * q;
-                    if (kq + rl < na) {
-                        cellp[kq * 16] = make_float2(0.f, 0.f);
-                        if (ok && !(SSQ_TILE_EXP & 64)) Tx[loff + (unsigned)kq * nN] = v[q];
+                for (int q = 0; q < 8; ++q)
+                    if (k0 + q < na) {
+                        T[(k0 + q) * TILE_COLS + c] = make_float2(0.f, 0.f);
+                        if (ok && !(SSQ_TILE_EXP & 64)) *reinterpret_cast<float2*>(Tx8 + ((unsigned)(k0 + q) * N8 + col8)) = v[q];
                     }
-                }
             }
-            // (cells are cleared by other lanes than the ones that read them next: on the GPU the
-            // wavefront runs in lockstep; the barrier makes that explicit for the CPU emulation)
-            __builtin_amdgcn_wave_barrier();
-            if (A.counters && c == 0 && u == 0)
+            if (A.counters && c == 0)
                 __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
             next_tile(up);
-            if (up.itl < ntl) (void)lane_col(up.tx, u_ok);
         };
         using TM = TileTerm<CSTK == 2>;
         using term_t = typename TM::type;
         auto uprocess = [&](const USlot& s) {
-            if (SSQ_TILE_EXP & 128) { done += s.meta & 1; if ((s.meta & 1) && c == 0) lds_store_relaxed(my_done, done); if (s.meta & 2) write_out(); return; }
-            const int kb = s.kb;
-            const int k = (u_ok && rl < (s.meta >> 2) && kb != TILE_NOBIN) ? kb : -1;
-            term_t vr = term_t(0), vi = term_t(0);
-            float2 o = make_float2(0.f, 0.f);
-            float2* cell = slab;
-            if (k >= 0) {
-                if (cstk == 2) { vr = TM::make(s.W.x, s.cd); vi = TM::make(s.W.y, s.cd); }
-                else { const float cs = cstk == 1 ? s.cf : A.cst0; vr = TM::make(s.W.x, cs); vi = TM::make(s.W.y, cs); }
-                cell = slab + (k * 16 + cl);
-                if (!(SSQ_TILE_EXP & 8)) o = *cell;
+            if (!(SSQ_TILE_EXP & 128)) {
+                const int nvalid = s.meta >> 2;
+                int cell[TILE_G]; term_t vx[TILE_G], vy[TILE_G];
+#pragma unroll
+                for (int r = 0; r < TILE_G; ++r) {
+                    // (the bin map's "no contribution" mark 0xFFFF and the rows a short step repeats
+                    // go to the scratch row)
+                    const int kb = s.kb[r];
+                    const int bin = r < nvalid ? min(kb, na) : na;
+                    cell[r] = bin * TILE_COLS + c;
+                    if (cstk == 2) { vx[r] = TM::make(s.W[r].x, s.cd[r]); vy[r] = TM::make(s.W[r].y, s.cd[r]); }
+                    else { const float cs = cstk == 1 ? s.cf[r] : A.cst0; vx[r] = TM::make(s.W[r].x, cs); vy[r] = TM::make(s.W[r].y, cs); }
+                }
+                if (!(SSQ_TILE_EXP & 8)) update4<TM>(T, cell, vx, vy);
             }
-            // lower rows of this column, ascending: quad lanes rl-3, rl-2, rl-1
-            // (quad_perm [0,0,0,0], [0,0,0,1], [0,0,1,2]); -1 never matches a valid bin
-            const int k3 = tile_dpp<0x00>(-1, k), k2 = tile_dpp<0x40>(-1, k), k1 = tile_dpp<0x90>(-1, k);
-            const term_t r3 = tile_dpp<0x00>(term_t(0), vr), i3 = tile_dpp<0x00>(term_t(0), vi);
-            const term_t r2 = tile_dpp<0x40>(term_t(0), vr), i2 = tile_dpp<0x40>(term_t(0), vi);
-            const term_t r1 = tile_dpp<0x90>(term_t(0), vr), i1 = tile_dpp<0x90>(term_t(0), vi);
-            if (rl >= 3 && k3 == k) { o.x = TM::fold(o.x, r3); o.y = TM::fold(o.y, i3); }
-            if (rl >= 2 && k2 == k) { o.x = TM::fold(o.x, r2); o.y = TM::fold(o.y, i2); }
-            if (rl >= 1 && k1 == k) { o.x = TM::fold(o.x, r1); o.y = TM::fold(o.y, i1); }
-            o.x = TM::fold(o.x, vr); o.y = TM::fold(o.y, vi);
-            // a higher row of the quad hitting the same cell writes it instead
-            // (quad_perm [1,2,3,3], [2,3,3,3], [3,3,3,3])
-            const int h1 = tile_dpp<0xF9>(-1, k), h2 = tile_dpp<0xFE>(-1, k), h3 = tile_dpp<0xFF>(-1, k);
-            const bool last = !((rl <= 2 && h1 == k) || (rl <= 1 && h2 == k) || (rl == 0 && h3 == k));
-            if (k >= 0 && last && !(SSQ_TILE_EXP & 8)) *cell = o;
-            if ((SSQ_TILE_EXP & 8) && o.x == 123.f) *cell = o;
-            __builtin_amdgcn_wave_barrier();
             // (the ring slot of the step is free again: its bins were loaded long ago)
             if (s.meta & 1) { ++done; if (c == 0) lds_store_relaxed(my_done, done); }
             if (s.meta & 2) write_out();
         };
         const int total = A.nsteps * ntl;
         USlot sl[TILE_D];
-        if (SSQ_TILE_EXP & 2) __builtin_amdgcn_s_setprio(3);
+        if (!(SSQ_TILE_EXP & 2)) __builtin_amdgcn_s_setprio(3);   // the serial part of the tile goes first
 #pragma unroll
         for (int k = 0; k < TILE_D; ++k) uload(sl[k]);
         for (int g0 = 0; g0 < total; g0 += TILE_D) {
@@ -601,9 +593,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         const int slot = pc & (TILE_RING - 1);
         TILE_STAMP(trk, wv, trj, 2);
         for (;;) {                                            // (the slowest of the updaters counts)
-            const int d0 = lds_load_relaxed(L.upd_done), d1 = lds_load_relaxed(L.upd_done + 1);
-            const int d2 = lds_load_relaxed(L.upd_done + 2), d3 = lds_load_relaxed(L.upd_done + 3);
-            if (min(min(d0, d1), min(d2, d3)) > pc - TILE_RING) break;
+            if (lds_load_relaxed(L.upd_done) > pc - TILE_RING) break;
             // (a long sleep: the ring is two tiles deep, and a dozen wavefronts polling LDS in a
             // tight loop take the LDS and the issue slots from the updaters they are waiting for)
             __builtin_amdgcn_s_sleep(SSQ_TILE_BPSLEEP);
