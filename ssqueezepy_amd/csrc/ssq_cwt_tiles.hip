@@ -8,30 +8,37 @@
 //                         per decimation class turns it into the samples u_i[q] (plan-owned
 //                         intermediate, ~34 MB per signal at N=160k: L2 / Infinity-Cache food).
 //
-//   tile_kernel           one persistent workgroup per CU walks 64-column tiles of one signal
-//                         after the other. The 64 columns x na bins of the tile's Tx live in LDS
-//                         (which is why there is one workgroup per CU); lane = column. Two
-//                         kinds of wavefronts:
-//                           * producers (all but one): take the steps (4 consecutive rows) of
-//                             the interpolated rows from a ticket counter; per row and lane ONE
-//                             8-byte load of u_i (the lanes hold a window of consecutive
-//                             samples, taps come from the neighbours with ds_bpermute), 8 taps
-//                             x (phi, phi') as packed FMAs, modulation by hardware sin / cos of
-//                             the exact phase kc n mod M, Wx stored (512-byte runs), phase
-//                             transform + bin exactly as the other fused kernels do
-//                             (ssq_point_math.inl), the 2-byte bin stored to a small ring in
-//                             global memory (L2-resident), a flag in LDS. They hold no tile
-//                             state and wait for nobody (but the ring's back-pressure).
-//                           * the updater (wavefront 0): walks ALL rows of the tile in ascending
-//                             order -- the rows the block / exact kernels left in HBM (Wx + bin
-//                             map) and, behind the producers' flags, the interpolated rows (Wx
-//                             back from L2, bins from the ring) -- and does the reassignment
-//                             T[bin] += Wx * const in LDS, several steps of loads in flight.
-//                             One wavefront, program order: every cell receives its contributions
-//                             in ascending row order, the reference's (algos.py:859-953), so the
-//                             float sums are bit-identical to the CPU loop on the same Wx / dWx.
-//                             At the end of a tile it writes Tx once and clears the tile.
+//   tile_kernel           one persistent workgroup per CU (16 wavefronts, 4 per SIMD) walks
+//                         64-column tiles of one signal after the other. The 64 columns x na bins
+//                         of the tile's Tx live in LDS (which is why there is one workgroup per
+//                         CU); lane = column. The steps (4 consecutive rows) of all tiles are
+//                         dealt to the wavefronts round-robin. Per step and lane:
+//                           interpolated rows: ONE 8-byte load of u_i per row (the lanes hold a
+//                             window of consecutive samples, taps come from the neighbours with
+//                             ds_bpermute), 8 taps x (phi, phi') as packed FMAs, modulation by
+//                             hardware sin / cos of the exact phase kc n mod M, Wx stored
+//                             (512-byte runs), phase transform + bin exactly as the other fused
+//                             kernels do (ssq_point_math.inl);
+//                           rows read back: Wx and the 2-byte bin the block / exact kernels left.
+//                         The arithmetic of different steps runs concurrently; only the
+//                         reassignment T[bin] += Wx * const is ordered, by a ticket in LDS (step
+//                         S may update the tile once `turn` says so): every cell receives its
+//                         contributions in ascending row order, the reference's
+//                         (algos.py:859-953), so the float sums are bit-identical to the CPU loop
+//                         on the same Wx / dWx. Inside a step the four rows' cells are read
+//                         together and chained in registers when they coincide (same lane = same
+//                         column: no cross-lane traffic), then written in row order. Between two
+//                         tiles all wavefronts write their share of the finished tile to Tx.
 //                         No workgroup barrier after the prologue, no atomics on data.
+//
+//                         Round 3 tried the other split -- producer wavefronts that only compute,
+//                         one (or four) updater wavefronts that only reassign, hand-over through an
+//                         L2-resident ring -- and measured it slower (400-550 us per transform
+//                         against 320): a single wavefront issues a dependent instruction every
+//                         8-10 cycles, so a serial stream of ~100 instructions per step cannot keep
+//                         up with fifteen producers. What that round kept from it: loads issued
+//                         unconditionally so that the compiler's wait counts stay static, 16
+//                         wavefronts at 128 registers, the float64-weight fold, one step per ticket.
 //
 // Compiled with -ffp-contract=off (bin indices); multiply-adds that may fuse are written as
 // explicit fmaf so every instantiation rounds identically.
@@ -47,37 +54,24 @@ namespace ssq {
 constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
 constexpr int TILE_G = 4;         // rows per step
 constexpr int TILE_W = 8;         // taps
-constexpr int TILE_RING = 128;    // producer steps whose bins may be in flight (power of two)
-#ifndef SSQ_TILE_DEPTH
-#define SSQ_TILE_DEPTH 4
-#endif
-constexpr int TILE_D = SSQ_TILE_DEPTH;   // steps of loads the updater keeps in flight
-// tuning experiments (A/B builds, tools/ab_variant.sh): 1 = the updater skips the rows read back,
-// 2 = the updater runs at high priority, 4 = the producers skip their arithmetic (WRONG RESULTS with 1, 4)
+constexpr int TILE_NOBIN = 0xFFFF;
+// tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
+// only), 2 = no ticket wait, 4 = no arithmetic
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
-#ifndef SSQ_TILE_BPSLEEP
-#define SSQ_TILE_BPSLEEP 20     // x 64 clocks between two looks at the updaters' progress
-#endif
-constexpr int TILE_NOBIN = 0xFFFF;
-constexpr int TILE_NU = 1;        // updater wavefronts per workgroup
 
 struct TileArgs {
-    const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step
-    const TileSeg* psegs; const TileRow* prows;      // the same records, producer steps only (dense)
-    const int4* usegs; int nusegs;                   // the updaters' view: per segment (first row, rows, kind, producer steps before it)
+    const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step, 4 rows per step
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
-    unsigned short* ring;                            // per workgroup: TILE_RING x 4 x 64 bins
     int64_t N, na;
-    int nsteps, npsteps, n1, mmask, sig0, nsig;
-    int cstk;            // reassignment weights: 0 one float (cst0), 1 float per row, 2 double per row
+    int nsteps, n1, mmask, sig0, nsig;
     float inv_m;         // 1 / M
     float theta_scale;   // 2 pi / (M dt): theta of a row = kc * theta_scale
     float cst0;          // the reassignment weight when it is the same for every row
-    unsigned long long* counters;   // [0] += tiles finished by the updater (what actually ran)
+    unsigned long long* counters;   // [0] += tiles finished (what actually ran)
     unsigned long long* trace;      // tuning aid (SSQ_TILE_TRACE): shader-clock stamps of one workgroup
     double gamma;
 };
@@ -114,14 +108,8 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
 __device__ __forceinline__ int lds_load_acquire(const int* p) {
     return __scoped_atomic_load_n(p, __ATOMIC_ACQUIRE, __MEMORY_SCOPE_WRKGRP);
 }
-__device__ __forceinline__ int lds_load_relaxed(const int* p) {
-    return __scoped_atomic_load_n(p, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
-}
 __device__ __forceinline__ void lds_store_release(int* p, int v) {
     __scoped_atomic_store_n(p, v, __ATOMIC_RELEASE, __MEMORY_SCOPE_WRKGRP);
-}
-__device__ __forceinline__ void lds_store_relaxed(int* p, int v) {
-    __scoped_atomic_store_n(p, v, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
 }
 
 // bin of a point the float32 screens could not decide (flipped as Tx wants it), or -1 when it
@@ -134,51 +122,32 @@ __device__ __forceinline__ int exact_bin(float2 W, float2 D, const SsqParams& sp
     return sp.flipud ? omax - ke : ke;
 }
 
-// trace (tuning aid): [wavefront][step of the traced tile, < 128][4 stamps], then 64 extra words
+// trace (tuning aid): [wavefront][step slot < 128][4 stamps], then 64 extra words
 constexpr int TRACE_STEPS = 128, TRACE_WORDS = 16 * TRACE_STEPS * 4 + 64;
 #define TILE_STAMP(on, wave, j, k)                                                               \
     do { if (tr && (on) && (j) < TRACE_STEPS && c == 0)                                        \
              tr[((size_t)(wave) * TRACE_STEPS + (j)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 constexpr int TRACE_TILE = 2;
 
-// what a step needs to know about its tile (64 columns of one signal of the launch group)
-struct TileCtx {
-    int tx, sg;              // tile along time, signal of the group
-    int colc, nabs, nabs0;   // column of the lane (clamped), its padded index, padded index of column 0
-    bool colok;
-    int64_t obase;           // element offset of the signal in Wx / dWx / Tx
-    int64_t kbase;           // ... in the bin map of the group
-};
-
 // the additive term of one point and how it is folded into a cell, in the CPU path's arithmetic:
 // float32 data with a float64 weight vector accumulates through double (algos.py:66-79)
 template <bool CST64> struct TileTerm {
     using type = float;
+    using wtype = float;
     static __device__ __forceinline__ float make(float z, float w) { return z * w; }
     static __device__ __forceinline__ float fold(float o, float t) { return o + t; }
 };
 template <> struct TileTerm<true> {
     using type = double;
+    using wtype = double;
     static __device__ __forceinline__ double make(float z, double w) { return (double)z * w; }
     static __device__ __forceinline__ float fold(float o, double t) { return (float)((double)o + t); }
 };
-// v_mov_b32_dpp quad_perm: lanes without a source keep `old`
-template <int CTRL> __device__ __forceinline__ int tile_dpp(int old, int v) {
-    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, 0xF, false);
-}
-template <int CTRL> __device__ __forceinline__ float tile_dpp(float old, float v) {
-    return __int_as_float(tile_dpp<CTRL>(__float_as_int(old), __float_as_int(v)));
-}
-template <int CTRL> __device__ __forceinline__ double tile_dpp(double old, double v) {
-    const int lo = tile_dpp<CTRL>(__double2loint(old), __double2loint(v));
-    const int hi = tile_dpp<CTRL>(__double2hiint(old), __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
 
 // ---- the reassignment of one step (4 rows) into the tile, in row order; lane = column. Rows of
-// a step that hit the same cell are chained in registers (same lane = same column: no cross-lane
-// traffic): the cells are read together, a row that hits the cell of an earlier row of the step
-// starts from that row's result, the cells are written back in row order.
+// a step that hit the same cell are chained in registers: the cells are read together, a row
+// that hits the cell of an earlier row of the step starts from that row's result, the cells are
+// written back in row order. `cell` of a point without contribution is the lane's scratch cell.
 template <typename TM>
 __device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const typename TM::type (&vx)[TILE_G],
                                         const typename TM::type (&vy)[TILE_G]) {
@@ -195,18 +164,11 @@ __device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], co
     for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
 }
 
-// LDS of a workgroup: the tile, then the control words, the flags and the step table
-struct TileLds {
-    float2* T;          // (na + 1) x 64 cells (the last row: scratch for points that contribute nothing)
-    int* next;          // producer ticket counter
-    int* upd_done;      // [TILE_NU]: producer steps each updater has consumed
-    int* gcnt;          // [TILE_RING / 4]: producer steps finished, per group of 4 consecutive steps
-    int4* segtab;       // [nusegs]: first row, rows, kind, producer steps of the tile before the segment
-};
-__host__ __device__ inline size_t tile_lds_bytes(int64_t na, int nusegs) {
-    return (size_t)(na + 1) * TILE_COLS * 8 + 32 + 4 * (TILE_RING / 4) + 16 * (size_t)nusegs;
+__host__ __device__ inline size_t tile_lds_bytes(int64_t na) {
+    return (size_t)(na + 1) * TILE_COLS * 8 + 16;
 }
 
+// CSTK: reassignment weights -- 0 one float (cst0), 1 a float per row, 2 a double per row
 template <int GRID, bool STORE_D, int NW, int CSTK>
 __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -215,226 +177,73 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     const int64_t N = A.N;
     const unsigned nN = (unsigned)N;
     const int na = (int)A.na, omax = na - 1;
-    TileLds L;
-    L.T = reinterpret_cast<float2*>(lds_raw);
-    L.next = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
-    L.upd_done = L.next + 4;                                 // 16-byte aligned: read as one int4
-    L.gcnt = L.next + 8;
-    L.segtab = reinterpret_cast<int4*>(L.gcnt + TILE_RING / 4);
-    float2* T = L.T;
+    float2* T = reinterpret_cast<float2*>(lds_raw);           // (na + 1) x 64 cells, the last row: scratch
+    int* turn = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
+    int* wdone = turn + 1;
     for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
-    if (threadIdx.x < 8) L.next[threadIdx.x] = 0;
-    for (int k = threadIdx.x; k < TILE_RING / 4; k += 64 * NW) L.gcnt[k] = 0;
-    for (int k = threadIdx.x; k < A.nusegs; k += 64 * NW) L.segtab[k] = A.usegs[k];
+    if (threadIdx.x == 0) { *turn = 0; *wdone = 0; }
     __syncthreads();
+    const int scratch = na * TILE_COLS + c;
 
     // The workgroup is persistent: it walks the tiles blockIdx.x, + gridDim.x, ... of the launch
-    // group (tile = 64 columns of one signal); positions advance monotonically, so the
-    // divisions are done once, by repeated subtraction
+    // group (tile = 64 columns of one signal). All steps of all its tiles form one sequence
+    // S = 0, 1, ...: wavefront w takes S = w, w + NW, ... (positions advance monotonically, so
+    // divisions are replaced by repeated subtraction). Ticket of step S of tile itl: S + itl --
+    // one extra ticket per tile, during which the finished tile is written out.
     const int ntx = (int)((N + TILE_COLS - 1) / TILE_COLS);
     const int ntot = ntx * A.nsig;
     const int ntl = ntot > (int)blockIdx.x ? (ntot - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    auto ctx_of = [&](int tx, int sg) {
-        TileCtx t;
-        t.tx = tx; t.sg = sg;
-        const int col0 = tx * TILE_COLS, col = col0 + c;
-        t.colok = col < N;
-        t.colc = t.colok ? col : (int)N - 1;                 // loads stay in range
-        t.nabs = A.n1 + t.colc; t.nabs0 = A.n1 + col0;
-        t.obase = (int64_t)(A.sig0 + sg) * na * N;
-        t.kbase = (int64_t)sg * na * N;
-        return t;
+    const int nst = A.nsteps;
+    const int total = nst * ntl;
+    struct Pos { int S, itl, st, tx, sg; };                   // a step: sequence number, tile, step in tile, tile position
+    auto advance = [&](Pos& q, int by) {
+        q.S += by; q.st += by;
+        while (q.st >= nst && q.itl < ntl) {
+            q.st -= nst; ++q.itl; q.tx += (int)gridDim.x;
+            while (q.tx >= ntx) { q.tx -= ntx; ++q.sg; }
+        }
     };
-    struct TilePos { int itl, tx, sg; };                     // the workgroup's itl-th tile
-    TilePos pos0;
-    pos0.itl = 0; pos0.sg = (int)blockIdx.x / ntx; pos0.tx = (int)blockIdx.x - pos0.sg * ntx;
-    auto next_tile = [&](TilePos& q) {
-        ++q.itl; q.tx += (int)gridDim.x;
-        while (q.tx >= ntx) { q.tx -= ntx; ++q.sg; }
-    };
-    const int nps = A.npsteps;
     unsigned long long* tr = (A.trace && (int)blockIdx.x == (100 < (int)gridDim.x ? 100 : (int)gridDim.x - 1)) ? A.trace : nullptr;
-    unsigned short* ring = A.ring + (size_t)blockIdx.x * TILE_RING * TILE_G * TILE_COLS;
 
-    if (wv < TILE_NU) {
-        // ------------------------------------------------------------------ the updaters
-        // One wavefront, lane = column, walks ALL rows of the tile in ascending order. Its
-        // instruction stream is the serial part of the tile, so it is kept lean: a cursor over
-        // (tile, segment, row) advanced with a few scalar operations, row addresses as a uniform
-        // pointer + the lane's column, no masks (a point that contributes nothing goes to a scratch
-        // row of the tile; lanes past the last column work on LDS columns that are never written
-        // out), one look at the producers' progress per 4 steps, several steps of loads in flight.
-        int* my_done = L.upd_done;
-        const int nsg = A.nusegs;
-        struct USlot {
-            float2 W[TILE_G]; unsigned short kb[TILE_G];      // (bins stay as loaded: a conversion here would wait for the load)
-            float cf[TILE_G]; double cd[TILE_G];
-            int meta;                                         // wave-uniform: 1 = interpolated rows, 2 = last step of the tile, rows << 2
-        };
-        const float* cstf = (const float*)A.cst;
-        const double* cstd = (const double*)A.cst;
-        constexpr int cstk = CSTK;
-        auto lane_col = [&](int tx, bool& ok) {               // the lane's column in a tile
-            const int col = tx * TILE_COLS + c;
-            ok = col < N;
-            return ok ? col : (int)N - 1;
-        };
-        // ---- load side
-        TilePos lp = pos0;                                    // tile of the next load
-        bool l_ok;
-        const unsigned N8 = nN * 8u, maxoff8 = (unsigned)(na - 1) * N8;
-        unsigned l_col8 = (unsigned)lane_col(lp.tx, l_ok) * 8u;
-        const char* l_Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N);
-        const char* l_kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)lp.sg * na * N);
-        int l_seg = 0, l_row, l_left, l_kind, l_p;
-        {
-            const int4 sg0 = L.segtab[0];
-            l_row = __builtin_amdgcn_readfirstlane(sg0.x); l_left = __builtin_amdgcn_readfirstlane(sg0.y);
-            l_kind = __builtin_amdgcn_readfirstlane(sg0.z); l_p = __builtin_amdgcn_readfirstlane(sg0.w);
-        }
-        int l_waited = -1;                                    // last group of producer steps known complete
-        // Loads are issued unconditionally (past the last step: a repeat of the last addresses, marked
-        // empty): the compiler counts the loads in flight per path, and a path that skips some makes
-        // every wait a full drain.
-        auto uload = [&](USlot& s) {
-            const bool real = lp.itl < ntl;
-            const int nvalid = real ? (l_left < TILE_G ? l_left : TILE_G) : 0;
-            const bool interp = real && l_kind != 0;
-            if (!(SSQ_TILE_EXP & 16) && interp && (l_p >> 2) > l_waited) {
-                // producer steps are waited for by groups of four (one counter per group)
-                const int g = l_p >> 2;
-                const int* f = L.gcnt + (g & (TILE_RING / 4 - 1));
-                const int want = 4 * ((g >> 5) + 1);          // (TILE_RING / 4 = 32 groups in the ring)
-                while (lds_load_acquire(f) < want) __builtin_amdgcn_s_sleep(1);
-                l_waited = g;
-            }
-            s.meta = (interp ? 1 : 0) | ((real && l_left <= TILE_G && l_seg == nsg - 1) ? 2 : 0) | (nvalid << 2);
-            // Addresses: a wave-uniform 64-bit base per tile + a 32-bit byte offset (na * N * 8 < 2^32),
-            // = (row * N + column) * 8, formed with one scalar and one vector addition per row. Rows
-            // past the end of a short step are clamped to the last row of the transform (their
-            // points go to the scratch row).
-            const unsigned base8 = (unsigned)l_row * N8;
-            const char* ringp = reinterpret_cast<const char*>(ring) + (size_t)(l_p & (TILE_RING - 1)) * (TILE_G * TILE_COLS * 2);
-            unsigned vo[TILE_G];
+    // rows k = wv, wv + NW, ... of the finished tile go to Tx and are cleared; the last
+    // wavefront to finish opens the next tile's tickets
+    auto write_out = [&](int itl, int tx, int sg) {
+        const int boundary = (itl + 1) * nst + itl;           // the ticket after the tile's last step
+        while (lds_load_acquire(turn) != boundary) __builtin_amdgcn_s_sleep(1);
+        const unsigned col = (unsigned)(tx * TILE_COLS + c);
+        const bool ok = col < nN;
+        float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
+        for (int k0 = wv; k0 < na; k0 += 4 * NW) {
+            float2 v[4];
 #pragma unroll
-            for (int r = 0; r < TILE_G; ++r) {
-                const unsigned o8 = min(base8 + (unsigned)r * N8, maxoff8);       // wave-uniform
-                vo[r] = o8 + l_col8;
-                s.W[r] = *reinterpret_cast<const float2*>(l_Wx8 + vo[r]);
-                if (cstk == 1) s.cf[r] = cstf[min(l_row + r, na - 1)];
-                if (cstk == 2) s.cd[r] = cstd[min(l_row + r, na - 1)];
-            }
-            // bins: from the ring (interpolated rows; the producers fill all four rows of a slot) or
-            // from the bin map (rows read back)
-            if (interp) {
+            for (int q = 0; q < 4; ++q) { const int k = k0 + q * NW; v[q] = T[(k < na ? k : na) * TILE_COLS + c]; }
 #pragma unroll
-                for (int r = 0; r < TILE_G; ++r)
-                    s.kb[r] = *reinterpret_cast<const unsigned short*>(ringp + (unsigned)(c * 2 + r * TILE_COLS * 2));
-            } else {
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r)
-                    s.kb[r] = *reinterpret_cast<const unsigned short*>(l_kx8 + (vo[r] >> 2));
-            }
-            if (real) {                                       // advance the cursor
-                l_row += TILE_G; l_left -= TILE_G; l_p += l_kind;
-                if (l_left <= 0) {
-                    if (++l_seg == nsg) {
-                        l_seg = 0; next_tile(lp);
-                        if (lp.itl < ntl) {
-                            l_col8 = (unsigned)lane_col(lp.tx, l_ok) * 8u;
-                            l_Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + lp.sg) * na * N);
-                            l_kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)lp.sg * na * N);
-                        }
-                    }
-                    const int4 sg = L.segtab[l_seg];
-                    l_row = __builtin_amdgcn_readfirstlane(sg.x); l_left = __builtin_amdgcn_readfirstlane(sg.y);
-                    l_kind = __builtin_amdgcn_readfirstlane(sg.z);
-                    l_p = lp.itl * nps + __builtin_amdgcn_readfirstlane(sg.w);
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q * NW;
+                if (k < na) {
+                    T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+                    if (ok) Tx[(unsigned)k * nN + col] = v[q];
                 }
             }
-        };
-        // ---- update side
-        TilePos up = pos0;                                    // the tile being reassigned
-        int done = 0;                                         // producer steps consumed
-        // the finished tile goes to Tx and is cleared
-        auto write_out = [&]() {
-            bool ok; const unsigned col8 = (unsigned)lane_col(up.tx, ok) * 8u;
-            char* Tx8 = reinterpret_cast<char*>(A.Tx + (int64_t)(A.sig0 + up.sg) * na * N);
-            for (int k0 = 0; k0 < na; k0 += 8) {              // 8 bins in flight
-                float2 v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = T[(k0 + q < na ? k0 + q : na) * TILE_COLS + c];
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (k0 + q < na) {
-                        T[(k0 + q) * TILE_COLS + c] = make_float2(0.f, 0.f);
-                        if (ok && !(SSQ_TILE_EXP & 64)) *reinterpret_cast<float2*>(Tx8 + ((unsigned)(k0 + q) * N8 + col8)) = v[q];
-                    }
-            }
-            if (A.counters && c == 0)
-                __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
-            next_tile(up);
-        };
-        using TM = TileTerm<CSTK == 2>;
-        using term_t = typename TM::type;
-        auto uprocess = [&](const USlot& s) {
-            if (!(SSQ_TILE_EXP & 128)) {
-                const int nvalid = s.meta >> 2;
-                int cell[TILE_G]; term_t vx[TILE_G], vy[TILE_G];
-#pragma unroll
-                for (int r = 0; r < TILE_G; ++r) {
-                    // (the bin map's "no contribution" mark 0xFFFF and the rows a short step repeats
-                    // go to the scratch row)
-                    const int kb = s.kb[r];
-                    const int bin = r < nvalid ? min(kb, na) : na;
-                    cell[r] = bin * TILE_COLS + c;
-                    if (cstk == 2) { vx[r] = TM::make(s.W[r].x, s.cd[r]); vy[r] = TM::make(s.W[r].y, s.cd[r]); }
-                    else { const float cs = cstk == 1 ? s.cf[r] : A.cst0; vx[r] = TM::make(s.W[r].x, cs); vy[r] = TM::make(s.W[r].y, cs); }
-                }
-                if (!(SSQ_TILE_EXP & 8)) update4<TM>(T, cell, vx, vy);
-            }
-            // (the ring slot of the step is free again: its bins were loaded long ago)
-            if (s.meta & 1) { ++done; if (c == 0) lds_store_relaxed(my_done, done); }
-            if (s.meta & 2) write_out();
-        };
-        const int total = A.nsteps * ntl;
-        USlot sl[TILE_D];
-        if (!(SSQ_TILE_EXP & 2)) __builtin_amdgcn_s_setprio(3);   // the serial part of the tile goes first
-#pragma unroll
-        for (int k = 0; k < TILE_D; ++k) uload(sl[k]);
-        for (int g0 = 0; g0 < total; g0 += TILE_D) {
-#pragma unroll
-            for (int k = 0; k < TILE_D; ++k) { uprocess(sl[k]); uload(sl[k]); }
         }
-        return;
-    }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (c == 0) {
+            const int before = __scoped_atomic_fetch_add(wdone, 1, __ATOMIC_ACQ_REL, __MEMORY_SCOPE_WRKGRP);
+            if (before + 1 == NW * (itl + 1)) {
+                lds_store_release(turn, boundary + 1);
+                if (A.counters) __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+            }
+        }
+    };
 
-    // ---------------------------------------------------------------------- producers
-    const int ptotal = nps * ntl;
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
-    // a ticket = the next producer step of the workgroup, with the tile it belongs to
-    struct Ticket { int p, ps, tx, sg; };                    // ps: index among the tile's producer steps
-    TilePos gp = pos0;                                        // tile of the last ticket taken
-    auto grab = [&]() {
-        int p = 0;
-        if (c == 0) p = __scoped_atomic_fetch_add(L.next, 1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
-        Ticket t;
-        // (lane 0's value for everybody; as a bpermute so that the CPU emulation of the kernels,
-        // where readfirstlane is the identity, sees a real broadcast)
-        t.p = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ds_bpermute(0, p));
-        // (a ticket past the end repeats the position of the last one: its loads are issued all
-        // the same -- valid addresses, results unused -- so that the number of loads in flight
-        // does not depend on the path taken)
-        const bool real = t.p < ptotal;
-        // (the last group of four steps is completed by whoever draws the tickets that do not exist)
-        if (!real && t.p < ((ptotal + 3) & ~3) && c == 0)
-            __scoped_atomic_fetch_add(&L.gcnt[(t.p >> 2) & (TILE_RING / 4 - 1)], 1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
-        if (real) while (t.p >= (gp.itl + 1) * nps) next_tile(gp);
-        t.ps = real ? t.p - gp.itl * nps : 0; t.tx = gp.tx; t.sg = gp.sg;
-        return t;
-    };
+    using TM = TileTerm<CSTK == 2>;
+    using term_t = typename TM::type;
+    using w_t = typename TM::wtype;
+    const w_t* cstv = (const w_t*)A.cst;
 
     // Step and row records are the same for every lane. They are fetched with vector loads from a
     // lane-independent address (one request per wavefront) rather than scalar loads: scalar and
@@ -442,178 +251,216 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // scalar load in flight turns every wait for a ds_bpermute result into a full drain.
     int vz = 0;
     SSQ_OPAQUE_V(vz);
-    const int4* rows4 = reinterpret_cast<const int4*>(A.prows) + vz;
-    const int4* steps4 = reinterpret_cast<const int4*>(A.psegs) + vz;
+    const int4* rows4 = reinterpret_cast<const int4*>(A.rows) + vz;
+    const int4* steps4 = reinterpret_cast<const int4*>(A.steps) + vz;
+    const w_t* cstu = cstv + vz;
 
-    // Software pipeline over this wavefront's tickets: the records of a step are fetched while
-    // the step before it is computed, its samples half a step ahead.
-    int4 sa, sb, rec[TILE_G];                 // next step: (kind, first, nsteps, lgR | wtab, stride, L-1, base), rows
-    auto load_rec = [&](const Ticket& k) {
-        const int g = k.ps;
+    // Software pipeline over this wavefront's steps: the records of a step are fetched while the
+    // step before it is computed, its samples (or Wx and bins) half a step ahead, the
+    // interpolation weights when the last taps of the step before are done. ALL loads are issued
+    // unconditionally (past the last step: the last step again, results unused): the compiler
+    // counts the loads in flight per path, and a path that skips some turns every wait into a
+    // full drain.
+    int4 sa, sb, rec[TILE_G];                 // next step: (kind, -, -, lgR | wtab, stride, L-1, base), rows
+    auto load_rec = [&](const Pos& q) {
+        const int g = q.st;
         sa = steps4[2 * g]; sb = steps4[2 * g + 1];
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) rec[r] = rows4[g * TILE_G + r];
     };
-    float2 xu[2][TILE_G];
-    int xr[2][TILE_G], xkc[2][TILE_G];
-    int xbaddr[2], xwoff[2], xmask[2];
-    auto load = [&](auto BB, const Ticket& k) {              // samples of the step whose records are in (sa, sb, rec)
+    float2 xu[2][TILE_G];                     // samples of the interpolated rows / Wx of the rows read back
+    int xr[2][TILE_G], xkc[2][TILE_G];        // row (sign bit: padding), centre bin
+    unsigned short xk[2][TILE_G];             // bins of the rows read back (as loaded: a conversion here would wait for the load)
+    w_t xc[2][CSTK == 0 ? 1 : TILE_G];        // per-row weights
+    int xkind[2], xbaddr[2], xwoff[2], xmask[2];
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    auto load = [&](auto BB, const Pos& q) {   // data of the step whose records are in (sa, sb, rec)
         constexpr int b = decltype(BB)::value;
-        const TileCtx t = ctx_of(k.tx, k.sg);
+        const int kind = __builtin_amdgcn_readfirstlane(sa.x);
+        xkind[b] = kind;
+        const int col0 = q.tx * TILE_COLS, col = col0 + c;
+        const int colc = col < (int)N ? col : (int)N - 1;         // loads stay in range
+        const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
         const int lgR = sa.w;
         xwoff[b] = sb.x; xmask[b] = (1 << lgR) - 1;
-        const int q0 = t.nabs >> lgR, qb = (t.nabs0 >> lgR) - (TILE_W / 2 - 1);
-        // the sample this lane holds (lanes past the widest window any lane needs repeat the last one)
+        const int q0 = nabs >> lgR, qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
+        // interpolated rows: the sample this lane holds (lanes past the widest window any lane
+        // needs repeat the last one); rows read back: the lane's own point
         const int wlast = (63 >> lgR) + TILE_W;
         const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb.z);
         xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
-        const float2* Ub = A.U + sb.w + (int64_t)t.sg * sb.y;
+        const float2* Ub = A.U + sb.w + (int64_t)q.sg * sb.y;
+        const float2* Wx = A.Wx + (int64_t)(A.sig0 + q.sg) * na * N;
+        const unsigned short* kidx = A.kidx + (int64_t)q.sg * na * N;
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) {
             const int4 d = rec[r];
+            const int row = d.x & 0xFFFF;
             xr[b][r] = d.x; xkc[b][r] = d.z;
-            xu[b][r] = Ub[(unsigned)d.y + uidx];
+            const unsigned o = (unsigned)row * nN + (unsigned)colc;
+            // one 8-byte load either way: a sample of u (interpolated) or Wx (read back)
+            const float2* src = kind ? Ub + ((unsigned)d.y + uidx) : Wx + o;
+            xu[b][r] = *src;
+            // (interpolated rows have no bin yet: a fixed, cached line instead of a scattered read)
+            xk[b][r] = kidx[kind ? (unsigned)colc : o];
+            if (CSTK != 0) xc[b][r] = cstu[row];
         }
     };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
+    ssq_f2 wt[TILE_W];                        // (phi_t, phi'_t / (R dt)) of the step in hand
+    auto load_wt = [&](auto BB, const Pos& q) {
+        constexpr int b = decltype(BB)::value;
+        const int col = q.tx * TILE_COLS + c;
+        const int nabs = A.n1 + (col < (int)N ? col : (int)N - 1);
+        const float4* wp = A.wtab + (int64_t)(xwoff[b] + (nabs & xmask[b])) * 4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = wp[t];
+            wt[2 * t].x = v.x; wt[2 * t].y = v.y; wt[2 * t + 1].x = v.z; wt[2 * t + 1].y = v.w;
+        }
+    };
 
-    Ticket kc_ = grab();                      // the step computed
-    if (kc_.p >= ptotal) return;
-    load_rec(kc_); load(B0{}, kc_);
-    Ticket kn = grab();                       // the step whose samples are loaded next
-    load_rec(kn);
-    // (phi_t, phi'_t / (R dt)) of the step in hand: fetched for the next step when the last taps of
-    // this one are done -- unconditionally (64 bytes per lane from an L1 / L2-resident table): a
-    // load under a condition would make the compiler drain all loads at the join
-    ssq_f2 wt[TILE_W];
-    auto load_wt = [&](auto BB, const Ticket& k) {
-        constexpr int b = decltype(BB)::value;
-        const TileCtx t = ctx_of(k.tx, k.sg);
-        const float4* wp = A.wtab + (int64_t)(xwoff[b] + (t.nabs & xmask[b])) * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = wp[q];
-            wt[2 * q].x = v.x; wt[2 * q].y = v.y; wt[2 * q + 1].x = v.z; wt[2 * q + 1].y = v.w;
+    Pos pc; pc.S = 0; pc.itl = 0; pc.st = 0;
+    pc.sg = (int)blockIdx.x / ntx; pc.tx = (int)blockIdx.x - pc.sg * ntx;
+    int w_itl = 0, w_tx = pc.tx, w_sg = pc.sg;                // next tile to write out
+    advance(pc, wv);                          // the step computed
+    auto write_outs_before = [&](int itl) {   // every finished tile before tile `itl`, in order
+        while (w_itl < itl) {
+            write_out(w_itl, w_tx, w_sg);
+            ++w_itl; w_tx += (int)gridDim.x;
+            while (w_tx >= ntx) { w_tx -= ntx; ++w_sg; }
         }
     };
-    load_wt(B0{}, kc_);
-    auto step = [&](auto BB, auto BN) {
-        constexpr int b = decltype(BB)::value;
-        const TileCtx tc = ctx_of(kc_.tx, kc_.sg);
-        const bool trk = kc_.p / nps == TRACE_TILE && tr;
-        const int trj = kc_.ps;
-        TILE_STAMP(trk, wv, trj, 0);
-        float2* Wx = A.Wx + tc.obase;
-        float2* dWx = STORE_D ? A.dWx + tc.obase : nullptr;
-        const int baddr = xbaddr[b];
-        int kout[TILE_G];
-        Ticket knn; knn.p = ptotal; knn.ps = 0; knn.tx = 0; knn.sg = 0;
+    Pos pl = pc;                              // a valid step for the loads past the end
+    auto clampp = [&](const Pos& q) { return q.S < total ? q : pl; };
+    if (pc.S < total) {
+        load_rec(pc); load(B0{}, pc); load_wt(B0{}, pc);
+        Pos pn = pc; advance(pn, NW);         // the step whose data are loaded next
+        load_rec(clampp(pn));
+        auto step = [&](auto BB, auto BN) {
+            constexpr int b = decltype(BB)::value;
+            const bool trk = tr && pc.itl == TRACE_TILE;
+            TILE_STAMP(trk, wv, pc.st, 0);
+            const int col0 = pc.tx * TILE_COLS, col = col0 + c;
+            const bool colok = col < (int)N;
+            const int colc = colok ? col : (int)N - 1;
+            const int nabs = A.n1 + colc;
+            int cell[TILE_G]; term_t vx[TILE_G], vy[TILE_G];
+            Pos pnn = pn;
+            if (__builtin_amdgcn_readfirstlane(xkind[b]) == 0) {
+                // rows read back: Wx and the bin are there
+                load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn)); load_wt(BN, clampp(pn));
 #pragma unroll
-        for (int r = 0; r < ((SSQ_TILE_EXP & 4) ? 0 : TILE_G); ++r) {
-            if (r == TILE_G / 2) {
-                // the next step: its samples now (its records came in during the first rows), then
-                // a ticket and the records of the one after
-                load(BN, kn);
-                knn = grab();
-                load_rec(knn);
-                TILE_STAMP(trk, wv, trj, 1);
-            }
-            // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
-            // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
-            ssq_f2 are2, aim2;
-            {
-                int fr[TILE_W], fi[TILE_W];
-                const int ur = __float_as_int(xu[b][r].x), ui = __float_as_int(xu[b][r].y);
-                SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
-                SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
-                SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
-                SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
-                SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
-                SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
-                SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
-                SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
-                SSQ_LDS_WAIT();
+                for (int r = 0; r < TILE_G; ++r) {
+                    const int kk = xk[b][r];
+                    const bool act = xr[b][r] >= 0 && colok && kk != TILE_NOBIN;
+                    cell[r] = act ? kk * TILE_COLS + c : scratch;
+                    const w_t cs = CSTK == 0 ? (w_t)A.cst0 : xc[b][CSTK == 0 ? 0 : r];
+                    vx[r] = TM::make(xu[b][r].x, cs); vy[r] = TM::make(xu[b][r].y, cs);
+                }
+            } else {
+                float2* Wx = A.Wx + (int64_t)(A.sig0 + pc.sg) * na * N;
+                float2* dWx = STORE_D ? A.dWx + (int64_t)(A.sig0 + pc.sg) * na * N : nullptr;
+                const int baddr = xbaddr[b];
 #pragma unroll
-                for (int t = 0; t < TILE_W; ++t) {
-                    ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
-                    if (t == 0) { SSQ_PK_MUL_LO(are2, wt[0], sv); SSQ_PK_MUL_HI(aim2, wt[0], sv); }
-                    else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
+                for (int r = 0; r < ((SSQ_TILE_EXP & 4) ? 0 : TILE_G); ++r) {
+                    if (r == TILE_G / 2) {
+                        // the next step: its data now (its records came in during the first rows),
+                        // then the records of the one after
+                        load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
+                        TILE_STAMP(trk, wv, pc.st, 1);
+                    }
+                    // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
+                    // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
+                    ssq_f2 are2, aim2;
+                    {
+                        int fr[TILE_W], fi[TILE_W];
+                        const int ur = __float_as_int(xu[b][r].x), ui = __float_as_int(xu[b][r].y);
+                        SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
+                        SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
+                        SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
+                        SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
+                        SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
+                        SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
+                        SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
+                        SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
+                        SSQ_LDS_WAIT();
+#pragma unroll
+                        for (int t = 0; t < TILE_W; ++t) {
+                            ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
+                            if (t == 0) { SSQ_PK_MUL_LO(are2, wt[0], sv); SSQ_PK_MUL_HI(aim2, wt[0], sv); }
+                            else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
+                        }
+                    }
+                    if (r == TILE_G - 1) load_wt(BN, clampp(pn));     // (the taps of this step are done)
+                    const float are = are2.x, aim = aim2.x;
+                    float dre = are2.y, dim = aim2.y;
+                    // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
+                    const float theta = (float)xkc[b][r] * A.theta_scale;
+                    dre = __builtin_fmaf(-theta, aim, dre);
+                    dim = __builtin_fmaf(theta, are, dim);
+                    // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
+                    // (M <= 2^24, checked by the host), v_sin_f32 / v_cos_f32 take revolutions (measured on
+                    // the M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
+                    const float rev = (float)(__umul24((unsigned)xkc[b][r], (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
+                    const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+                    const float2 Wv = cmulf(tw, make_float2(are, aim));
+                    const float2 Dv = cmulf(tw, make_float2(dre, dim));
+                    // (rows that only pad a step repeat the previous row -- same address, same value --
+                    // and lanes past the last column repeat its point; neither contributes below)
+                    const int row = xr[b][r] & 0xFFFF;
+                    const bool pad = xr[b][r] < 0;
+                    const unsigned o = (unsigned)row * nN + (unsigned)colc;
+                    Wx[o] = Wv;
+                    if (STORE_D) dWx[o] = Dv;
+                    // phase transform and bin: as emit_point<LEAN> of the block kernels
+                    const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
+                    const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
+                    const bool above = m2 > m2hi, below = m2 < m2lo;
+                    const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+                    bool ok;
+                    const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
+                    const int kf = (kb ^ fx) + fa;
+                    const bool live = colok && !pad;
+                    int kout = (above && live) ? kf : -1;
+                    // undecided by the float32 screens (~0.05 % of the points, one row in 30): the exact
+                    // double path
+                    const bool pend = live && !(below | (above & ok));
+                    if (__builtin_amdgcn_ballot_w64(pend)) {
+                        if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
+                    }
+                    // (a point without contribution adds to the lane's scratch cell)
+                    cell[r] = kout >= 0 ? kout * TILE_COLS + c : scratch;
+                    const w_t cs = CSTK == 0 ? (w_t)A.cst0 : xc[b][CSTK == 0 ? 0 : r];
+                    vx[r] = TM::make(Wv.x, cs); vy[r] = TM::make(Wv.y, cs);
+                }
+                if (SSQ_TILE_EXP & 4) {
+                    load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn)); load_wt(BN, clampp(pn));
+#pragma unroll
+                    for (int r = 0; r < TILE_G; ++r) { cell[r] = scratch; vx[r] = term_t(0); vy[r] = term_t(0); }
                 }
             }
-            if (r == TILE_G - 1) load_wt(BN, kn);
-            const float are = are2.x, aim = aim2.x;
-            float dre = are2.y, dim = aim2.y;
-            // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
-            const float theta = (float)xkc[b][r] * A.theta_scale;
-            dre = __builtin_fmaf(-theta, aim, dre);
-            dim = __builtin_fmaf(theta, are, dim);
-            // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
-            // (M <= 2^24, checked by the host), v_sin_f32 / v_cos_f32 take revolutions (measured on
-            // the M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
-            const float rev = (float)(__umul24((unsigned)xkc[b][r], (unsigned)tc.nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
-            const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-            const float2 Wv = cmulf(tw, make_float2(are, aim));
-            const float2 Dv = cmulf(tw, make_float2(dre, dim));
-            // (rows that only pad a step repeat the previous row -- same address, same value --
-            // and lanes past the last column repeat its point; neither contributes below)
-            const int row = xr[b][r] & 0xFFFF;
-            const bool pad = xr[b][r] < 0;
-            const unsigned o = (unsigned)row * nN + (unsigned)tc.colc;
-            Wx[o] = Wv;
-            if (STORE_D) dWx[o] = Dv;
-            // phase transform and bin: as emit_point<LEAN> of the block kernels
-            const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
-            const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
-            const bool above = m2 > m2hi, below = m2 < m2lo;
-            const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
-            bool ok;
-            const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
-            const int kf = (kb ^ fx) + fa;
-            const bool live = tc.colok && !pad;
-            kout[r] = (above && live) ? kf : TILE_NOBIN;
-            // undecided by the float32 screens (~0.05 % of the points, one row in 30): the exact
-            // double path
-            const bool pend = live && !(below | (above & ok));
-            if (__builtin_amdgcn_ballot_w64(pend)) {
-                if (pend) {
-                    const int ke = exact_bin(Wv, Dv, sp, omax, A.gamma);
-                    kout[r] = ke >= 0 ? ke : TILE_NOBIN;
-                }
-            }
+            TILE_STAMP(trk, wv, pc.st, 2);
+            // the step's update, in ticket order (tiles finished before it are written out first)
+            write_outs_before(pc.itl);
+            const int ticket = pc.S + pc.itl;
+            if (!(SSQ_TILE_EXP & 2)) while (lds_load_acquire(turn) != ticket) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_wave_barrier();
+            if (!(SSQ_TILE_EXP & 1)) update4<TM>(T, cell, vx, vy);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (c == 0) lds_store_release(turn, ticket + 1);
+            TILE_STAMP(trk, wv, pc.st, 3);
+            pl = pc; pc = pn; pn = pnn;
+        };
+        for (;;) {
+            if (pc.S >= total) break;
+            step(B0{}, B1{});
+            if (pc.S >= total) break;
+            step(B1{}, B0{});
         }
-        if (SSQ_TILE_EXP & 4) {
-            load(BN, kn); knn = grab(); load_rec(knn); load_wt(BN, kn);
-#pragma unroll
-            for (int r = 0; r < TILE_G; ++r) kout[r] = TILE_NOBIN;
-        }
-        // hand the step to the updater: bins into the ring slot (free once the updater has
-        // consumed step p - TILE_RING), then the flag behind a release (Wx and bins in memory)
-        const int pc = kc_.p;
-        const int slot = pc & (TILE_RING - 1);
-        TILE_STAMP(trk, wv, trj, 2);
-        for (;;) {                                            // (the slowest of the updaters counts)
-            if (lds_load_relaxed(L.upd_done) > pc - TILE_RING) break;
-            // (a long sleep: the ring is two tiles deep, and a dozen wavefronts polling LDS in a
-            // tight loop take the LDS and the issue slots from the updaters they are waiting for)
-            __builtin_amdgcn_s_sleep(SSQ_TILE_BPSLEEP);
-        }
-        unsigned short* rb = ring + (size_t)slot * (TILE_G * TILE_COLS) + c;
-#pragma unroll
-        for (int r = 0; r < TILE_G; ++r) rb[r * TILE_COLS] = (unsigned short)kout[r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (c == 0)
-            __scoped_atomic_fetch_add(&L.gcnt[(pc >> 2) & (TILE_RING / 4 - 1)], 1, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
-        TILE_STAMP(trk, wv, trj, 3);
-        kc_ = kn; kn = knn;
-    };
-    for (;;) {
-        if (kc_.p >= ptotal) break;
-        step(B0{}, B1{});
-        if (kc_.p >= ptotal) break;
-        step(B1{}, B0{});
     }
+    write_outs_before(ntl);
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -629,7 +476,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         ncu = pr.multiProcessorCount;
         if (const char* e = getenv("SSQ_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
     }
-    SSQ_REQUIRE(tile_lds_bytes(na, nsegs) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
+    SSQ_REQUIRE(tile_lds_bytes(na) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
                 "na = %lld: the Tx tile exceeds the LDS", (long long)na);
     // the modulation phase kc * n mod M is formed with a 24-bit multiply and carried in a float
     SSQ_REQUIRE(M <= ((int64_t)1 << 24), "the tile path needs a padded length <= 2^24");
@@ -642,59 +489,19 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     };
     int rc;
     static_assert(sizeof(TileSeg) == 32 && sizeof(TileRow) == 16 && sizeof(TileIRow) == 32, "table layout");
-    {   // one record per step; `first` of the device copy = the step's index among the producer
-        // steps of a tile (-1: rows read back)
+    {   // one record per step (a wavefront's consecutive steps are usually of different segments)
         std::vector<TileSeg> hs((size_t)nsteps);
-        std::vector<int32_t> hp;
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
-        const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
         int64_t covered = 0;
         for (int i = 0; i < nsegs; ++i) {
             SSQ_REQUIRE(sg[i].first == covered && sg[i].nsteps >= 1 && sg[i].first + sg[i].nsteps <= nsteps,
                         "tile segment %d does not continue the step list", i);
             SSQ_REQUIRE(sg[i].kind == 0 || sg[i].kind == 1, "tile segment %d: bad kind", i);
-            for (int t = 0; t < sg[i].nsteps; ++t) {
-                const size_t st = (size_t)sg[i].first + t;
-                hs[st] = sg[i];
-                hs[st].first = sg[i].kind == 1 ? (int32_t)hp.size() : -1;
-                if (sg[i].kind == 1) hp.push_back((int32_t)st);
-                // the kernel derives the rows of a step from the first one
-                const int32_t r0 = rw[st * TILE_G].row;
-                SSQ_REQUIRE(r0 >= 0 && r0 < na, "tile step %zu: bad first row", st);
-                for (int r = 1; r < TILE_G; ++r) {
-                    const int32_t rr = rw[st * TILE_G + r].row;
-                    SSQ_REQUIRE(rr < 0 ? true : (rr == r0 + r && rw[st * TILE_G + r - 1].row >= 0 && rr < na),
-                                "tile step %zu: rows are not consecutive", st);
-                }
-            }
+            for (int t = 0; t < sg[i].nsteps; ++t) hs[(size_t)sg[i].first + t] = sg[i];
             covered += sg[i].nsteps;
         }
         SSQ_REQUIRE(covered == nsteps, "tile segments cover %lld of %d steps", (long long)covered, nsteps);
-        SSQ_REQUIRE(!hp.empty(), "tile tables without interpolated rows");
-        npsteps = (int)hp.size();
         if ((rc = up((void**)&steps, hs.data(), sizeof(TileSeg) * nsteps))) return rc;
-        // the producers' own dense copies of the records (no indirection in their pipeline)
-        std::vector<TileSeg> hps(hp.size());
-        std::vector<TileRow> hpr(hp.size() * TILE_G);
-        for (size_t i = 0; i < hp.size(); ++i) {
-            hps[i] = hs[(size_t)hp[i]];
-            for (int r = 0; r < TILE_G; ++r) hpr[i * TILE_G + r] = rw[(size_t)hp[i] * TILE_G + r];
-        }
-        // the updaters' view of the row list: per segment
-        std::vector<int32_t> hu((size_t)nsegs * 4);
-        for (int i = 0, pbefore = 0; i < nsegs; ++i) {
-            int nrows = 0;
-            for (int t = 0; t < sg[i].nsteps; ++t)
-                for (int r = 0; r < TILE_G; ++r) nrows += rw[((size_t)sg[i].first + t) * TILE_G + r].row >= 0 ? 1 : 0;
-            // (only the last step of a segment may be short: the kernel derives a step's rows from the segment)
-            SSQ_REQUIRE(nrows > (sg[i].nsteps - 1) * TILE_G, "tile segment %d: a short step inside the segment", i);
-            hu[4 * i] = rw[(size_t)sg[i].first * TILE_G].row; hu[4 * i + 1] = nrows;
-            hu[4 * i + 2] = sg[i].kind; hu[4 * i + 3] = pbefore;
-            if (sg[i].kind == 1) pbefore += sg[i].nsteps;
-        }
-        if ((rc = up((void**)&usegs, hu.data(), hu.size() * 4))) return rc;
-        if ((rc = up((void**)&psegs, hps.data(), sizeof(TileSeg) * hps.size()))) return rc;
-        if ((rc = up((void**)&prows, hpr.data(), sizeof(TileRow) * hpr.size()))) return rc;
     }
     if ((rc = up((void**)&rows, d.rows, sizeof(TileRow) * TILE_G * nsteps))) return rc;
     if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
@@ -718,12 +525,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     if ((rc = up((void**)&irows, hi.data(), sizeof(TileIRow) * n_irows))) return rc;
     SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * group * u_total)); bytes += 8 * group * u_total;
     SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * group * u_total));
-    {
-        const size_t rb = (size_t)ncu * TILE_RING * TILE_G * TILE_COLS * 2;
-        SSQ_CHECK_HIP(hipMalloc(&ring, rb)); bytes += (int64_t)rb;
-        SSQ_CHECK_HIP(hipMalloc((void**)&counters, 64));
-        SSQ_CHECK_HIP(hipMemset(counters, 0, 64));
-    }
+    SSQ_CHECK_HIP(hipMalloc((void**)&counters, 64));
+    SSQ_CHECK_HIP(hipMemset(counters, 0, 64));
     for (size_t c = 0; c < cls.size(); ++c) {
         FftPlan fp;
         rc = fp.create(1, SSQ_F32, (size_t)cls[c].L, (size_t)(group * cls[c].nrows), 1.0);
@@ -747,9 +550,9 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, psegs, prows, usegs, irows, wtab, tbank, U, ring, counters};
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    steps = nullptr; rows = nullptr; psegs = nullptr; prows = nullptr; usegs = nullptr; irows = nullptr; wtab = tbank = U = ring = nullptr;
+    steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = nullptr;
     counters = nullptr;
 }
 
@@ -766,16 +569,16 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
     return 0;
 }
 
-// wavefronts per workgroup (one of them the updater): 16 by default = 4 per SIMD (128 VGPRs);
-// SSQ_TILE_NW = 8 | 12 | 16 selects another build of the kernel (tuning aid)
+// wavefronts per workgroup: 16 by default = 4 per SIMD (128 VGPRs); SSQ_TILE_NW = 8 | 12 | 16
+// selects another build of the kernel (tuning aid)
 template <int GRID, bool STORE_D, int NW, int CSTK>
 static int launch_tile_c(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     auto kern = tile_kernel<GRID, STORE_D, NW, CSTK>;
-    const size_t lds = tile_lds_bytes(P.na, P.nsegs);
+    const size_t lds = tile_lds_bytes(P.na);
     static bool attr_set = false;            // per instantiation
     if (!attr_set) {
         SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds > 64 * 1024 ? 160 * 1024 : 64 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     // persistent workgroups, one per CU (the tile fills the LDS)
@@ -788,8 +591,9 @@ static int launch_tile_c(const TilePlan& P, const TileArgs& A, const SsqParams& 
 }
 template <int GRID, bool STORE_D, int NW>
 static int launch_tile_nw(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
-    if (A.cstk == 0) return launch_tile_c<GRID, STORE_D, NW, 0>(P, A, sp, nsig, stream);
-    if (A.cstk == 1) return launch_tile_c<GRID, STORE_D, NW, 1>(P, A, sp, nsig, stream);
+    const int cstk = sp.cst_f64 ? 2 : (sp.cst_uniform ? 0 : 1);
+    if (cstk == 0) return launch_tile_c<GRID, STORE_D, NW, 0>(P, A, sp, nsig, stream);
+    if (cstk == 1) return launch_tile_c<GRID, STORE_D, NW, 1>(P, A, sp, nsig, stream);
     return launch_tile_c<GRID, STORE_D, NW, 2>(P, A, sp, nsig, stream);
 }
 template <int GRID, bool STORE_D>
@@ -803,14 +607,11 @@ static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
     TileArgs A;
-    A.steps = steps; A.rows = rows; A.psegs = psegs; A.prows = prows;
-    A.usegs = (const int4*)usegs; A.nusegs = nsegs;
+    A.steps = steps; A.rows = rows;
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = cst;
     A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
-    A.ring = (unsigned short*)ring;
-    A.N = N; A.na = na; A.nsteps = nsteps; A.npsteps = npsteps; A.n1 = (int)n1; A.mmask = (int)(M - 1);
+    A.N = N; A.na = na; A.nsteps = nsteps; A.n1 = (int)n1; A.mmask = (int)(M - 1);
     A.sig0 = sig; A.nsig = nsig; A.inv_m = 1.0f / (float)M;
-    A.cstk = sp.cst_f64 ? 2 : (sp.cst_uniform ? 0 : 1);
     A.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); A.cst0 = cst0;
     A.counters = counters;
     A.gamma = sp.gamma;

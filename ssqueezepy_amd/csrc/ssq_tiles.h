@@ -38,16 +38,11 @@ struct TilePlan {
     double dt = 1.0;
     int nsegs = 0, nsteps = 0, n_irows = 0;
     int64_t u_total = 0, lmax = 0;
-    int npsteps = 0;                        // steps of interpolated rows (the producers' work list)
     int ncu = 0;                            // persistent workgroups of the tile kernel (one per CU)
-    TileSeg* steps = nullptr;               // the segment record of every step (`first`: index among
-                                            // the producer steps, -1 for rows read back)
-    TileSeg* psegs = nullptr; TileRow* prows = nullptr;   // records of the producer steps only (dense)
-    int32_t* usegs = nullptr;               // the updaters' segment table (4 ints per segment)
+    TileSeg* steps = nullptr;               // the segment record of every step
     TileRow* rows = nullptr; TileIRow* irows = nullptr;
     void* wtab = nullptr; void* tbank = nullptr;
     void* U = nullptr;                      // group x u_total complex64
-    void* ring = nullptr;                   // bins of the producer steps in flight, per workgroup
     unsigned long long* counters = nullptr; // [0]: tiles the kernel has finished since plan creation
     struct Cls { int64_t L, nrows, upre; };
     std::vector<Cls> cls;

@@ -202,26 +202,36 @@ inline void run_block(const std::function<void()>& body, dim3 bidx, dim3 bdim, d
         for (unsigned oi = 0; oi < nw; ++oi) {
             const unsigned wv = order[oi];
             const unsigned lo = wv * 64, hi = std::min(nt, lo + 64);
-            for (;;) {                       // sweep the wave until it reaches a block barrier
-                bool at_wave = false, other = false;
+            for (;;) {                       // sweep the wave until it reaches a block barrier or polls
+                // lanes that are not parked at a wavefront operation run to their next yield
                 for (unsigned i = lo; i < hi; ++i) {
                     // SSQ_EMU_LANES=reverse: the lanes of a wavefront in descending order (code
                     // that is correct only in lockstep, without a wave_barrier, shows up)
                     const unsigned t = lanes_reversed ? hi - 1 - (i - lo) : i;
                     Fiber& f = w.fibers[t];
-                    if (f.wait == FINISHED || f.wait == AT_BLOCK || f.wait == AT_SPIN) continue;
-                    resume(w, f);            // RUNNABLE or AT_WAVE: run to its next yield
+                    if (f.wait == RUNNABLE) resume(w, f);
                 }
+                unsigned n_wave = 0, n_spin = 0, n_block = 0;
                 for (unsigned t = lo; t < hi; ++t) {
                     const int s = w.fibers[t].wait;
-                    if (s == AT_WAVE) at_wave = true;
-                    else if (s == AT_BLOCK || s == AT_SPIN) other = true;
+                    n_wave += s == AT_WAVE; n_spin += s == AT_SPIN; n_block += s == AT_BLOCK;
                 }
-                if (!at_wave) break;
-                if (other) {
+                // Some lanes poll LDS for another wavefront's progress: the others must run first.
+                // (Lanes of one wavefront may leave a polling loop in different sweeps -- a lane that
+                // runs before the lane whose store it polls for -- so lanes already at the next
+                // wavefront operation stay parked there until the pollers have caught up.)
+                if (n_spin) break;
+                if (!n_wave) break;
+                if (n_block) {
                     fprintf(stderr, "emu: wavefront %u of workgroup (%u,%u,%u) diverged: some lanes "
                             "wait at a wavefront operation, others at __syncthreads\n", wv, bidx.x, bidx.y, bidx.z);
                     abort();
+                }
+                // every live lane is at the wavefront operation: complete it
+                for (unsigned i = lo; i < hi; ++i) {
+                    const unsigned t = lanes_reversed ? hi - 1 - (i - lo) : i;
+                    Fiber& f = w.fibers[t];
+                    if (f.wait == AT_WAVE) resume(w, f);
                 }
             }
             for (unsigned t = lo; t < hi; ++t) any_alive |= w.fibers[t].wait == AT_BLOCK || w.fibers[t].wait == AT_SPIN;
