@@ -27,6 +27,8 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 #define SSQ_PK_FMA_LO(acc, w, s) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(s))
 #define SSQ_PK_FMA_HI(acc, w, s) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(s))
 #define SSQ_BPERMUTE_OFF(d, addr, v, off) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(d) : "v"(addr), "v"(v), "n"(off))
+// bitfield insert: d = (m & a) | (~m & b) in one instruction (the compiler spells the select out as four)
+#define SSQ_BFI(d, m, a, b) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b))
 #define SSQ_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SSQ_LDS_WAITN(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
 #endif

@@ -56,7 +56,7 @@ constexpr int TILE_G = 4;         // rows per step
 constexpr int TILE_W = 8;         // taps
 constexpr int TILE_NOBIN = 0xFFFF;
 // tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
-// only), 2 = no ticket wait, 4 = no arithmetic
+// only), 4 = no arithmetic
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
@@ -111,6 +111,30 @@ __device__ __forceinline__ int lds_load_acquire(const int* p) {
 __device__ __forceinline__ void lds_store_release(int* p, int v) {
     __scoped_atomic_store_n(p, v, __ATOMIC_RELEASE, __MEMORY_SCOPE_WRKGRP);
 }
+// The ticket itself: LDS serves the operations of one wavefront in program order and those of the
+// CU's wavefronts from one queue, so a tile access issued before the ticket store is performed
+// before an access another wavefront issues after it has read the new ticket -- no wait for
+// completion is needed on either side (the compiler is kept from moving LDS accesses across).
+__device__ __forceinline__ int ticket_peek(const int* p) {
+    const int v = __scoped_atomic_load_n(p, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void ticket_wait(const int* turn, int ticket) {
+    // (only the wavefront next in line polls without sleeping)
+    for (;;) {
+        const int d = ticket - ticket_peek(turn);
+        if (d == 0) break;
+        // (s_sleep 0 is the shortest pause there is; under the CPU emulation it is where the
+        // other wavefronts get to run)
+        if (d > 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(0);
+    }
+}
+__device__ __forceinline__ void ticket_pass(int* turn, int next, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __scoped_atomic_store_n(turn, next, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
+    asm volatile("" ::: "memory");
+}
 
 // bin of a point the float32 screens could not decide (flipped as Tx wants it), or -1 when it
 // does not contribute: the exact double sequence of the CPU path (~0.05 % of the points). Inline:
@@ -148,20 +172,51 @@ template <> struct TileTerm<true> {
 // a step that hit the same cell are chained in registers: the cells are read together, a row
 // that hits the cell of an earlier row of the step starts from that row's result, the cells are
 // written back in row order. `cell` of a point without contribution is the lane's scratch cell.
+// Everything that does not depend on the tile is prepared BEFORE the step's turn (the ticket
+// section is the serial part of a tile): the cells' addresses, the terms, and the "same cell"
+// tests as bit masks, so that inside the turn a select is one v_bfi_b32 per word.
+struct Update4Prep {
+    int off[TILE_G];                   // byte offset of the cell in the tile
+    int same[TILE_G][TILE_G];          // [r][q], q < r: all ones if row q hits the cell of row r
+};
+__device__ __forceinline__ void update4_prepare(const int (&cell)[TILE_G], Update4Prep& u) {
+#pragma unroll
+    for (int r = 0; r < TILE_G; ++r) {
+        u.off[r] = cell[r] * 8;
+        SSQ_OPAQUE_V(u.off[r]);        // (materialised here, not behind the ticket)
+#pragma unroll
+        for (int q = 0; q < r; ++q) { u.same[r][q] = cell[q] == cell[r] ? -1 : 0; SSQ_OPAQUE_V(u.same[r][q]); }
+    }
+}
+__device__ __forceinline__ float bit_select(int m, float a, float b) {      // m ? a : b, per bit
+    int d;
+    SSQ_BFI(d, m, __float_as_int(a), __float_as_int(b));
+    return __int_as_float(d);
+}
 template <typename TM>
-__device__ __forceinline__ void update4(float2* T, const int (&cell)[TILE_G], const typename TM::type (&vx)[TILE_G],
-                                        const typename TM::type (&vy)[TILE_G]) {
+__device__ __forceinline__ void update4_apply(unsigned char* tile, const Update4Prep& u, const typename TM::type (&vx)[TILE_G],
+                                              const typename TM::type (&vy)[TILE_G]) {
     float2 t[TILE_G];
 #pragma unroll
-    for (int r = 0; r < TILE_G; ++r) t[r] = T[cell[r]];
+    for (int r = 0; r < TILE_G; ++r) t[r] = *reinterpret_cast<float2*>(tile + u.off[r]);
 #pragma unroll
     for (int r = 0; r < TILE_G; ++r) {
 #pragma unroll
-        for (int q = 0; q < r; ++q) if (cell[q] == cell[r]) t[r] = t[q];
+        for (int q = 0; q < r; ++q) {
+            t[r].x = bit_select(u.same[r][q], t[q].x, t[r].x);
+            t[r].y = bit_select(u.same[r][q], t[q].y, t[r].y);
+        }
         t[r].x = TM::fold(t[r].x, vx[r]); t[r].y = TM::fold(t[r].y, vy[r]);
     }
 #pragma unroll
-    for (int r = 0; r < TILE_G; ++r) T[cell[r]] = t[r];
+    for (int r = 0; r < TILE_G; ++r) *reinterpret_cast<float2*>(tile + u.off[r]) = t[r];
+}
+// (pins a term in a register before the ticket)
+__device__ __forceinline__ void keep_term(float& x) { SSQ_OPAQUE_V(x); }
+__device__ __forceinline__ void keep_term(double& x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    SSQ_OPAQUE_V(lo); SSQ_OPAQUE_V(hi);
+    x = __hiloint2double(hi, lo);
 }
 
 __host__ __device__ inline size_t tile_lds_bytes(int64_t na) {
@@ -209,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // wavefront to finish opens the next tile's tickets
     auto write_out = [&](int itl, int tx, int sg) {
         const int boundary = (itl + 1) * nst + itl;           // the ticket after the tile's last step
-        while (lds_load_acquire(turn) != boundary) __builtin_amdgcn_s_sleep(1);
+        while (ticket_peek(turn) != boundary) __builtin_amdgcn_s_sleep(1);
         const unsigned col = (unsigned)(tx * TILE_COLS + c);
         const bool ok = col < nN;
         float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
@@ -442,14 +497,17 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             }
             TILE_STAMP(trk, wv, pc.st, 2);
             // the step's update, in ticket order (tiles finished before it are written out first)
+            Update4Prep up4;
+            update4_prepare(cell, up4);
+#pragma unroll
+            for (int r = 0; r < TILE_G; ++r) { keep_term(vx[r]); keep_term(vy[r]); }
             write_outs_before(pc.itl);
             const int ticket = pc.S + pc.itl;
-            if (!(SSQ_TILE_EXP & 2)) while (lds_load_acquire(turn) != ticket) __builtin_amdgcn_s_sleep(1);
+            ticket_wait(turn, ticket);
             __builtin_amdgcn_wave_barrier();
-            if (!(SSQ_TILE_EXP & 1)) update4<TM>(T, cell, vx, vy);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (!(SSQ_TILE_EXP & 1)) update4_apply<TM>(lds_raw, up4, vx, vy);
             __builtin_amdgcn_wave_barrier();
-            if (c == 0) lds_store_release(turn, ticket + 1);
+            ticket_pass(turn, ticket + 1, c);
             TILE_STAMP(trk, wv, pc.st, 3);
             pl = pc; pc = pn; pn = pnn;
         };
@@ -569,7 +627,8 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
     return 0;
 }
 
-// wavefronts per workgroup: 16 by default = 4 per SIMD (128 VGPRs); SSQ_TILE_NW = 8 | 12 | 16
+// wavefronts per workgroup: 12 by default = 3 per SIMD (168 VGPRs: the step pipeline needs ~160;
+// at 16 wavefronts / 128 registers it spills and measured slower); SSQ_TILE_NW = 8 | 12 | 16
 // selects another build of the kernel (tuning aid)
 template <int GRID, bool STORE_D, int NW, int CSTK>
 static int launch_tile_c(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
@@ -598,10 +657,10 @@ static int launch_tile_nw(const TilePlan& P, const TileArgs& A, const SsqParams&
 }
 template <int GRID, bool STORE_D>
 static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
-    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 16; return v == 8 || v == 12 ? v : 16; }();
+    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 12; return v == 8 || v == 16 ? v : 12; }();
     if (nw == 8) return launch_tile_nw<GRID, STORE_D, 8>(P, A, sp, nsig, stream);
-    if (nw == 12) return launch_tile_nw<GRID, STORE_D, 12>(P, A, sp, nsig, stream);
-    return launch_tile_nw<GRID, STORE_D, 16>(P, A, sp, nsig, stream);
+    if (nw == 16) return launch_tile_nw<GRID, STORE_D, 16>(P, A, sp, nsig, stream);
+    return launch_tile_nw<GRID, STORE_D, 12>(P, A, sp, nsig, stream);
 }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
