@@ -120,16 +120,6 @@ __device__ __forceinline__ int ticket_peek(const int* p) {
     asm volatile("" ::: "memory");
     return v;
 }
-__device__ __forceinline__ void ticket_wait(const int* turn, int ticket) {
-    // (only the wavefront next in line polls without sleeping)
-    for (;;) {
-        const int d = ticket - ticket_peek(turn);
-        if (d == 0) break;
-        // (s_sleep 0 is the shortest pause there is; under the CPU emulation it is where the
-        // other wavefronts get to run)
-        if (d > 1) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(0);
-    }
-}
 __device__ __forceinline__ void ticket_pass(int* turn, int next, int lane) {
     asm volatile("" ::: "memory");
     if (lane == 0) __scoped_atomic_store_n(turn, next, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
@@ -193,12 +183,39 @@ __device__ __forceinline__ float bit_select(int m, float a, float b) {      // m
     SSQ_BFI(d, m, __float_as_int(a), __float_as_int(b));
     return __int_as_float(d);
 }
-template <typename TM>
-__device__ __forceinline__ void update4_apply(unsigned char* tile, const Update4Prep& u, const typename TM::type (&vx)[TILE_G],
-                                              const typename TM::type (&vy)[TILE_G]) {
-    float2 t[TILE_G];
+// The wait for the step's turn and the read of its cells in ONE LDS round trip: the wavefront
+// next in line issues the ticket read and, right behind it, the reads of its four cells; LDS
+// serves them in that order, so when the ticket read shows the step's turn the cell reads were
+// served after the predecessor's writes (otherwise the batch is thrown away and issued again).
+// Wavefronts further from their turn only look at the ticket, with a pause in between.
+__device__ __forceinline__ void ticket_wait_read4(const int* turn, int ticket, unsigned char* tile,
+                                                  const Update4Prep& u, float2 (&t)[TILE_G]) {
+    for (;;) {
+        const int d = ticket - ticket_peek(turn);
+        if (d <= 1) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    for (;;) {
+        const int v = __scoped_atomic_load_n(turn, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
+        asm volatile("" ::: "memory");
 #pragma unroll
-    for (int r = 0; r < TILE_G; ++r) t[r] = *reinterpret_cast<float2*>(tile + u.off[r]);
+        for (int r = 0; r < TILE_G; ++r) {
+            // (a relaxed atomic read: a plain one could be hoisted out of the loop, a volatile one
+            // loses the LDS address space)
+            const unsigned long long bits = __scoped_atomic_load_n(reinterpret_cast<unsigned long long*>(tile + u.off[r]),
+                                                                   __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
+            t[r].x = __int_as_float((int)(unsigned)bits); t[r].y = __int_as_float((int)(unsigned)(bits >> 32));
+        }
+        asm volatile("" ::: "memory");
+        if (v == ticket) break;
+        // (s_sleep 0 is the shortest pause there is; under the CPU emulation it is where the
+        // other wavefronts get to run)
+        __builtin_amdgcn_s_sleep(0);
+    }
+}
+template <typename TM>
+__device__ __forceinline__ void update4_finish(unsigned char* tile, const Update4Prep& u, float2 (&t)[TILE_G],
+                                               const typename TM::type (&vx)[TILE_G], const typename TM::type (&vy)[TILE_G]) {
 #pragma unroll
     for (int r = 0; r < TILE_G; ++r) {
 #pragma unroll
@@ -503,9 +520,10 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             for (int r = 0; r < TILE_G; ++r) { keep_term(vx[r]); keep_term(vy[r]); }
             write_outs_before(pc.itl);
             const int ticket = pc.S + pc.itl;
-            ticket_wait(turn, ticket);
+            float2 tcell[TILE_G];
+            ticket_wait_read4(turn, ticket, lds_raw, up4, tcell);
             __builtin_amdgcn_wave_barrier();
-            if (!(SSQ_TILE_EXP & 1)) update4_apply<TM>(lds_raw, up4, vx, vy);
+            if (!(SSQ_TILE_EXP & 1)) update4_finish<TM>(lds_raw, up4, tcell, vx, vy);
             __builtin_amdgcn_wave_barrier();
             ticket_pass(turn, ticket + 1, c);
             TILE_STAMP(trk, wv, pc.st, 3);
