@@ -56,7 +56,7 @@ constexpr int TILE_G = 4;         // rows per step
 constexpr int TILE_W = 8;         // taps
 constexpr int TILE_NOBIN = 0xFFFF;
 // tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
-// only), 4 = no arithmetic
+// only), 4 = no arithmetic, 8 = no priorities
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
@@ -119,6 +119,18 @@ __device__ __forceinline__ int ticket_peek(const int* p) {
     const int v = __scoped_atomic_load_n(p, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP);
     asm volatile("" ::: "memory");
     return v;
+}
+// Earliest deadline first: the wavefronts of a SIMD compete for its issue slots (the oldest wins by
+// default, so the youngest would always be late for its turn and everybody would wait for it); a
+// wavefront raises its priority as its turn comes closer.
+__device__ __forceinline__ void ticket_priority(const int* turn, int ticket) {
+#if !(SSQ_TILE_EXP & 8)
+    const int d = __builtin_amdgcn_readfirstlane(ticket - ticket_peek(turn));
+    if (d <= 3) __builtin_amdgcn_s_setprio(3);
+    else if (d <= 6) __builtin_amdgcn_s_setprio(2);
+    else if (d <= 9) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#endif
 }
 __device__ __forceinline__ void ticket_pass(int* turn, int next, int lane) {
     asm volatile("" ::: "memory");
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             constexpr int b = decltype(BB)::value;
             const bool trk = tr && pc.itl == TRACE_TILE;
             TILE_STAMP(trk, wv, pc.st, 0);
+            ticket_priority(turn, pc.S + pc.itl);
             const int col0 = pc.tx * TILE_COLS, col = col0 + c;
             const bool colok = col < (int)N;
             const int colc = colok ? col : (int)N - 1;
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             Pos pnn = pn;
             if (__builtin_amdgcn_readfirstlane(xkind[b]) == 0) {
                 // rows read back: Wx and the bin are there
-                load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn)); load_wt(BN, clampp(pn));
+                load(BN, clampp(pn)); load_wt(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
                     const int kk = xk[b][r];
@@ -437,10 +450,10 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
 #pragma unroll
                 for (int r = 0; r < ((SSQ_TILE_EXP & 4) ? 0 : TILE_G); ++r) {
                     if (r == TILE_G / 2) {
-                        // the next step: its data now (its records came in during the first rows),
-                        // then the records of the one after
-                        load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
+                        // the next step: its data now (its records came in at the end of the step before)
+                        load(BN, clampp(pn));
                         TILE_STAMP(trk, wv, pc.st, 1);
+                        ticket_priority(turn, pc.S + pc.itl);
                     }
                     // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
                     // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
@@ -464,7 +477,12 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                             else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
                         }
                     }
-                    if (r == TILE_G - 1) load_wt(BN, clampp(pn));     // (the taps of this step are done)
+                    if (r == TILE_G - 1) {
+                        // the taps of this step are done: the next step's weights, then the records of
+                        // the step after it. Loads return in issue order: what the next step needs first
+                        // (samples, weights) must not queue behind loads it needs later.
+                        load_wt(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
+                    }
                     const float are = are2.x, aim = aim2.x;
                     float dre = are2.y, dim = aim2.y;
                     // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
@@ -507,7 +525,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     vx[r] = TM::make(Wv.x, cs); vy[r] = TM::make(Wv.y, cs);
                 }
                 if (SSQ_TILE_EXP & 4) {
-                    load(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn)); load_wt(BN, clampp(pn));
+                    load(BN, clampp(pn)); load_wt(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
 #pragma unroll
                     for (int r = 0; r < TILE_G; ++r) { cell[r] = scratch; vx[r] = term_t(0); vy[r] = term_t(0); }
                 }
