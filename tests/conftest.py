@@ -89,3 +89,17 @@ def orc():
     from oracle import oracle
     oracle.lib()
     return oracle
+
+
+def report_measured(test, **values):
+    """Print the measured parity figures of a test and append them to
+    ``gpurun_out/parity_measured.jsonl`` (when that directory exists): the bounds asserted in the
+    tests are set from these (about 2x the measured value), see profiles/r3*_parity_measured.jsonl."""
+    import json
+    rec = {"test": test}
+    rec.update({k: (float(v) if not isinstance(v, (str, int)) else v) for k, v in values.items()})
+    print("measured:", json.dumps(rec))
+    d = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_measured.jsonl'), 'a') as fh:
+            fh.write(json.dumps(rec) + "\n")

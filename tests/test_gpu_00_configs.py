@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import compute_module, two_chirps
+from conftest import compute_module, two_chirps, report_measured
 from pipeline import oracle_ssq_stft, GRIDNAME
 
 pytestmark = pytest.mark.gpu
@@ -91,6 +91,7 @@ def test_config2_ssq_cwt_full_size_vs_oracle(S, orc):
     # bin boundary
     moved = np.abs(Tx - Tr).sum() / np.abs(Tr).sum()
     assert moved <= 2e-2, moved
+    report_measured('config2', eW=eW.max(), eD=eD.max(), colsum=np.abs(cs - cr).max() / np.abs(cr).max(), moved=moved)
 
     # the same rows through `cwt` (block kernels for every row)
     W2, _, dW2 = S.cwt(x, wav, scales=scales, derivative=True, astensor=False)
@@ -130,6 +131,7 @@ def test_config5_ssq_cwt_float64_long_vs_oracle(S, orc):
         worst[1] = max(worst[1], np.abs(_np(dWx[r0:r0 + slab]) - dWr).max() / dmax)
         del Psih, prod, Wr, dWr
     assert worst[0] <= 1e-12 and worst[1] <= 1e-12, worst
+    report_measured('config5', eW=worst[0], eD=worst[1])
 
     # reassignment: columns are independent -- three column slabs, bit for bit
     ssq_freqs, const, grid, p = _ssq_design(S, sc64, N, wav)
@@ -162,6 +164,13 @@ def test_config3_ssq_stft_full_size_vs_oracle(S, orc):
     assert np.array_equal(Tx, ref)
     cs, cr = Tx.sum(0), r['Tx'].sum(0)
     assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    report_measured('default_arguments', eW=np.abs(Wx - r['Wx']).max() / np.abs(r['Wx']).max(),
+                    eD=np.abs(dWx - r['dWx']).max() / np.abs(r['dWx']).max(),
+                    colsum=np.abs(cs - cr).max() / np.abs(cr).max(),
+                    moved=np.abs(Tx - r['Tx']).sum() / np.abs(r['Tx']).sum())
+    report_measured('config3', eS=np.abs(Sx - r['Sx']).max() / np.abs(r['Sx']).max(),
+                    eD=np.abs(dSx - r['dSx']).max() / np.abs(r['dSx']).max(),
+                    colsum=np.abs(cs - cr).max() / np.abs(cr).max())
     # batched == single, as the bench runs it
     xb = np.stack([x, two_chirps(N, seed=4)])
     Tb, Sb, *_ = S.ssq_stft(xb, n_fft=1024, hop_len=256, dtype='float32', astensor=False)
@@ -207,3 +216,7 @@ def test_default_arguments_full_size_vs_oracle(S, orc):
     assert np.array_equal(Tx, ref)
     cs, cr = Tx.sum(0), r['Tx'].sum(0)
     assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    report_measured('default_arguments', eW=np.abs(Wx - r['Wx']).max() / np.abs(r['Wx']).max(),
+                    eD=np.abs(dWx - r['dWx']).max() / np.abs(r['dWx']).max(),
+                    colsum=np.abs(cs - cr).max() / np.abs(cr).max(),
+                    moved=np.abs(Tx - r['Tx']).sum() / np.abs(r['Tx']).sum())
