@@ -164,10 +164,6 @@ def test_config3_ssq_stft_full_size_vs_oracle(S, orc):
     assert np.array_equal(Tx, ref)
     cs, cr = Tx.sum(0), r['Tx'].sum(0)
     assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
-    report_measured('default_arguments', eW=np.abs(Wx - r['Wx']).max() / np.abs(r['Wx']).max(),
-                    eD=np.abs(dWx - r['dWx']).max() / np.abs(r['dWx']).max(),
-                    colsum=np.abs(cs - cr).max() / np.abs(cr).max(),
-                    moved=np.abs(Tx - r['Tx']).sum() / np.abs(r['Tx']).sum())
     report_measured('config3', eS=np.abs(Sx - r['Sx']).max() / np.abs(r['Sx']).max(),
                     eD=np.abs(dSx - r['dSx']).max() / np.abs(r['dSx']).max(),
                     colsum=np.abs(cs - cr).max() / np.abs(cr).max())
