@@ -86,11 +86,13 @@ def test_config2_ssq_cwt_full_size_vs_oracle(S, orc):
     # the oracle end to end: sum_k Tx[k, j] does not depend on the bin a point lands in
     Tr = orc.ssqueeze(Wr, dWr, grid, p, const, gamma, True, typing=0, parallel=True)
     cs, cr = Tx.sum(0), Tr.sum(0)
-    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    # (bounds: a few times what the MI355X measures -- profiles/r3p_parity_measured.jsonl: column
+    # sums 2.1e-6, moved 3.7e-5, eW 6.0e-6, eD 5.3e-6)
+    assert np.abs(cs - cr).max() <= 1e-5 * np.abs(cr).max()
     # ... and the two maps agree except where a 1e-6 difference of Wx moves a point across a
     # bin boundary
     moved = np.abs(Tx - Tr).sum() / np.abs(Tr).sum()
-    assert moved <= 2e-2, moved
+    assert moved <= 2e-4, moved
     report_measured('config2', eW=eW.max(), eD=eD.max(), colsum=np.abs(cs - cr).max() / np.abs(cr).max(), moved=moved)
 
     # the same rows through `cwt` (block kernels for every row)
@@ -163,7 +165,7 @@ def test_config3_ssq_stft_full_size_vs_oracle(S, orc):
                        Sfs=r['Sfs'], typing=0)
     assert np.array_equal(Tx, ref)
     cs, cr = Tx.sum(0), r['Tx'].sum(0)
-    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    assert np.abs(cs - cr).max() <= 2e-6 * np.abs(cr).max()       # (measured 2.4e-7)
     report_measured('config3', eS=np.abs(Sx - r['Sx']).max() / np.abs(r['Sx']).max(),
                     eD=np.abs(dSx - r['dSx']).max() / np.abs(r['dSx']).max(),
                     colsum=np.abs(cs - cr).max() / np.abs(cr).max())
@@ -211,7 +213,8 @@ def test_default_arguments_full_size_vs_oracle(S, orc):
                        typing=0, parallel=True)
     assert np.array_equal(Tx, ref)
     cs, cr = Tx.sum(0), r['Tx'].sum(0)
-    assert np.abs(cs - cr).max() <= 1e-4 * np.abs(cr).max()
+    assert np.abs(cs - cr).max() <= 1e-5 * np.abs(cr).max()       # (measured 1.9e-6)
+    assert np.abs(Tx - r['Tx']).sum() <= 2e-4 * np.abs(r['Tx']).sum()   # (measured 4.6e-5)
     report_measured('default_arguments', eW=np.abs(Wx - r['Wx']).max() / np.abs(r['Wx']).max(),
                     eD=np.abs(dWx - r['dWx']).max() / np.abs(r['dWx']).max(),
                     colsum=np.abs(cs - cr).max() / np.abs(cr).max(),
