@@ -67,81 +67,6 @@ void set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Small transforms are launch-bound (config 1: 12 launches for 0.1 ms of work). With
-// SSQ_GRAPHS=1 a plan records the launches of an execute in a hipGraph the second time it sees
-// the same set of pointers / sizes / parameters (torch's caching allocator hands the same
-// buffers to a caller that repeats a call) and replays it from then on; anything the capture
-// cannot hold switches the plan back to eager launches for good. OFF by default: measured on
-// the MI355X / ROCm 7.2 (back-to-back calls, `tools/run_configs.py`), replay is slower than the
-// eager launches it replaces -- config 1: 0.298 ms replayed vs 0.126 ms eager, config 3 single:
-// 0.130 vs 0.098 ms (a dozen dependent graph nodes cost more than a dozen asynchronous launches
-// that overlap the previous call's kernels).
-struct GraphCache {
-    struct Entry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; int seen = 0; };
-    std::vector<Entry> entries;
-    bool disabled = false;
-    // launches are recorded on a stream of the plan's own (the caller's may be the legacy
-    // default stream, which cannot capture) and the graph is then launched on the caller's
-    hipStream_t cap = nullptr;
-    static bool enabled_by_env() {
-        static const bool on = [] { const char* e = getenv("SSQ_GRAPHS"); return e && atoi(e) != 0; }();
-        return on;
-    }
-    // returns 1 if the graph was replayed, 0 if the caller must launch eagerly (and, when
-    // *capture is set, inside a capture that `finish` closes), < 0 on error
-    int begin(const std::vector<uint64_t>& key, hipStream_t stream, bool* capture, size_t* slot) {
-        *capture = false;
-        if (disabled || !enabled_by_env()) return 0;
-        for (size_t i = 0; i < entries.size(); ++i)
-            if (entries[i].key == key) {
-                Entry& e = entries[i];
-                if (e.exec) return hipGraphLaunch(e.exec, stream) == hipSuccess ? 1 : (disabled = true, 0);
-                if (++e.seen < 2) return 0;
-                if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) { cap = nullptr; disabled = true; return 0; }
-                if (hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); disabled = true; return 0; }
-                *capture = true; *slot = i;
-                return 0;
-            }
-        if (entries.size() >= 8) {                     // bounded: forget the oldest
-            if (entries[0].exec) (void)hipGraphExecDestroy(entries[0].exec);
-            if (entries[0].graph) (void)hipGraphDestroy(entries[0].graph);
-            entries.erase(entries.begin());
-        }
-        Entry e; e.key = key; e.seen = 1;
-        entries.push_back(e);
-        return 0;
-    }
-    // closes the capture opened by `begin`, instantiates and launches the graph; `rc` = status
-    // of the launches recorded. Returns rc, or 0 after falling back to one eager run by the caller
-    // (signalled through *rerun)
-    int finish(size_t slot, hipStream_t stream, int rc, bool* rerun) {
-        *rerun = false;
-        hipGraph_t g = nullptr;
-        hipError_t e = hipStreamEndCapture(cap, &g);
-        if (rc || e != hipSuccess || !g) {
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            disabled = true; *rerun = true;          // nothing ran: launch eagerly this once
-            return 0;
-        }
-        hipGraphExec_t x = nullptr;
-        if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || hipGraphLaunch(x, stream) != hipSuccess) {
-            if (x) (void)hipGraphExecDestroy(x);
-            (void)hipGraphDestroy(g); (void)hipGetLastError();
-            disabled = true; *rerun = true;
-            return 0;
-        }
-        entries[slot].exec = x; entries[slot].graph = g;
-        return 0;
-    }
-    void destroy() {
-        for (auto& e : entries) { if (e.exec) (void)hipGraphExecDestroy(e.exec); if (e.graph) (void)hipGraphDestroy(e.graph); }
-        entries.clear();
-        if (cap) (void)hipStreamDestroy(cap);
-        cap = nullptr;
-    }
-};
-
 // A cached plan owns device workspaces that every execute reuses. Executes are asynchronous
 // and torch's side streams do not synchronise with each other, so two executes of one plan on
 // different streams (or from two host threads) would overwrite each other's workspace. `enter`

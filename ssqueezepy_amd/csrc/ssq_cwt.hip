@@ -1,21 +1,28 @@
-// ssq_cwt.hip -- CWT / synchrosqueezed-CWT plan (C ABI: ssq_cwt_*).
+// ssq_cwt.hip -- CWT / synchrosqueezed-CWT plan (C ABI: ssq_cwt_*): creation, the tables of the
+// fast paths, and the orchestration of one execute.
 //
-// Data flow per signal (reference: ssqueezepy/_cwt.py:255-306, _ssq_cwt.py:250-289):
-//   x (N) --pad_kernel--> xp (M) --rocFFT R2C--> xh (M/2+1)
-//   rows in chunks:  xh, banded bank --bank_multiply_kernel--> P = psih*xh, dP = P*(1j*xi/dt)
-//                    --rocFFT C2C inverse, batched, scaled 1/M, in place-->  padded Wx, dWx
-//                    --cwt_epilogue_kernel--> Wx[:, n1:n1+N] (+ dWx / w / bin map)
-//   bin map or w --accumulate_tile_kernel--> Tx
-// Only the returned arrays (Wx, Tx [, dWx, w]) are written at full size; the padded
-// intermediates live in a plan-owned workspace that is reused chunk after chunk.
+// Per launch group of signals (reference: ssqueezepy/_cwt.py:255-306, _ssq_cwt.py:250-289):
+//   x (N) --pad_kernel--> xp (M) --rocFFT R2C--> xh (M/2+1)                       (whole batch)
+//   fast paths, when the plan has them (padded power-of-two length, analytic bank):
+//     block rows   ssq_cwt_blocks.hip: blockzoom kernels (overlap-save blocks, LDS FFTs) ->
+//                  Wx (+ dWx / w / 2-byte bin map)
+//     exact rows   ssq_cwt_blocks.hip: four-step full-length FFT for the rows whose band is cut
+//                  by the Nyquist bin (float32)
+//     tile rows    ssq_cwt_tiles.hip (fused ssq_cwt form only): decimated baseband samples on a
+//                  side stream, then the column-tile kernel: Wx of the interpolated rows and Tx
+//                  of ALL rows (reads back the Wx + bins the block / exact kernels left)
+//   generic path (any length / padtype None / rpadded / non-analytic banks), in row chunks:
+//     xh, banded bank --bank_multiply_kernel--> P = psih*xh, dP = P*(1j*xi/dt)
+//     --rocFFT C2C inverse, batched, scaled 1/M, in place--> padded Wx, dWx
+//     --cwt_epilogue_kernel--> Wx[:, n1:n1+N] (+ dWx / w / bin map)
+//   without the tile path: bin map or w --accumulate kernels (ssq_kernels.hip)--> Tx
+// Only the returned arrays (Wx, Tx [, dWx, w]) are written at full size; padded intermediates
+// live in plan-owned workspaces reused chunk after chunk.
 //
-// The bank is *banded*: each row keeps only the contiguous run of DFT bins on which
-// the wavelet is non-negligible (hard part 4: 12.8 % of na*M at
-// N=160k), so the multiply reads ~40 MB instead of 315 MB and the bank stays in the
-// 256 MiB Infinity Cache across calls.
+// The bank is *banded*: each row keeps only the contiguous run of DFT bins on which the wavelet
+// is non-negligible (7 % of na*M at N=160k), so it stays in the 256 MiB Infinity Cache across calls.
 //
-// Compiled with -ffp-contract=off (the epilogue computes bin indices; see
-// ssq_kernels.hip).
+// Compiled with -ffp-contract=off (the epilogue computes bin indices; see ssq_kernels.hip).
 #include "ssq_common.h"
 #include "ssq_fft.h"
 #include "ssq_blocks.h"
@@ -146,7 +153,6 @@ struct ssq_cwt_plan {
     WeightVersions weights;
     float cst0 = 0.f;                     // first weight (all of them when sp.cst_uniform)
     PlanOrder order;
-    GraphCache graphs;                    // replayed launches of small transforms
     std::string algo = "rocfft";
     // rows evaluated by the exact full-length path (all rows unless a block plan
     // took some over)
@@ -164,6 +170,10 @@ struct ssq_cwt_plan {
     int64_t timed_signals = 0;
 };
 
+static int h2d(void* dst, const void* src, size_t bytes) {
+    SSQ_CHECK_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
 static int dev_alloc(void** p, size_t bytes, int64_t& acc) {
     SSQ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 1));
     acc += (int64_t)bytes;
@@ -203,12 +213,12 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     TRY(dev_alloc(&pl->bank, (size_t)nnz * rs, pl->bytes));
     TRY(dev_alloc((void**)&pl->band_off, (size_t)(d.na + 1) * 8, pl->bytes));
     TRY(dev_alloc((void**)&pl->band_lo, (size_t)d.na * 4, pl->bytes));
-    SSQ_CHECK_HIP(hipMemcpy(pl->bank, d.bank, (size_t)nnz * rs, hipMemcpyHostToDevice));
-    SSQ_CHECK_HIP(hipMemcpy(pl->band_off, d.band_off, (size_t)(d.na + 1) * 8, hipMemcpyHostToDevice));
-    SSQ_CHECK_HIP(hipMemcpy(pl->band_lo, d.band_lo, (size_t)d.na * 4, hipMemcpyHostToDevice));
+    TRY(h2d(pl->bank, d.bank, (size_t)nnz * rs));
+    TRY(h2d(pl->band_off, d.band_off, (size_t)(d.na + 1) * 8));
+    TRY(h2d(pl->band_lo, d.band_lo, (size_t)d.na * 4));
     if (d.row_scale) {
         TRY(dev_alloc(&pl->row_scale, (size_t)d.na * rs, pl->bytes));
-        SSQ_CHECK_HIP(hipMemcpy(pl->row_scale, d.row_scale, (size_t)d.na * rs, hipMemcpyHostToDevice));
+        TRY(h2d(pl->row_scale, d.row_scale, (size_t)d.na * rs));
     }
     TRY(dev_alloc(&pl->xp, (size_t)pl->d.max_batch * d.m * rs, pl->bytes));
     TRY(dev_alloc(&pl->xh, (size_t)pl->d.max_batch * (d.m / 2 + 1) * cs, pl->bytes));
@@ -230,8 +240,8 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
         for (int64_t i = 0; i < d.na; ++i) all[i] = (int32_t)i;
         TRY(dev_alloc((void**)&pl->gen_rows, (size_t)d.na * 4, pl->bytes));
         TRY(dev_alloc((void**)&pl->all_rows, (size_t)d.na * 4, pl->bytes));
-        SSQ_CHECK_HIP(hipMemcpy(pl->gen_rows, all.data(), (size_t)d.na * 4, hipMemcpyHostToDevice));
-        SSQ_CHECK_HIP(hipMemcpy(pl->all_rows, all.data(), (size_t)d.na * 4, hipMemcpyHostToDevice));
+        TRY(h2d(pl->gen_rows, all.data(), (size_t)d.na * 4));
+        TRY(h2d(pl->all_rows, all.data(), (size_t)d.na * 4));
         pl->n_gen = d.na;
     }
     TRY(pl->fwd.create(0, d.dtype, (size_t)d.m, (size_t)pl->d.max_batch, 1.0));
@@ -250,7 +260,6 @@ void ssq_cwt_plan_destroy(ssq_cwt_plan* pl) {
     for (hipEvent_t e : pl->tev) (void)hipEventDestroy(e);
     pl->weights.destroy();
     pl->order.destroy();
-    pl->graphs.destroy();
     void* ptrs[] = {pl->bank, pl->band_off, pl->band_lo, pl->row_scale, pl->xp, pl->xh, pl->prod,
                     pl->kidx, pl->gen_rows, pl->all_rows};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -534,33 +543,11 @@ int ssq_cwt_execute(ssq_cwt_plan* pl, const void* x, int64_t batch, void* Wx, vo
     SSQ_REQUIRE(Wx, "Wx buffer is required");
     hipStream_t st = as_stream(stream);
     pl->order.enter(st);
-    auto run_on = [&](hipStream_t q) {
-        return pl->d.dtype == SSQ_F32 ? cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, q)
-                                      : cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, q);
-    };
-    auto run = [&]() { return run_on(st); };
-    int rc;
-    // launch-bound sizes only (below ~64 MB of output the launches cost as much as the kernels)
-    const bool small = (double)batch * pl->d.na * pl->d.n * pl->csize() <= 64e6 && !pl->timing && pl->executed;
-    if (!small) rc = run();
-    else {
-        const SsqParams& sp = pl->sp;
-        uint64_t ph = 1469598103934665603ull;
-        for (size_t i = 0; i < sizeof(SsqParams); ++i) ph = (ph ^ ((const unsigned char*)&sp)[i]) * 1099511628211ull;
-        const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)x, (uint64_t)batch, (uint64_t)(uintptr_t)Wx,
-                                           (uint64_t)(uintptr_t)dWx, (uint64_t)(uintptr_t)Tx, (uint64_t)(uintptr_t)w,
-                                           (uint64_t)rpadded, (uint64_t)(uintptr_t)pl->cst, pl->have_ssq ? ph : 0,
-                                           (uint64_t)(uintptr_t)st};
-        bool capture = false, rerun = false; size_t slot = 0;
-        int g = pl->graphs.begin(key, st, &capture, &slot);
-        if (g == 1) rc = 0;
-        else if (!capture) rc = run();
-        else {                                   // record on the plan's capture stream, launch on `st`
-            rc = run_on(pl->graphs.cap);
-            rc = pl->graphs.finish(slot, st, rc, &rerun);
-            if (rerun) rc = run();
-        }
-    }
+    // (replaying the launches of small transforms from a hipGraph was built in round 2 and
+    // measured slower than the eager launches on ROCm 7.2 -- config 1: 0.298 vs 0.126 ms -- so it
+    // is gone; what helps small transforms is fewer launches)
+    const int rc = pl->d.dtype == SSQ_F32 ? cwt_execute_t<float>(pl, x, batch, Wx, dWx, Tx, w, rpadded, st)
+                                          : cwt_execute_t<double>(pl, x, batch, Wx, dWx, Tx, w, rpadded, st);
     pl->order.leave(st);
     return rc;
 }

@@ -198,7 +198,6 @@ struct ssq_stft_plan {
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;   // current entries of
     WeightVersions weights, freqs;                                                      // these
     PlanOrder order;
-    GraphCache graphs;
     bool executed = false;
 };
 
@@ -258,7 +257,7 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
 void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
     if (!pl) return;
     pl->fft.destroy();
-    pl->weights.destroy(); pl->freqs.destroy(); pl->order.destroy(); pl->graphs.destroy();
+    pl->weights.destroy(); pl->freqs.destroy(); pl->order.destroy();
     void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
                     pl->ftw, pl->kidx};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -384,32 +383,8 @@ extern "C" int ssq_stft_execute(ssq_stft_plan* pl, const void* x, int64_t batch,
     SSQ_REQUIRE(!(Tx || w) || pl->have_ssq, "Tx / w requested but ssq parameters were not set");
     hipStream_t st = as_stream(stream);
     pl->order.enter(st);
-    auto run_on = [&](hipStream_t q) {
-        return pl->d.dtype == SSQ_F32 ? stft_execute_t<float>(pl, x, batch, Sx, dSx, Tx, w, q)
-                                      : stft_execute_t<double>(pl, x, batch, Sx, dSx, Tx, w, q);
-    };
-    auto run = [&]() { return run_on(st); };
-    int rc;
-    const bool small = (double)batch * pl->rows * pl->n_hops * 2 * pl->rsize() <= 64e6 && pl->executed;
-    if (!small) rc = run();
-    else {
-        const SsqParams& sp = pl->sp;
-        uint64_t ph = 1469598103934665603ull;
-        for (size_t i = 0; i < sizeof(SsqParams); ++i) ph = (ph ^ ((const unsigned char*)&sp)[i]) * 1099511628211ull;
-        const std::vector<uint64_t> key = {(uint64_t)(uintptr_t)x, (uint64_t)batch, (uint64_t)(uintptr_t)Sx,
-                                           (uint64_t)(uintptr_t)dSx, (uint64_t)(uintptr_t)Tx, (uint64_t)(uintptr_t)w,
-                                           (uint64_t)(uintptr_t)pl->cst, (uint64_t)(uintptr_t)pl->Sfs,
-                                           pl->have_ssq ? ph : 0, (uint64_t)(uintptr_t)st};
-        bool capture = false, rerun = false; size_t slot = 0;
-        int g = pl->graphs.begin(key, st, &capture, &slot);
-        if (g == 1) rc = 0;
-        else if (!capture) rc = run();
-        else {                                   // record on the plan's capture stream, launch on `st`
-            rc = run_on(pl->graphs.cap);
-            rc = pl->graphs.finish(slot, st, rc, &rerun);
-            if (rerun) rc = run();
-        }
-    }
+    const int rc = pl->d.dtype == SSQ_F32 ? stft_execute_t<float>(pl, x, batch, Sx, dSx, Tx, w, st)
+                                          : stft_execute_t<double>(pl, x, batch, Sx, dSx, Tx, w, st);
     pl->executed = true;
     pl->order.leave(st);
     return rc;

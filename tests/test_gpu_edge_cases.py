@@ -176,13 +176,9 @@ def test_plan_reuse_across_streams_and_parameter_changes(S):
         assert torch.equal(T, r2[h])
 
 
-def test_small_transforms_replay_their_launches(S):
-    """With SSQ_GRAPHS=1 launch-bound sizes are replayed from a hipGraph once a call repeats
-    with the same buffers (csrc/ssq_common.h: GraphCache; off by default -- replay measured
-    slower than eager launches): results must equal the eager ones, follow the contents of
-    the input buffer, and follow a change of parameters. (The switch is read once per process:
-    run this module with SSQ_GRAPHS=1 to exercise the replay; without it the same assertions
-    hold for the eager path.)"""
+def test_small_transforms_repeat_and_follow_their_inputs(S):
+    """Launch-bound sizes called repeatedly with the buffers torch hands out in turn: results
+    equal the first call's, follow the contents of the input buffer, and equal a fresh plan's."""
     import torch
     from ssqueezepy_amd import _cwt
     N = 10000
