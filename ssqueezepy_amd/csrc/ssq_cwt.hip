@@ -454,9 +454,16 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         mark(2 + 4 * slot + 1);
         if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
             if constexpr (sizeof(T) == 4) {
-                int rc = pl->blk->run_exact((int)b0, ng, pl->xh, (float*)Wx, (float*)dWx, (float*)w, kidx,
-                                            (const float*)pl->row_scale, d.dt, pl->sp, stream);
-                if (rc) return rc;
+                // In sub-groups of a few signals: the four-step intermediate Z of a sub-group (4 MB per
+                // row and signal) then stays in the 256 MiB Infinity Cache between the two passes.
+                static const int eg = [] { const char* e = getenv("SSQ_EXACT_GROUP"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
+                for (int s0 = 0; s0 < ng; s0 += eg) {
+                    const int ns = std::min(eg, ng - s0);
+                    int rc = pl->blk->run_exact((int)b0 + s0, ns, pl->xh, (float*)Wx, (float*)dWx, (float*)w,
+                                                kidx ? kidx + (size_t)s0 * na * N : nullptr,
+                                                (const float*)pl->row_scale, d.dt, pl->sp, stream);
+                    if (rc) return rc;
+                }
             }
         } else
         for (int64_t b = b0; b < b0 + ng; ++b) {
