@@ -263,15 +263,17 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     const int na = (int)A.na, omax = na - 1;
     float2* T = reinterpret_cast<float2*>(lds_raw);           // (na + 1) x 64 cells, the last row: scratch
     int* turn = reinterpret_cast<int*>(lds_raw + (size_t)(na + 1) * TILE_COLS * 8);
+    int* wdone = turn + 1;
     for (int k = wv; k <= na; k += NW) T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
-    if (threadIdx.x == 0) *turn = 0;
+    if (threadIdx.x == 0) { *turn = 0; *wdone = 0; }
     __syncthreads();
     const int scratch = na * TILE_COLS + c;
 
     // The workgroup is persistent: it walks the tiles blockIdx.x, + gridDim.x, ... of the launch
     // group (tile = 64 columns of one signal). All steps of all its tiles form one sequence
     // S = 0, 1, ...: wavefront w takes S = w, w + NW, ... (positions advance monotonically, so
-    // divisions are replaced by repeated subtraction). Ticket of step S: S.
+    // divisions are replaced by repeated subtraction). Ticket of step S of tile itl: S + itl --
+    // one extra ticket per tile, during which the finished tile is written out.
     const int ntx = (int)((N + TILE_COLS - 1) / TILE_COLS);
     const int ntot = ntx * A.nsig;
     const int ntl = ntot > (int)blockIdx.x ? (ntot - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
@@ -287,26 +289,38 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     };
     unsigned long long* tr = (A.trace && (int)blockIdx.x == (100 < (int)gridDim.x ? 100 : (int)gridDim.x - 1)) ? A.trace : nullptr;
 
-    // The finished tile goes to Tx and is cleared by the wavefront that applied its last step,
-    // inside that step's turn: the other wavefronts go on computing meanwhile (a rendezvous of all
-    // wavefronts at every tile -- everybody writes a share -- left them idle for a quarter of the
-    // tile's time: measured with SSQ_TILE_TRACE).
-    auto write_out = [&](int tx, int sg) {
+    // rows k = wv, wv + NW, ... of the finished tile go to Tx and are cleared; the last
+    // wavefront to finish opens the next tile's tickets. (Round 3 also measured the write-out by
+    // ONE wavefront, inside the turn of the tile's last step, so that the others never meet: a
+    // single wavefront stores 300 x 512 bytes in ~17 k cycles -- 345 us per transform against 275.)
+    auto write_out = [&](int itl, int tx, int sg) {
+        const int boundary = (itl + 1) * nst + itl;           // the ticket after the tile's last step
+        while (ticket_peek(turn) != boundary) __builtin_amdgcn_s_sleep(1);
         const unsigned col = (unsigned)(tx * TILE_COLS + c);
         const bool ok = col < nN;
         float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
-        for (int k0 = 0; k0 < na; k0 += 8) {                  // 8 bins in flight
-            float2 v[8];
+        for (int k0 = wv; k0 < na; k0 += 4 * NW) {
+            float2 v[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = T[(k0 + q < na ? k0 + q : na) * TILE_COLS + c];
+            for (int q = 0; q < 4; ++q) { const int k = k0 + q * NW; v[q] = T[(k < na ? k : na) * TILE_COLS + c]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (k0 + q < na) {
-                    T[(k0 + q) * TILE_COLS + c] = make_float2(0.f, 0.f);
-                    if (ok) Tx[(unsigned)(k0 + q) * nN + col] = v[q];
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q * NW;
+                if (k < na) {
+                    T[k * TILE_COLS + c] = make_float2(0.f, 0.f);
+                    if (ok) Tx[(unsigned)k * nN + col] = v[q];
                 }
+            }
         }
-        if (A.counters && c == 0) __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (c == 0) {
+            const int before = __scoped_atomic_fetch_add(wdone, 1, __ATOMIC_ACQ_REL, __MEMORY_SCOPE_WRKGRP);
+            if (before + 1 == NW * (itl + 1)) {
+                lds_store_release(turn, boundary + 1);
+                if (A.counters) __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+            }
+        }
     };
 
     const float g2 = (float)(A.gamma * A.gamma);
@@ -394,7 +408,15 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
 
     Pos pc; pc.S = 0; pc.itl = 0; pc.st = 0;
     pc.sg = (int)blockIdx.x / ntx; pc.tx = (int)blockIdx.x - pc.sg * ntx;
+    int w_itl = 0, w_tx = pc.tx, w_sg = pc.sg;                // next tile to write out
     advance(pc, wv);                          // the step computed
+    auto write_outs_before = [&](int itl) {   // every finished tile before tile `itl`, in order
+        while (w_itl < itl) {
+            write_out(w_itl, w_tx, w_sg);
+            ++w_itl; w_tx += (int)gridDim.x;
+            while (w_tx >= ntx) { w_tx -= ntx; ++w_sg; }
+        }
+    };
     Pos pl = pc;                              // a valid step for the loads past the end
     auto clampp = [&](const Pos& q) { return q.S < total ? q : pl; };
     if (pc.S < total) {
@@ -405,7 +427,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             constexpr int b = decltype(BB)::value;
             const bool trk = tr && pc.itl == TRACE_TILE;
             TILE_STAMP(trk, wv, pc.st, 0);
-            ticket_priority(turn, pc.S);
+            ticket_priority(turn, pc.S + pc.itl);
             const int col0 = pc.tx * TILE_COLS, col = col0 + c;
             const bool colok = col < (int)N;
             const int colc = colok ? col : (int)N - 1;
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                         // the next step: its data now (its records came in at the end of the step before)
                         load(BN, clampp(pn));
                         TILE_STAMP(trk, wv, pc.st, 1);
-                        ticket_priority(turn, pc.S);
+                        ticket_priority(turn, pc.S + pc.itl);
                     }
                     // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
                     // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
@@ -511,18 +533,18 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                 }
             }
             TILE_STAMP(trk, wv, pc.st, 2);
-            // the step's update, in ticket order
+            // the step's update, in ticket order (tiles finished before it are written out first)
             Update4Prep up4;
             update4_prepare(cell, up4);
 #pragma unroll
             for (int r = 0; r < TILE_G; ++r) { keep_term(vx[r]); keep_term(vy[r]); }
-            const int ticket = pc.S;
+            write_outs_before(pc.itl);
+            const int ticket = pc.S + pc.itl;
             float2 tcell[TILE_G];
             ticket_wait_read4(turn, ticket, lds_raw, up4, tcell);
             __builtin_amdgcn_wave_barrier();
             if (!(SSQ_TILE_EXP & 1)) update4_finish<TM>(lds_raw, up4, tcell, vx, vy);
             __builtin_amdgcn_wave_barrier();
-            if (pc.st == nst - 1) { write_out(pc.tx, pc.sg); __builtin_amdgcn_wave_barrier(); }
             ticket_pass(turn, ticket + 1, c);
             TILE_STAMP(trk, wv, pc.st, 3);
             pl = pc; pc = pn; pn = pnn;
@@ -534,6 +556,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
             step(B1{}, B0{});
         }
     }
+    write_outs_before(ntl);
 }
 
 // ---------------------------------------------------------------------------- host side
