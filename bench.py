@@ -214,16 +214,24 @@ def main():
     # transform, sets the rate). Outside the timed region of `value`.
     gather_ms = None
     if world > 1 and args.gather_tx:
+        # in chunks of a few signals: one collective moves (world - 1) x chunk x na x N x 8 bytes per
+        # rank over the xGMI links (point to point, ~153 GB/s each), the receive buffer stays small
+        # enough to sit next to the transform's own outputs (config 4: 24.6 GB of Tx per GPU)
+        chunk = max(1, min(B, int(os.environ.get('SSQ_GATHER_CHUNK', '8'))))
         Tx = step()[0]
-        big = torch.empty((world,) + tuple(Tx.shape), dtype=Tx.dtype, device=dev)
+        big = torch.empty((world, chunk) + tuple(Tx.shape[1:]), dtype=Tx.dtype, device=dev)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         Tx = step()[0]
-        if backend == 'nccl':
-            dist.all_gather_into_tensor(big, Tx)
-        else:
-            parts = [torch.empty_like(Tx).cpu() for _ in range(world)]
-            dist.all_gather(parts, Tx.cpu())
+        for c0 in range(0, B, chunk):
+            part = Tx[c0:c0 + chunk]
+            if part.shape[0] < chunk:                     # last, short chunk
+                part = torch.cat([part, part.new_zeros((chunk - part.shape[0],) + tuple(part.shape[1:]))])
+            if backend == 'nccl':
+                dist.all_gather_into_tensor(big, part.contiguous())
+            else:
+                parts = [torch.empty_like(part).cpu() for _ in range(world)]
+                dist.all_gather(parts, part.cpu())
         torch.cuda.synchronize(); dist.barrier()
         tg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
@@ -265,6 +273,8 @@ def main():
             "value": value, "unit": "transforms/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True,
+            "per_gpu": {"transforms_per_s": value / world, "signals_per_step": B,
+                        "output_bytes_per_step": int(2 * B * na * N * 8)},
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "ssq_cwt('gmw'), N=%d, %d %s scales (nv=32), "

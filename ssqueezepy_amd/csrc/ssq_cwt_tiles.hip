@@ -376,20 +376,25 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         const int wlast = (63 >> lgR) + TILE_W;
         const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb.z);
         xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
-        const float2* Ub = A.U + sb.w + (int64_t)q.sg * sb.y;
-        const float2* Wx = A.Wx + (int64_t)(A.sig0 + q.sg) * na * N;
-        const unsigned short* kidx = A.kidx + (int64_t)q.sg * na * N;
+        // Addresses: a wave-uniform 64-bit base (scalar arithmetic on the records, which arrived half
+        // a step ago) + one 32-bit byte offset per lane that is the same for the four rows.
+        const char* Ub8 = reinterpret_cast<const char*>(A.U + __builtin_amdgcn_readfirstlane(sb.w)
+                                                        + (int64_t)q.sg * __builtin_amdgcn_readfirstlane(sb.y));
+        const char* Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + q.sg) * na * N);
+        const char* kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)q.sg * na * N);
+        const unsigned vo = kind ? uidx * 8u : (unsigned)colc * 8u;
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) {
             const int4 d = rec[r];
-            const int row = d.x & 0xFFFF;
+            const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane(d.x) & 0xFFFFu;
             xr[b][r] = d.x; xkc[b][r] = d.z;
-            const unsigned o = (unsigned)row * nN + (unsigned)colc;
             // one 8-byte load either way: a sample of u (interpolated) or Wx (read back)
-            const float2* src = kind ? Ub + ((unsigned)d.y + uidx) : Wx + o;
-            xu[b][r] = *src;
+            const char* base = kind ? Ub8 + (size_t)(unsigned)__builtin_amdgcn_readfirstlane(d.y) * 8u
+                                    : Wx8 + (size_t)row * (nN * 8u);
+            xu[b][r] = *reinterpret_cast<const float2*>(base + vo);
             // (interpolated rows have no bin yet: a fixed, cached line instead of a scattered read)
-            xk[b][r] = kidx[kind ? (unsigned)colc : o];
+            const char* kb = kind ? kx8 : kx8 + (size_t)row * (nN * 2u);
+            xk[b][r] = *reinterpret_cast<const unsigned short*>(kb + (unsigned)colc * 2u);
             if (CSTK != 0) xc[b][r] = cstu[row];
         }
     };
@@ -446,8 +451,9 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     vx[r] = TM::make(xu[b][r].x, cs); vy[r] = TM::make(xu[b][r].y, cs);
                 }
             } else {
-                float2* Wx = A.Wx + (int64_t)(A.sig0 + pc.sg) * na * N;
-                float2* dWx = STORE_D ? A.dWx + (int64_t)(A.sig0 + pc.sg) * na * N : nullptr;
+                char* Wx8 = reinterpret_cast<char*>(A.Wx + (int64_t)(A.sig0 + pc.sg) * na * N);
+                char* dWx8 = STORE_D ? reinterpret_cast<char*>(A.dWx + (int64_t)(A.sig0 + pc.sg) * na * N) : nullptr;
+                const unsigned colc8 = (unsigned)colc * 8u;
                 const int baddr = xbaddr[b];
 #pragma unroll
                 for (int r = 0; r < ((SSQ_TILE_EXP & 4) ? 0 : TILE_G); ++r) {
@@ -500,11 +506,11 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     const float2 Dv = cmulf(tw, make_float2(dre, dim));
                     // (rows that only pad a step repeat the previous row -- same address, same value --
                     // and lanes past the last column repeat its point; neither contributes below)
-                    const int row = xr[b][r] & 0xFFFF;
-                    const bool pad = xr[b][r] < 0;
-                    const unsigned o = (unsigned)row * nN + (unsigned)colc;
-                    Wx[o] = Wv;
-                    if (STORE_D) dWx[o] = Dv;
+                    const int xrow = __builtin_amdgcn_readfirstlane(xr[b][r]);
+                    const bool pad = xrow < 0;
+                    const size_t rowoff = (size_t)((unsigned)xrow & 0xFFFFu) * (nN * 8u);   // wave-uniform
+                    *reinterpret_cast<float2*>(Wx8 + rowoff + colc8) = Wv;
+                    if (STORE_D) *reinterpret_cast<float2*>(dWx8 + rowoff + colc8) = Dv;
                     // phase transform and bin: as emit_point<LEAN> of the block kernels
                     const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
                     const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
