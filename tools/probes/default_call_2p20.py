@@ -10,7 +10,7 @@ for i in range(3):
     Tx,Wx,sf,sc=S.ssq_cwt(x)
     torch.cuda.synchronize(); print("call",i,"%.1f ms"%((time.time()-t0)*1e3))
 plan=next(iter(_cwt._PLAN_CACHE.values()))
-print(plan.algo, plan.na, plan.tile_rows)
+print(plan.algo, plan.na, plan.tile_rows, 'tiles done (what executed):', plan.tiles_done(), 'expected', 3 * ((N + 63) // 64))
 const=np.log(2)/32
 lhs,rhs=Tx.sum(0),None
 # log-piecewise: const varies per row: use plan's const? skip identity; check finite
