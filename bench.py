@@ -22,7 +22,10 @@ Prints ONE JSON line on rank 0: transforms/s (whole job), ms per step, plus
   dominant_kernel
                the column-tile kernel (interpolation + reassignment, ~2/3 of the time):
                its own bytes / its own time from the plan's HIP-event stage timing;
-               rocprofv3 --kernel-trace --stats of this command: profiles/r2*_kernel_stats.txt.
+               rocprofv3 --kernel-trace --stats of this command: profiles/r3*_kernel_stats.txt.
+  per_gpu      transforms/s, signals and output bytes per step and GPU (--batch 64 is
+               BASELINE config 4's per-GPU shape: 49 GB of Tx + Wx per step).
+`--scales log-piecewise` runs the reference's default scales (float64 per-row weights) instead.
   cpu_baseline the CPU oracle pipeline (scipy.fft on 64 threads + the OpenMP C
                restatement of the reference's loop nests, oracle/) on a bounded sample of
                the same workload, same box, core count stated (kind "port").
