@@ -98,7 +98,7 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
     plus `interp_rows` (bool mask)."""
     na = len(lo)
     lens = np.diff(off).astype(np.int64)
-    if M & (M - 1) or (na + 1) * COLS * 8 + 16 > 160 * 1024 or na * N >= 2 ** 29:
+    if M & (M - 1) or M > 2 ** 23 or (na + 1) * COLS * 8 + 16 > 160 * 1024 or na * N >= 2 ** 29:
         return None                              # the Tx tile must fit one CU's LDS
     lgR = np.full(na, -1, np.int64)
     for i in range(na):

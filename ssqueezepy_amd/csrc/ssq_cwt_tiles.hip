@@ -62,7 +62,8 @@ constexpr int TILE_NOBIN = 0xFFFF;
 #endif
 
 struct TileArgs {
-    const TileSeg* steps; const TileRow* rows;       // one TileSeg record per step, 4 rows per step
+    const int4* pstep;                               // one packed record per step (see TilePlan::create)
+    const int2* prow;                                // 4 packed row records per step (see TilePlan::create)
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
@@ -150,9 +151,14 @@ __device__ __forceinline__ int exact_bin(float2 W, float2 D, const SsqParams& sp
 
 // trace (tuning aid): [wavefront][step slot < 128][4 stamps], then 64 extra words
 constexpr int TRACE_STEPS = 128, TRACE_WORDS = 16 * TRACE_STEPS * 4 + 64;
+// (compiled in with -DSSQ_TILE_TRACE_BUILD, tools/ab_build.sh: the stamps cost registers)
+#ifdef SSQ_TILE_TRACE_BUILD
 #define TILE_STAMP(on, wave, j, k)                                                               \
     do { if (tr && (on) && (j) < TRACE_STEPS && c == 0)                                        \
              tr[((size_t)(wave) * TRACE_STEPS + (j)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TILE_STAMP(on, wave, j, k) do { (void)(on); } while (0)
+#endif
 constexpr int TRACE_TILE = 2;
 
 // the additive term of one point and how it is folded into a cell, in the CPU path's arithmetic:
@@ -337,8 +343,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // scalar load in flight turns every wait for a ds_bpermute result into a full drain.
     int vz = 0;
     SSQ_OPAQUE_V(vz);
-    const int4* rows4 = reinterpret_cast<const int4*>(A.rows) + vz;
-    const int4* steps4 = reinterpret_cast<const int4*>(A.steps) + vz;
+    const int2* rows2 = reinterpret_cast<const int2*>(A.prow) + vz;   // per row: row | pad << 9 | kc << 10, offset of its samples
+    const int4* steps4 = reinterpret_cast<const int4*>(A.pstep) + vz;   // per step: kind | lgR << 1 | weight offset << 8, L - 1, stride, base
     const w_t* cstu = cstv + vz;
 
     // Software pipeline over this wavefront's steps: the records of a step are fetched while the
@@ -347,56 +353,61 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // unconditionally (past the last step: the last step again, results unused): the compiler
     // counts the loads in flight per path, and a path that skips some turns every wait into a
     // full drain.
-    int4 sa, sb, rec[TILE_G];                 // next step: (kind, -, -, lgR | wtab, stride, L-1, base), rows
+    int4 sa; int2 rec[TILE_G];                // next step: its packed record, its rows
     auto load_rec = [&](const Pos& q) {
         const int g = q.st;
-        sa = steps4[2 * g]; sb = steps4[2 * g + 1];
+        sa = steps4[g];
 #pragma unroll
-        for (int r = 0; r < TILE_G; ++r) rec[r] = rows4[g * TILE_G + r];
+        for (int r = 0; r < TILE_G; ++r) rec[r] = rows2[g * TILE_G + r];
     };
     float2 xu[2][TILE_G];                     // samples of the interpolated rows / Wx of the rows read back
-    int xr[2][TILE_G], xkc[2][TILE_G];        // row (sign bit: padding), centre bin
-    unsigned short xk[2][TILE_G];             // bins of the rows read back (as loaded: a conversion here would wait for the load)
+    // per row: the packed record (interpolated rows) or the bin (rows read back) -- one register
+    // either way (16 wavefronts need the step pipeline under 128 registers)
+    int xq[2][TILE_G];
+    int xnv[2];                               // rows of the step that are not padding
     w_t xc[2][CSTK == 0 ? 1 : TILE_G];        // per-row weights
     int xkind[2], xbaddr[2], xwoff[2], xmask[2];
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
     auto load = [&](auto BB, const Pos& q) {   // data of the step whose records are in (sa, sb, rec)
         constexpr int b = decltype(BB)::value;
-        const int kind = __builtin_amdgcn_readfirstlane(sa.x);
+        const int sax = __builtin_amdgcn_readfirstlane(sa.x);
+        const int kind = sax & 1;
         xkind[b] = kind;
         const int col0 = q.tx * TILE_COLS, col = col0 + c;
         const int colc = col < (int)N ? col : (int)N - 1;         // loads stay in range
         const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
-        const int lgR = sa.w;
-        xwoff[b] = sb.x; xmask[b] = (1 << lgR) - 1;
+        const int lgR = (sax >> 1) & 31;
+        xwoff[b] = sax >> 8; xmask[b] = (1 << lgR) - 1;
         const int q0 = nabs >> lgR, qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
         // interpolated rows: the sample this lane holds (lanes past the widest window any lane
         // needs repeat the last one); rows read back: the lane's own point
         const int wlast = (63 >> lgR) + TILE_W;
-        const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & sb.z);
+        const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & __builtin_amdgcn_readfirstlane(sa.y));
         xbaddr[b] = (q0 - (TILE_W / 2 - 1) - qb) * 4;            // lane that holds tap 0
         // Addresses: a wave-uniform 64-bit base (scalar arithmetic on the records, which arrived half
         // a step ago) + one 32-bit byte offset per lane that is the same for the four rows.
-        const char* Ub8 = reinterpret_cast<const char*>(A.U + __builtin_amdgcn_readfirstlane(sb.w)
-                                                        + (int64_t)q.sg * __builtin_amdgcn_readfirstlane(sb.y));
+        const char* Ub8 = reinterpret_cast<const char*>(A.U + __builtin_amdgcn_readfirstlane(sa.w)
+                                                        + (int64_t)q.sg * __builtin_amdgcn_readfirstlane(sa.z));
         const char* Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + q.sg) * na * N);
         const char* kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)q.sg * na * N);
         const unsigned vo = kind ? uidx * 8u : (unsigned)colc * 8u;
+        int nv = 0;
 #pragma unroll
         for (int r = 0; r < TILE_G; ++r) {
-            const int4 d = rec[r];
-            const unsigned row = (unsigned)__builtin_amdgcn_readfirstlane(d.x) & 0xFFFFu;
-            xr[b][r] = d.x; xkc[b][r] = d.z;
+            const int2 d = rec[r];
+            const int dx = __builtin_amdgcn_readfirstlane(d.x);
+            const unsigned row = (unsigned)dx & 0x1FFu;
+            nv += ((dx >> 9) & 1) ^ 1;
             // one 8-byte load either way: a sample of u (interpolated) or Wx (read back)
             const char* base = kind ? Ub8 + (size_t)(unsigned)__builtin_amdgcn_readfirstlane(d.y) * 8u
                                     : Wx8 + (size_t)row * (nN * 8u);
             xu[b][r] = *reinterpret_cast<const float2*>(base + vo);
-            // (interpolated rows have no bin yet: a fixed, cached line instead of a scattered read)
-            const char* kb = kind ? kx8 : kx8 + (size_t)row * (nN * 2u);
-            xk[b][r] = *reinterpret_cast<const unsigned short*>(kb + (unsigned)colc * 2u);
+            if (kind) xq[b][r] = d.x;
+            else xq[b][r] = *reinterpret_cast<const unsigned short*>(kx8 + (size_t)row * (nN * 2u) + (unsigned)colc * 2u);
             if (CSTK != 0) xc[b][r] = cstu[row];
         }
+        xnv[b] = nv;
     };
     ssq_f2 wt[TILE_W];                        // (phi_t, phi'_t / (R dt)) of the step in hand
     auto load_wt = [&](auto BB, const Pos& q) {
@@ -444,8 +455,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                 load(BN, clampp(pn)); load_wt(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
 #pragma unroll
                 for (int r = 0; r < TILE_G; ++r) {
-                    const int kk = xk[b][r];
-                    const bool act = xr[b][r] >= 0 && colok && kk != TILE_NOBIN;
+                    const int kk = xq[b][r] & 0xFFFF;
+                    const bool act = r < xnv[b] && colok && kk != TILE_NOBIN;
                     cell[r] = act ? kk * TILE_COLS + c : scratch;
                     const w_t cs = CSTK == 0 ? (w_t)A.cst0 : xc[b][CSTK == 0 ? 0 : r];
                     vx[r] = TM::make(xu[b][r].x, cs); vy[r] = TM::make(xu[b][r].y, cs);
@@ -494,21 +505,22 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     const float are = are2.x, aim = aim2.x;
                     float dre = are2.y, dim = aim2.y;
                     // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a'),  theta = 2 pi kc / (M dt)
-                    const float theta = (float)xkc[b][r] * A.theta_scale;
+                    const int xrow = __builtin_amdgcn_readfirstlane(xq[b][r]);
+                    const int kcs = (int)((unsigned)xrow >> 10);               // centre bin (wave-uniform)
+                    const float theta = (float)kcs * A.theta_scale;
                     dre = __builtin_fmaf(-theta, aim, dre);
                     dim = __builtin_fmaf(theta, are, dim);
                     // e^{2 i pi kc n / M}: the phase kc n mod M is exact in integers and in float
                     // (M <= 2^24, checked by the host), v_sin_f32 / v_cos_f32 take revolutions (measured on
                     // the M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
-                    const float rev = (float)(__umul24((unsigned)xkc[b][r], (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
+                    const float rev = (float)(__umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
                     const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
                     const float2 Wv = cmulf(tw, make_float2(are, aim));
                     const float2 Dv = cmulf(tw, make_float2(dre, dim));
                     // (rows that only pad a step repeat the previous row -- same address, same value --
                     // and lanes past the last column repeat its point; neither contributes below)
-                    const int xrow = __builtin_amdgcn_readfirstlane(xr[b][r]);
-                    const bool pad = xrow < 0;
-                    const size_t rowoff = (size_t)((unsigned)xrow & 0xFFFFu) * (nN * 8u);   // wave-uniform
+                    const bool pad = (xrow >> 9) & 1;
+                    const size_t rowoff = (size_t)((unsigned)xrow & 0x1FFu) * (nN * 8u);   // wave-uniform
                     *reinterpret_cast<float2*>(Wx8 + rowoff + colc8) = Wv;
                     if (STORE_D) *reinterpret_cast<float2*>(dWx8 + rowoff + colc8) = Dv;
                     // phase transform and bin: as emit_point<LEAN> of the block kernels
@@ -581,7 +593,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     SSQ_REQUIRE(tile_lds_bytes(na) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
                 "na = %lld: the Tx tile exceeds the LDS", (long long)na);
     // the modulation phase kc * n mod M is formed with a 24-bit multiply and carried in a float
-    SSQ_REQUIRE(M <= ((int64_t)1 << 24), "the tile path needs a padded length <= 2^24");
+    // (and the centre bin, < M / 2, shares a word with the row: 22 bits)
+    SSQ_REQUIRE(M <= ((int64_t)1 << 23), "the tile path needs a padded length <= 2^23");
     SSQ_REQUIRE((int64_t)group * u_total < ((int64_t)1 << 31), "tile intermediates exceed 2^31 entries");
     auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
         SSQ_CHECK_HIP(hipMalloc(dst, nbytes ? nbytes : 1));
@@ -591,21 +604,40 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     };
     int rc;
     static_assert(sizeof(TileSeg) == 32 && sizeof(TileRow) == 16 && sizeof(TileIRow) == 32, "table layout");
-    {   // one record per step (a wavefront's consecutive steps are usually of different segments)
-        std::vector<TileSeg> hs((size_t)nsteps);
+    {   // one packed record per step (a wavefront's consecutive steps are usually of different
+        // segments): kind | log2 R << 1 | weight-table offset << 8, L - 1, entries between two
+        // signals' rows of the class, entries before the class
+        std::vector<int32_t> hs((size_t)nsteps * 4);
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
         int64_t covered = 0;
         for (int i = 0; i < nsegs; ++i) {
             SSQ_REQUIRE(sg[i].first == covered && sg[i].nsteps >= 1 && sg[i].first + sg[i].nsteps <= nsteps,
                         "tile segment %d does not continue the step list", i);
             SSQ_REQUIRE(sg[i].kind == 0 || sg[i].kind == 1, "tile segment %d: bad kind", i);
-            for (int t = 0; t < sg[i].nsteps; ++t) hs[(size_t)sg[i].first + t] = sg[i];
+            SSQ_REQUIRE(sg[i].lgR >= 0 && sg[i].lgR < 32 && sg[i].wtab_off >= 0 && sg[i].wtab_off < (1 << 23),
+                        "tile segment %d does not fit its packed record", i);
+            for (int t = 0; t < sg[i].nsteps; ++t) {
+                int32_t* q = &hs[((size_t)sg[i].first + t) * 4];
+                q[0] = sg[i].kind | (sg[i].lgR << 1) | (sg[i].wtab_off << 8);
+                q[1] = sg[i].lmask; q[2] = sg[i].sig_stride; q[3] = sg[i].cls_base;
+            }
             covered += sg[i].nsteps;
         }
         SSQ_REQUIRE(covered == nsteps, "tile segments cover %lld of %d steps", (long long)covered, nsteps);
-        if ((rc = up((void**)&steps, hs.data(), sizeof(TileSeg) * nsteps))) return rc;
+        if ((rc = up((void**)&steps, hs.data(), hs.size() * 4))) return rc;
     }
-    if ((rc = up((void**)&rows, d.rows, sizeof(TileRow) * TILE_G * nsteps))) return rc;
+    {   // row records as the kernel reads them: row | padding << 9 | centre bin << 10, offset of the
+        // row's samples inside its class
+        const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
+        std::vector<int32_t> hp((size_t)nsteps * TILE_G * 2);
+        for (size_t i = 0; i < (size_t)nsteps * TILE_G; ++i) {
+            const int32_t row = rw[i].row & 0xFFFF;
+            SSQ_REQUIRE(row < 512 && rw[i].kc >= 0 && rw[i].kc < (1 << 22), "tile row %zu does not fit its packed record", i);
+            hp[2 * i] = row | (rw[i].row < 0 ? 0x200 : 0) | (int32_t)((uint32_t)rw[i].kc << 10);
+            hp[2 * i + 1] = rw[i].ubase;
+        }
+        if ((rc = up((void**)&rows, hp.data(), hp.size() * 4))) return rc;
+    }
     if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
     if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
     cls.resize(d.n_classes);
@@ -710,7 +742,7 @@ static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
     TileArgs A;
-    A.steps = steps; A.rows = rows;
+    A.pstep = reinterpret_cast<const int4*>(steps); A.prow = reinterpret_cast<const int2*>(rows);
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = cst;
     A.Wx = (float2*)Wx; A.dWx = (float2*)dWx; A.Tx = (float2*)Tx; A.kidx = kidx;
     A.N = N; A.na = na; A.nsteps = nsteps; A.n1 = (int)n1; A.mmask = (int)(M - 1);
