@@ -248,7 +248,9 @@ int  ssq_cwt_execute(ssq_cwt_plan* plan, const void* x, int64_t batch, void* Wx,
  * same filter bank applied block-wise. */
 typedef struct {
     int            n_classes;
-    const int64_t* classes;      /* n_classes x 4: P, margin, valid, blocks/signal  */
+    const int64_t* classes;      /* n_classes x 5: P, margin, valid, blocks/signal, analytic   */
+                                 /* (1: blocks of the analytic signal, for rows continued past */
+                                 /* the Nyquist bin; such classes come last)                   */
     const int32_t* rows;         /* na x 6: class, kappa_lo, K_P, L', G, pbank_off  */
     const void*    pbank;        /* P-grid band values of the block rows (plan dtype) */
     const void*    pxi;          /* xi at the same bins (same indexing, plan dtype)   */

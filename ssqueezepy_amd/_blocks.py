@@ -23,9 +23,21 @@ entries times exp(2i*pi*kappa*c/P). L'-point FFTs fit in LDS, adjacent columns a
 adjacent output samples (coalesced stores), and nothing but the returned arrays
 touches HBM.
 
-Rows for which (2) fails -- the few smallest scales, whose pass-band is cut by the
-Nyquist frequency so that their impulse response decays like 1/t -- and rows of a
-non-analytic / non-power-of-two configuration stay on the exact full-length path.
+Rows whose pass-band is cut by the Nyquist frequency (the few smallest scales) fail (2) as
+the reference states them: the cut makes their impulse response decay like 1/t. But the cut
+can be moved from the filter to the signal. With x_a the analytic signal of the padded input
+(spectrum X_a = xh on bins [0, M/2), half of it at the Nyquist bin, zero above: one length-M
+inverse FFT per signal), a row is  ifft(psih * xh) = ifft(g * X_a)  for EVERY g that equals
+the un-halved bank on [0, M/2] -- whatever g holds on the bins above M/2 multiplies zeros.
+Taking for g the wavelet's own smooth continuation past Nyquist, psih(scale * 2 pi k / M) for
+k > M/2 (times a smooth taper where that continuation would be too wide for the LDS FFT),
+the filter has a compact response again (margins of 25-40 samples for the default GMW) and
+the row runs through the same block kernels, fed with the block spectra of x_a (complex
+blocks, P bins each) instead of those of x: `extend_past_nyquist`, classes with
+`analytic = 1`. The identity is exact; what differs from the reference is rounding only.
+
+Rows of a non-analytic / non-power-of-two configuration, and Nyquist-cut rows that cannot be
+extended, stay on the exact full-length path.
 
 This module measures m per row, picks the block class of every row and builds the
 tables the kernel needs (`ssq_cwt_plan_set_blocks`, include/ssq_hip.h).
@@ -64,7 +76,7 @@ def _tail_margin(f, tol, denoise):
     return out
 
 
-def _margins(vals, off, lo, M, tol, chunk=32, denoise=False):
+def _margins(vals, off, lo, M, tol, chunk=32, denoise=False, extended=None):
     """Per row: smallest m such that the impulse response's L1 mass outside
     [-m, m] (circularly, on the M-point grid) is <= tol * total. Double precision.
 
@@ -82,14 +94,16 @@ def _margins(vals, off, lo, M, tol, chunk=32, denoise=False):
         periodised with period M / s -- start at 16384 points and double until the
         margin is below 1/8 of the period (a compact response is then unaffected);
       * a band that reaches the Nyquist bin is cut there by the reference, its response
-        decays like 1/t: such rows go to the exact path without being measured."""
+        decays like 1/t: such rows go to the exact path without being measured -- unless
+        `extended[i]` says the band handed in is the row's continuation past Nyquist
+        (`extend_past_nyquist`), which is measured like any other wide band."""
     na = len(lo)
     lens = np.diff(off)
     out = np.full(na, M // 2, np.int64)
     todo = {}                                  # (kind, grid length) -> rows
     for i in range(na):
         hi = int(lo[i] + lens[i])
-        if lens[i] == 0 or hi >= M // 2 + 1:
+        if lens[i] == 0 or (hi >= M // 2 + 1 and not (extended is not None and extended[i])):
             continue                           # empty, or cut at Nyquist: exact path
         d = 0
         while (M >> (d + 1)) >= 8192 and 8 * hi <= (M >> (d + 1)):
@@ -128,14 +142,66 @@ def _margins(vals, off, lo, M, tol, chunk=32, denoise=False):
     return out
 
 
-def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
+def extend_past_nyquist(fn, scales, w_hi, vals, off, lo, M, vals64=None):
+    """Continue the Nyquist-cut rows of the banded bank past the Nyquist bin (module
+    docstring). `fn`: the wavelet's frequency-domain function, evaluated here in float64
+    (the continuation only has to be smooth: it multiplies the zeros of the analytic
+    signal's spectrum); `w_hi`: upper end of the wavelet's support (`_bank.support_hull`).
+
+    Returns ``(vals_x, off_x, vals64_x, extended)``: the bank with every extended row
+    replaced by  [its band with the Nyquist bin un-halved | continuation on bins M/2+1 ...],
+    in the bank dtype and in float64, and the per-row flag. Rows that are not cut, or whose
+    continuation does not fit, are returned unchanged (flag False)."""
+    from scipy.special import erfc
+    na, half = len(lo), M // 2
+    lens = np.diff(off)
+    h = 2 * np.pi / M
+    S = M // P_MIN
+    extended = np.zeros(na, bool)
+    bands, bands64 = [], []
+    for i in range(na):
+        band = vals[off[i]:off[i + 1]]
+        b64 = (band if vals64 is None else vals64[off[i]:off[i + 1]]).astype(np.float64)
+        # (at M == P_MIN the single-block class takes the cut rows as they are)
+        if M > P_MIN and M % 2 == 0 and lens[i] > 0 and lo[i] + lens[i] == half + 1:
+            a = float(np.asarray(scales).reshape(-1)[i])
+            k_nat = int(np.ceil(w_hi / (a * h))) + 1         # where the continuation has died out
+            # the widest band an LDS FFT takes at the shortest block length, and no wrap to DC
+            k_lim = min(int(lo[i]) + (L_MAX - 1) * S, M - S)
+            k_end = min(k_nat, k_lim)                         # one past the last bin
+            # (a taper needs room to be smooth; the wavelet's own tail needs none)
+            if k_end - half >= (2 if k_end == k_nat else max(M // 16, 2)):
+                k = np.arange(half + 1, k_end)
+                with np.errstate(all='ignore'):
+                    e = np.asarray(fn(a * h * k.astype(np.float64)))
+                e = np.where(np.isfinite(e), e, 0).real.astype(np.float64)
+                if k_end < k_nat:
+                    # smooth step 1 -> 0 over (M/2, k_end): equals 1 to 1e-17 at the Nyquist
+                    # bin, a Gaussian-shaped response in time
+                    e = e * (0.5 * erfc(6 * (2 * (k - half) / float(k_end - half) - 1)))
+                band = band.copy(); b64 = b64.copy()
+                band[-1] = band[-1] * 2; b64[-1] = b64[-1] * 2   # the halving moves into X_a (exact)
+                band = np.concatenate([band, e.astype(band.dtype)])
+                b64 = np.concatenate([b64, e])
+                extended[i] = True
+        bands.append(band); bands64.append(b64)
+    off_x = np.zeros(na + 1, np.int64)
+    np.cumsum([len(b) for b in bands], out=off_x[1:])
+    return (np.concatenate(bands) if bands else vals, off_x,
+            np.concatenate(bands64) if bands64 else vals64, extended)
+
+
+def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None, extension=None):
     """Plan the block decomposition.
 
     vals/off/lo: banded bank on the M-grid (`_bank.banded_bank`). `vals64`: the
     same band evaluated in float64 if available (margins are then measured on the
-    clean wavelet rather than on its float32 rounding noise).
+    clean wavelet rather than on its float32 rounding noise). `extension`:
+    ``(fn, scales, w_hi)`` to continue Nyquist-cut rows past the Nyquist bin
+    (`extend_past_nyquist`), or None to leave them on the exact path.
     Returns None when no row qualifies, else a dict of NumPy arrays:
-      classes  (nc, 4) int64: P, m (margin), V (valid), nb (blocks per signal)
+      classes  (nc, 5) int64: P, m (margin), V (valid), nb (blocks per signal), analytic
+               (1: the class' blocks are cut from the analytic signal, P bins per spectrum)
       rows     (na, 6) int32: class (-1 = exact path), kappa_lo, K_P, L', G, pbank_off
       pbank    concatenated P-grid band values of the block rows (bank dtype)
       pxi      xi (radian frequency) at the same bins, in the transform's dtype
@@ -160,7 +226,16 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
     half = M // 2
     if np.any(lo + lens > half + 1):
         return None                                   # negative-frequency content
-    margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol, denoise=f64)
+    # from here on `vals` / `off` / `lens` describe the bands the kernels apply: the bank's,
+    # except for the rows continued past Nyquist
+    bank_vals, bank_off = vals, off
+    extended = np.zeros(na, bool)
+    if extension is not None:
+        fn, scales, w_hi = extension
+        vals, off, vals64, extended = extend_past_nyquist(fn, scales, w_hi, vals, off, lo, M, vals64)
+        lens = np.diff(off)
+    margins = _margins(vals if vals64 is None else vals64, off, lo, M, tail_tol, denoise=f64,
+                       extended=extended)
 
     # block classes (P, margin): P = 4096, 8192, ..., M/2 with margin P/8 (valid 3P/4),
     # and the "global" class P = M (one block, no margin needed: the circular convolution
@@ -175,6 +250,8 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
         cands += [(P, den) for den in ((32, 16, 8) if P == P_MIN else (8,))]
         P *= 2
     cands.append((M, 1))
+    n_real = len(cands)
+    cands = cands + cands                             # the same classes over the analytic signal
     cls_of = np.full(na, -1, np.int64)
     rows = np.zeros((na, 6), np.int32)
     rows[:, 0] = -1
@@ -183,6 +260,8 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
         if lens[i] == 0:
             continue
         for c, (P, mden) in enumerate(cands):
+            if (c >= n_real) != bool(extended[i]):
+                continue
             if P < M and mden * margins[i] > P:
                 continue
             S = M // P
@@ -209,11 +288,12 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
             rows[i] = (c, k_lo, KP, Lp, G, pb_off)
             pb_off += KP
             break
+    extended &= cls_of >= 0            # (a continuation too wide for its block length: exact path)
     used = sorted(set(int(c) for c in cls_of if c >= 0))
     if not used:
         return None
     remap = {c: j for j, c in enumerate(used)}
-    classes = np.zeros((len(used), 4), np.int64)
+    classes = np.zeros((len(used), 5), np.int64)
     ctw, ctw_off = [], [0]
     for c in used:
         P, mden = cands[c]
@@ -223,7 +303,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
             m = P // mden
             V = P - 2 * m
             nb = -(-N // V)
-        classes[remap[c]] = (P, m, V, nb)
+        classes[remap[c]] = (P, m, V, nb, int(c >= n_real))
         q = np.arange(P)
         w = np.exp(2j * np.pi * q / P)
         ctw.append(w.astype(cdt))
@@ -246,7 +326,7 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
         c = rows[i, 0]
         if c < 0:
             continue
-        P, m, V, nb = classes[c]
+        P, m, V, nb = classes[c, :4]
         Lp, G = int(rows[i, 3]), int(rows[i, 4])
         Rp = int(P) // Lp
         b, c0 = np.meshgrid(np.arange(nb), np.arange(0, Rp, G), indexing='ij')
@@ -261,4 +341,5 @@ def plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=None, tail_tol=None):
                 pxi=(np.concatenate(px) if px else np.zeros(1, rdt)),
                 ctw=np.concatenate(ctw), ctw_off=np.array(ctw_off, np.int64),
                 ftw=np.concatenate(ftw), ftw_off=ftw_off, items=items,
-                generic_rows=generic_rows, margins=margins)
+                generic_rows=generic_rows, margins=margins, extended=extended,
+                band_vals=vals, band_off=off)

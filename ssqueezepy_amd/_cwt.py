@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc, CwtTilesDesc
 from . import algos
-from ._bank import banded_bank
+from ._bank import banded_bank, support_hull
 from ._blocks import plan_blocks, L_MIN
 from ._tiles import plan_tiles, RSUB as _tiles_rsub
 from .padding import pad_geometry, PADTYPES
@@ -54,6 +54,7 @@ class CwtPlan():
         self.max_batch = int(max_batch)
         vals, off, lo = banded_bank(wavelet, self.scales, self.M, tol=band_tol,
                                     nohalf=False)
+        self._band_tol = band_tol
         self.bank_nnz = int(off[-1])
         row_scale = None
         if not l1_norm:
@@ -76,6 +77,7 @@ class CwtPlan():
         self._pad_src = None
         self._ssq_key = None
         self.block_rows = 0
+        self.extended_rows = 0           # Nyquist-cut rows run as block rows (analytic signal)
         self.tile_rows = 0
         self.dt = float(dt)
         if algo == 0 and os.environ.get('SSQ_CWT_ALGO', 'auto') != 'generic':
@@ -89,6 +91,7 @@ class CwtPlan():
         if self.padtype is None or os.environ.get('SSQ_CWT_ALGO') == 'generic':
             return
         vals64 = None
+        fn64 = wavelet.fn if self.dtype == 'float64' else None
         if self.dtype == 'float32' and wavelet.family is not None:
             cfg = {k: v for k, v in wavelet.config.items() if k != 'dtype'}
             try:
@@ -97,10 +100,23 @@ class CwtPlan():
                                             self.M, tol=1e-3 * np.finfo('float32').eps)
                 if np.array_equal(o64, off) and np.array_equal(l64, lo):
                     vals64 = v64
+                    fn64 = twin.fn
             except Exception:
                 vals64 = None
+        # rows cut by the Nyquist bin are continued past it and run as block rows over the
+        # analytic signal (_blocks.extend_past_nyquist) when the wavelet can be evaluated in
+        # float64 (built-in families); SSQ_CWT_NYQ_EXT=0 keeps them on the exact path
+        extension = None
+        if fn64 is not None and os.environ.get('SSQ_CWT_NYQ_EXT', '1') != '0':
+            tol = self._band_tol if self._band_tol is not None else 1e-3 * np.finfo(self.dtype).eps
+            try:
+                _, w_hi = support_hull(wavelet.fn, np.dtype(self.dtype), tol,
+                                       w_extent=float(self.scales.max()) * np.pi * 1.01 + 1)
+                extension = (fn64, self.scales.astype('float64'), float(w_hi))
+            except Exception:
+                extension = None
         bp = plan_blocks(vals, off, lo, self.M, self.N, self.n1, self.dtype,
-                         vals64=vals64)
+                         vals64=vals64, extension=extension)
         if bp is None:
             return
         cls = np.ascontiguousarray(bp['classes'], dtype=np.int64)
@@ -147,6 +163,7 @@ class CwtPlan():
         d.n_generic = len(gen)
         check(self.lib.ssq_cwt_plan_set_blocks(self._h, ctypes.byref(d)))
         self.block_rows = int((rows[:, 0] >= 0).sum())
+        self.extended_rows = int(bp['extended'].sum())
         if tp is not None:
             self._set_tiles(tp, n_items_tile, len(gen))
         self.block_plan = {k: bp[k] for k in ('classes', 'margins')}

@@ -21,7 +21,9 @@ struct BlockClassDev {
     int64_t P, m, V, nb;    // block length, margin, valid length, blocks per signal
     int64_t ctw_off;        // offset of the class' column twiddles
     int64_t xb_off;         // offset of the class' block spectra
-    int64_t blk_off;        // offset of the class' gathered blocks
+    int64_t blk_off;        // offset of the class' gathered blocks (real classes)
+    int64_t xb_stride;      // bins per block spectrum: P / 2 + 1 (real blocks) or P (analytic)
+    int64_t analytic;       // 1: blocks of the analytic signal (rows continued past Nyquist, _blocks.py)
 };
 
 struct BlockPlan {
@@ -41,8 +43,13 @@ struct BlockPlan {
     int64_t ftw_off[5] = {0, 0, 0, 0, 0};
     void* blocks = nullptr;          // gathered signal blocks of one class (real)
     void* xb = nullptr;              // block spectra of every class (complex)
-    std::vector<FftPlan> ffts;       // one per run of classes with the same block length
+    std::vector<FftPlan> ffts;       // one per run of classes with the same block length and kind
     std::vector<int> fft_first;      // first class of each run
+    // analytic signal of the padded batch (classes with analytic = 1): one-sided spectrum ->
+    // length-M inverse transform, in place
+    void* xa = nullptr;
+    FftPlan inv_m;
+    int n_analytic = 0;
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take
     bool exact_ok = false;
@@ -60,9 +67,11 @@ struct BlockPlan {
     int create(const ssq_cwt_blocks_desc& d, int dtype, int64_t M, int64_t N, int64_t n1, int64_t na,
                int64_t max_batch, int64_t& bytes);
     void destroy();
-    // block spectra of all classes for the padded batch xp (max_batch x M)
+    // block spectra of all classes for the padded batch xp (max_batch x M) and its half
+    // spectrum xh (max_batch x (M / 2 + 1), what the analytic classes start from)
     // `need`: per class, 0 = skip (no row of the launch uses it), or nullptr for all
-    int spectra(const void* xp, int64_t batch, hipStream_t stream, const unsigned char* need = nullptr);
+    int spectra(const void* xp, const void* xh, int64_t batch, hipStream_t stream,
+                const unsigned char* need = nullptr);
     // all block rows of signals sig .. sig+nsig-1; kidx holds nsig maps
     // `limit`: per L' slot, run only the leading items (the tile path takes the other rows)
     int run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned short* kidx,

@@ -300,7 +300,7 @@ int ssq_cwt_plan_set_blocks(ssq_cwt_plan* pl, const ssq_cwt_blocks_desc* bd) {
     SSQ_REQUIRE((pl->d.m & (pl->d.m - 1)) == 0, "the block path needs a power-of-two padded length");
     SSQ_REQUIRE(bd->n_classes >= 1 && bd->n_generic >= 0 && bd->n_generic <= pl->d.na, "bad block tables");
     for (int c = 0; c < bd->n_classes; ++c) {
-        int64_t P = bd->classes[4 * c];
+        int64_t P = bd->classes[5 * c];
         SSQ_REQUIRE(P >= 4096 && (P & (P - 1)) == 0 && P <= pl->d.m, "class %d: bad block length %lld", c, (long long)P);
     }
     auto* b = new BlockPlan();
@@ -415,7 +415,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     // tile kernel reads back, no separate reassignment launch
     const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4;
     if (use_blocks) {
-        int rc = pl->blk->spectra(pl->xp, batch, stream, use_tiles ? pl->tile->class_need.data() : nullptr);
+        int rc = pl->blk->spectra(pl->xp, pl->xh, batch, stream, use_tiles ? pl->tile->class_need.data() : nullptr);
         if (rc) return rc;
     }
     mark(1);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     const BlockClassDev cl = A.classes[item.w];
     const int P = (int)cl.P, Rp = P / L;
     const int sig = A.sig + (int)blockIdx.y;
-    const c32* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * (cl.P / 2 + 1);
+    const c32* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * cl.xb_stride;
     const c32* ctw = A.ctw + cl.ctw_off;
     const float* psi = A.pbank + r.pb_off;
     const float* pxi = A.pxi + r.pb_off;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(FftGeom<double>::NT) void blockzoom_f64_kernel(Bloc
     const BlockClassDev cl = A.classes[item.w];
     const int P = (int)cl.P, Rp = P / L;
     const int sig = A.sig + (int)blockIdx.y;
-    const c64* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * (cl.P / 2 + 1);
+    const c64* xb = A.xb + cl.xb_off + ((int64_t)sig * cl.nb + blk) * cl.xb_stride;
     const c64* ctw = A.ctw + cl.ctw_off;
     const double* psi = A.pbank + r.pb_off;
     const double* pxi = A.pxi + r.pb_off;
@@ -593,21 +593,43 @@ __global__ __launch_bounds__(NT) void exact_pass2_kernel(ExactArgs E, SsqParams 
 
 // gather the overlapping blocks of the (periodic) padded signals, all classes in one
 // launch (blockIdx.y = class)
-template <typename T>
+// T: the element gathered -- a real sample of the padded signal (classes over x, into `blocks`)
+// or a complex sample of its analytic signal (classes with analytic = 1, straight into their
+// slots of `xb`, transformed in place)
+template <typename T, bool ANALYTIC>
 __global__ __launch_bounds__(256) void gather_blocks_kernel(const T* __restrict__ xp,
-                                                            T* __restrict__ blocks,
+                                                            T* __restrict__ dst,
                                                             const BlockClassDev* __restrict__ classes,
                                                             int64_t M, int64_t n1, int64_t batch) {
     const BlockClassDev k = classes[blockIdx.y];
     const int64_t total = batch * k.nb * k.P;
     const int64_t lead = (k.P == M) ? 0 : n1 - k.m;       // the single-block class starts at 0
-    T* out = blocks + k.blk_off;
+    T* out = dst + (ANALYTIC ? k.xb_off : k.blk_off);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         int64_t p = t % k.P, bb = t / k.P, b = bb % k.nb, s = bb / k.nb;
         int64_t src = (lead + b * k.V + p) % M;
         if (src < 0) src += M;
         out[t] = xp[s * M + src];
+    }
+}
+
+// One-sided spectrum of the analytic signal: X_a[k] = xh[k] for k < M / 2, half of it at the
+// Nyquist bin (the bank's halving of that bin, wavelets.py:86-95, moved to the signal -- exact),
+// zero above. The inverse transform of it follows in place.
+template <typename C>
+__global__ __launch_bounds__(256) void analytic_spectrum_kernel(const C* __restrict__ xh, C* __restrict__ xa,
+                                                                int64_t M, int64_t batch) {
+    const int64_t half = M / 2, total = batch * M;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t % M, s = t / M;
+        C v; v.x = 0; v.y = 0;
+        if (k <= half) {
+            v = xh[s * (half + 1) + k];
+            if (k == half) { v.x *= 0.5f; v.y *= 0.5f; }      // (exact in either precision)
+        }
+        xa[t] = v;
     }
 }
 
@@ -632,13 +654,17 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
     int64_t xb_total = 0, blk_max = 0;
     for (int c = 0; c < nc; ++c) {
         BlockClassDev& k = hcls[c];
-        k.P = d.classes[4 * c]; k.m = d.classes[4 * c + 1]; k.V = d.classes[4 * c + 2];
-        k.nb = d.classes[4 * c + 3];
+        k.P = d.classes[5 * c]; k.m = d.classes[5 * c + 1]; k.V = d.classes[5 * c + 2];
+        k.nb = d.classes[5 * c + 3];
+        k.analytic = d.classes[5 * c + 4] ? 1 : 0;
+        SSQ_REQUIRE(c == 0 || hcls[c - 1].analytic <= k.analytic, "block classes: analytic classes must come last");
         k.ctw_off = d.ctw_off[c];
+        k.xb_stride = k.analytic ? k.P : k.P / 2 + 1;
         k.xb_off = xb_total;
-        xb_total += max_batch * k.nb * (k.P / 2 + 1);
+        xb_total += max_batch * k.nb * k.xb_stride;
         k.blk_off = blk_max;
-        blk_max += max_batch * k.nb * k.P;
+        if (!k.analytic) blk_max += max_batch * k.nb * k.P;
+        n_analytic += (int)k.analytic;
     }
     auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
         SSQ_CHECK_HIP(hipMalloc(dst, nbytes ? nbytes : 1));
@@ -662,18 +688,25 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
     }
     SSQ_CHECK_HIP(hipMalloc((void**)&xb, 2 * rs * (size_t)xb_total)); bytes += 2 * rs * xb_total;
     SSQ_CHECK_HIP(hipMalloc((void**)&blocks, rs * (size_t)blk_max)); bytes += rs * blk_max;
-    // classes of equal block length are contiguous in `blocks` and `xb`: one batched
-    // real-to-complex transform per length
+    // classes of equal block length and kind are contiguous in `blocks` and `xb`: one batched
+    // real-to-complex transform per length (complex, in place in `xb`, for the analytic classes)
     for (int c = 0; c < nc;) {
         int e = c;
         int64_t nblocks = 0;
-        while (e < nc && hcls[e].P == hcls[c].P) nblocks += max_batch * hcls[e++].nb;
+        while (e < nc && hcls[e].P == hcls[c].P && hcls[e].analytic == hcls[c].analytic)
+            nblocks += max_batch * hcls[e++].nb;
         FftPlan fp;
-        rc = fp.create(0, dtype, (size_t)hcls[c].P, (size_t)nblocks, 1.0);
+        rc = fp.create(hcls[c].analytic ? 2 : 0, dtype, (size_t)hcls[c].P, (size_t)nblocks, 1.0);
         if (rc) return rc;
         bytes += (int64_t)fp.work_bytes;
         ffts.push_back(fp); fft_first.push_back(c);
         c = e;
+    }
+    if (n_analytic) {
+        SSQ_CHECK_HIP(hipMalloc(&xa, 2 * rs * (size_t)(max_batch * M))); bytes += 2 * rs * max_batch * M;
+        rc = inv_m.create(1, dtype, (size_t)M, (size_t)max_batch, 1.0 / (double)M);
+        if (rc) return rc;
+        bytes += (int64_t)inv_m.work_bytes;
     }
     n_generic = d.n_generic;
     return 0;
@@ -681,41 +714,68 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
 
 void BlockPlan::destroy() {
     for (auto& f : ffts) f.destroy();
-    void* ptrs[] = {twM, zbuf, classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
+    inv_m.destroy();
+    void* ptrs[] = {xa, twM, zbuf, classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
                     items[3], items[4]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
 }
 
-int BlockPlan::spectra(const void* xp, int64_t batch, hipStream_t stream, const unsigned char* need) {
+int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_t stream,
+                       const unsigned char* need) {
     (void)batch;                                   // planned batch: stale rows are ignored later
-    // classes are gathered and transformed in runs of equal block length; with `need`, only
-    // the runs that hold a needed class (class indices are contiguous per run)
-    int c_lo = nc, c_hi = -1;
+    // classes are gathered and transformed in runs of equal block length and kind; with `need`,
+    // only the runs that hold a needed class (class indices are contiguous per run). The real
+    // classes come first, the analytic ones last: one gather launch per kind.
     std::vector<char> run_on(ffts.size(), 1);
+    int lo[2] = {nc, nc}, hi[2] = {-1, -1};        // needed class range per kind
     for (size_t f = 0; f < ffts.size(); ++f) {
         const int a = fft_first[f], b = f + 1 < ffts.size() ? fft_first[f + 1] : nc;
         bool on = !need;
         for (int c = a; c < b && !on; ++c) on = need[c] != 0;
         run_on[f] = on;
-        if (on) { c_lo = std::min(c_lo, a); c_hi = std::max(c_hi, b - 1); }
+        const int kind = (int)hcls[a].analytic;
+        if (on) { lo[kind] = std::min(lo[kind], a); hi[kind] = std::max(hi[kind], b - 1); }
     }
-    if (c_hi < c_lo) return 0;
-    int64_t most = 0;
-    for (int c = c_lo; c <= c_hi; ++c) most = std::max<int64_t>(most, max_batch * hcls[c].nb * hcls[c].P);
-    dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 2048), (unsigned)(c_hi - c_lo + 1));
-    if (dtype == SSQ_F32)
-        hipLaunchKernelGGL(gather_blocks_kernel<float>, grid, dim3(256), 0, stream, (const float*)xp,
-                           (float*)blocks, classes + c_lo, M, n1, max_batch);
-    else
-        hipLaunchKernelGGL(gather_blocks_kernel<double>, grid, dim3(256), 0, stream, (const double*)xp,
-                           (double*)blocks, classes + c_lo, M, n1, max_batch);
-    SSQ_LAUNCH_CHECK();
     const size_t rs = dtype == SSQ_F32 ? 4 : 8;
+    for (int kind = 0; kind < 2; ++kind) {
+        if (hi[kind] < lo[kind]) continue;
+        int64_t most = 0;
+        for (int c = lo[kind]; c <= hi[kind]; ++c) most = std::max<int64_t>(most, max_batch * hcls[c].nb * hcls[c].P);
+        dim3 grid((unsigned)std::min<int64_t>((most + 255) / 256, 2048), (unsigned)(hi[kind] - lo[kind] + 1));
+        if (kind == 0) {
+            if (dtype == SSQ_F32)
+                hipLaunchKernelGGL((gather_blocks_kernel<float, false>), grid, dim3(256), 0, stream, (const float*)xp,
+                                   (float*)blocks, classes + lo[0], M, n1, max_batch);
+            else
+                hipLaunchKernelGGL((gather_blocks_kernel<double, false>), grid, dim3(256), 0, stream, (const double*)xp,
+                                   (double*)blocks, classes + lo[0], M, n1, max_batch);
+            SSQ_LAUNCH_CHECK();
+        } else {
+            // the analytic signal of every padded signal first
+            SSQ_REQUIRE(xh && xa, "analytic block classes need the half spectrum");
+            dim3 ga((unsigned)std::min<int64_t>((max_batch * M + 255) / 256, 4096));
+            if (dtype == SSQ_F32)
+                hipLaunchKernelGGL(analytic_spectrum_kernel<c32>, ga, dim3(256), 0, stream, (const c32*)xh, (c32*)xa, M, max_batch);
+            else
+                hipLaunchKernelGGL(analytic_spectrum_kernel<c64>, ga, dim3(256), 0, stream, (const c64*)xh, (c64*)xa, M, max_batch);
+            SSQ_LAUNCH_CHECK();
+            int rc = inv_m.execute(xa, nullptr, stream);
+            if (rc) return rc;
+            if (dtype == SSQ_F32)
+                hipLaunchKernelGGL((gather_blocks_kernel<c32, true>), grid, dim3(256), 0, stream, (const c32*)xa,
+                                   (c32*)xb, classes + lo[1], M, n1, max_batch);
+            else
+                hipLaunchKernelGGL((gather_blocks_kernel<c64, true>), grid, dim3(256), 0, stream, (const c64*)xa,
+                                   (c64*)xb, classes + lo[1], M, n1, max_batch);
+            SSQ_LAUNCH_CHECK();
+        }
+    }
     for (size_t f = 0; f < ffts.size(); ++f) {
         if (!run_on[f]) continue;
         const BlockClassDev& k = hcls[fft_first[f]];
-        int rc = ffts[f].execute((char*)blocks + (size_t)k.blk_off * rs,
-                                 (char*)xb + (size_t)k.xb_off * 2 * rs, stream);
+        int rc = k.analytic ? ffts[f].execute((char*)xb + (size_t)k.xb_off * 2 * rs, nullptr, stream)
+                            : ffts[f].execute((char*)blocks + (size_t)k.blk_off * rs,
+                                              (char*)xb + (size_t)k.xb_off * 2 * rs, stream);
         if (rc) return rc;
     }
     return 0;

@@ -8,7 +8,7 @@ import scipy.fft as sfft
 
 from ssqueezepy_amd.wavelets import Wavelet
 from ssqueezepy_amd.scales import process_scales
-from ssqueezepy_amd._bank import banded_bank
+from ssqueezepy_amd._bank import banded_bank, support_hull
 from ssqueezepy_amd.padding import pad_geometry
 from ssqueezepy_amd import _blocks
 
@@ -27,16 +27,45 @@ def _bank(N, nv, dtype, wavelet='gmw'):
     return vals, off, lo, M, n1, v64
 
 
+def _extension(N, nv, dtype, wavelet='gmw'):
+    """what `_cwt._try_blocks` hands to plan_blocks to continue Nyquist-cut rows"""
+    wav = Wavelet((wavelet, {'dtype': dtype}))
+    scales = np.asarray(process_scales('log', N, wav, nv=nv), dtype=dtype).reshape(-1)
+    _, w_hi = support_hull(wav.fn, np.dtype(dtype), 1e-3 * np.finfo(dtype).eps,
+                           w_extent=float(scales.max()) * np.pi * 1.01 + 1)
+    return Wavelet((wavelet, {'dtype': 'float64'})).fn, scales.astype('float64'), float(w_hi)
+
+
 @pytest.mark.parametrize('N,nv,dtype', [(6000, 8, 'float32'), (20000, 16, 'float32'),
                                         (50000, 4, 'float64'), (4097, 8, 'float64')])
-def test_plan_invariants(N, nv, dtype):
+@pytest.mark.parametrize('extend', [False, True])
+def test_plan_invariants(N, nv, dtype, extend):
     vals, off, lo, M, n1, v64 = _bank(N, nv, dtype)
-    bp = _blocks.plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=v64)
+    bp = _blocks.plan_blocks(vals, off, lo, M, N, n1, dtype, vals64=v64,
+                             extension=_extension(N, nv, dtype) if extend else None)
     assert bp is not None
     points = _blocks.POINTS_PER_WG[dtype]
     cls, rows = bp['classes'], bp['rows']
+    cut = (lo + np.diff(off)) == M // 2 + 1
+    ext = bp['extended']
+    if extend and M > _blocks.P_MIN:
+        # every Nyquist-cut row of the default GMW bank is continued and runs as a block row
+        assert cut.any() and np.array_equal(ext, cut) and len(bp['generic_rows']) == 0
+        assert np.all(cls[rows[ext, 0], 4] == 1) and np.all(cls[rows[~ext & (rows[:, 0] >= 0), 0], 4] == 0)
+        assert np.all(np.diff(cls[:, 4]) >= 0)            # analytic classes come last
+        # the continued band: the bank's values (Nyquist bin un-halved), then the continuation
+        for i in np.nonzero(ext)[0]:
+            n_in = off[i + 1] - off[i]
+            got = bp['band_vals'][bp['band_off'][i]:bp['band_off'][i + 1]]
+            assert np.array_equal(got[:n_in - 1], vals[off[i]:off[i + 1] - 1])
+            assert got[n_in - 1] == 2 * vals[off[i + 1] - 1] and len(got) > n_in
+            assert lo[i] + len(got) <= M and abs(got[-1]) <= 1e-6 * np.abs(got).max()
+    else:
+        assert not ext.any() and np.all(cls[:, 4] == 0)
+    # (from here on the bands the kernels apply)
+    vals, off = bp['band_vals'], bp['band_off']
     lens = np.diff(off)
-    for P, m, V, nb in cls:
+    for P, m, V, nb, ana in cls:
         assert P & (P - 1) == 0 and _blocks.P_MIN <= P <= M
         if P == M:
             assert (m, V, nb) == (0, M, 1)
@@ -47,7 +76,7 @@ def test_plan_invariants(N, nv, dtype):
         if c < 0:
             assert i in bp['generic_rows']
             continue
-        P, m, V, nb = cls[c]
+        P, m, V, nb = cls[c, :4]
         S = M // P
         assert Lp * G == points and KP <= Lp and Lp <= _blocks.L_MAX and P // Lp >= G
         # the P-grid band covers every P-grid bin inside the row's M-grid band

@@ -76,6 +76,39 @@ def test_block_kernels_vs_oracle(S, orc, dtype):
     _cwt.clear_plan_cache()
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_nyquist_rows_as_block_rows_vs_oracle(S, orc, dtype, monkeypatch):
+    """Rows cut by the Nyquist bin, continued past it and run by the block kernels over the
+    analytic signal (_blocks.extend_past_nyquist; classes with analytic = 1) against the oracle
+    of the reference's full-length algorithm, and next to the exact path they replace."""
+    from test_gpu_transforms import check_Tx
+    from ssqueezepy_amd import _cwt
+    N, nv = 6000, 8
+    x = two_chirps(N, seed=N)
+    wav = S.Wavelet(('gmw', {'dtype': dtype}))
+    r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=nv, typing=1)
+    out = {}
+    for ext in ('1', '0'):
+        monkeypatch.setenv('SSQ_CWT_NYQ_EXT', ext)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        if ext == '1':
+            assert plan.extended_rows >= 5 and plan.block_rows == len(sc), (plan.algo, plan.extended_rows)
+            assert 'fourstep' not in plan.algo and 'rocfft' not in plan.algo, plan.algo
+            assert plan.block_plan['classes'][:, 4].sum() >= 1
+        else:
+            assert plan.extended_rows == 0 and plan.block_rows < len(sc)
+        assert relmax(Wx, r['Wx']) <= RTOL[dtype] and relmax(dWx, r['dWx']) <= RTOL[dtype]
+        check_Tx(orc, Tx, Wx, dWx, r, dtype)
+        out[ext] = (Wx, plan.extended_rows)
+    # the rows the two runs evaluate differently agree to rounding; the others are identical
+    n_ext = out['1'][1]
+    assert np.array_equal(out['1'][0][n_ext:], out['0'][0][n_ext:])
+    assert relmax(out['1'][0][:n_ext], out['0'][0][:n_ext]) <= RTOL[dtype]
+    _cwt.clear_plan_cache()
+
+
 def test_stft_paths_vs_reference(S, orc):
     """The GPU suite's own ssq_stft test (fused STFT kernel with the bin map, generic
     rocFFT path, reference fixtures) under the emulator."""
