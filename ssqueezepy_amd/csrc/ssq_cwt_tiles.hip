@@ -44,7 +44,9 @@
 // explicit fmaf so every instantiation rounds identically.
 #include "ssq_common.h"
 #include "ssq_tiles.h"
+#include "ssq_ldsfft.h"
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 namespace ssq {
@@ -97,6 +99,118 @@ __global__ __launch_bounds__(256) void tile_spectra_kernel(const float2* __restr
             z = make_float2(x.x * b, x.y * b);
         }
         u[p] = z;
+    }
+}
+
+// ---- the long classes (L >= 2^14) of the intermediates: a four-step inverse FFT of our own.
+// rocFFT took 48 us per transform for them at config 2 (a single-kernel 16 384-point transform
+// at 0.5 TB/s, three passes for 65 536 points) plus the spectra kernel's write of the
+// zero-padded band; they are not hidden behind the block kernels (measured: side stream or
+// not, the same time), so they sit on the critical path. Here: L = A B, bin k = A k2 + k1,
+// sample q = B q1 + q2,
+//   pass 1  for every k1: B-point inverse FFT over k2 of the band -- formed on the fly from
+//           the signal's spectrum and the compensated bank values, zeros never touch memory --
+//           times e^{2 pi i k1 q2 / L} (hardware sin / cos of an exact phase, as the tile
+//           kernel's modulation), transposed through LDS into Y, blocked for pass 2;
+//   pass 2  for every q2: A-point inverse FFT over k1 -> u[B q1 + q2].
+// Both passes are the LDS Stockham transform of the block kernels (ssq_ldsfft.h): 4096 points
+// per 256-thread workgroup, 8 + 8 + 8 bytes per sample of HBM / L2 traffic.
+struct TileFftArgs {
+    const c32* xh; int64_t xh_stride; int sig0;
+    const TileIRow* irows;             // the rows of this class
+    const float* tbank;
+    c32* Y; c32* U;
+    const c32* ftw1; const c32* ftw2;  // e^{2 pi i q / B}, e^{2 pi i q / A}
+    int A, B, L, G2, nrows;
+    float inv_l;
+};
+
+template <int LB, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
+    __shared__ c32 buf[D_POINTS + 64];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x, r = blockIdx.y;
+    const TileIRow row = E.irows[r];
+    const int c0 = blockIdx.x * G;                          // first k1 of this workgroup
+    const c32* xh = E.xh + (int64_t)(E.sig0 + (int)blockIdx.z) * E.xh_stride;
+    const float* tb = E.tbank + row.tb_off;
+    const int half = E.L >> 1;
+    c32 z[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = LB / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int p = (c0 + g) + E.A * (u + k * STR);       // baseband bin, as tile_spectra_kernel
+                const int kk = p < half ? p : p - E.L;
+                const int t = row.kc + kk - row.lo;
+                c32 v = {0.f, 0.f};
+                if (t >= 0 && t < row.K) {
+                    const c32 X = xh[row.lo + t];
+                    const float b = tb[t];
+                    v = {X.x * b, X.y * b};
+                }
+                z[it * R1 + k] = v;
+            }
+        }
+    }
+    lds_ifft<LB, G, R1, R2, R3>(z, buf, E.ftw1, tid);
+    __syncthreads();
+    constexpr int NBL = PPT / RL, STRL = LB / RL;
+#pragma unroll
+    for (int it = 0; it < NBL; ++it) {
+        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) {
+            const int q2 = u + k * STRL;
+            // k1 q2 < A B = L <= 2^22: the phase is exact in integers and in float
+            const float rev = (float)((c0 + g) * q2) * E.inv_l;
+            const c32 tw = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
+            buf[g * (LB + 1) + q2] = cmul(z[it * RL + k], tw);
+        }
+    }
+    __syncthreads();
+    const int G2 = E.G2, lg2 = __ffs(G2) - 1;
+    constexpr int LG = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5;
+    c32* Yt = E.Y + ((int64_t)blockIdx.z * E.nrows + r) * E.L;
+#pragma unroll
+    for (int it = 0; it < PPT; ++it) {
+        // consecutive lanes: q2 % G2 fastest, then this workgroup's k1 -> runs of G * G2 entries
+        const int idx = tid + it * NT, q2i = idx & (G2 - 1), g = (idx >> lg2) & (G - 1);
+        const int q2t = idx >> (lg2 + LG), q2 = (q2t << lg2) + q2i;
+        Yt[((int64_t)q2t * E.A + (c0 + g)) * G2 + q2i] = buf[g * (LB + 1) + q2];
+    }
+}
+
+template <int LA, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
+    __shared__ c32 buf[D_POINTS];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    const int tid = threadIdx.x, r = blockIdx.y, bx = blockIdx.x;
+    const TileIRow row = E.irows[r];
+    const c32* Yr = E.Y + ((int64_t)blockIdx.z * E.nrows + r) * E.L;
+    c32 z[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = LA / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+            for (int k = 0; k < R1; ++k)
+                z[it * R1 + k] = Yr[(int64_t)bx * LA * G + (u + k * STR) * G + g];     // blocked Y
+        }
+    }
+    lds_ifft<LA, G, R1, R2, R3>(z, buf, E.ftw2, tid);
+    c32* u_out = E.U + row.ubase + (int64_t)blockIdx.z * row.sig_stride;
+    constexpr int NB = PPT / RL, STR = LA / RL;
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k)
+            u_out[(bx * G + g) + E.B * (u + k * STR)] = z[it * RL + k];
     }
 }
 
@@ -641,31 +755,67 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
     if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
     cls.resize(d.n_classes);
+    // classes of 2^14 entries and more: four-step kernels, L = A B with A <= B, both 128 .. 2048
+    // (SSQ_TILE_FFT=rocfft keeps every class on rocFFT)
+    const bool own_fft = !(getenv("SSQ_TILE_FFT") && !strcmp(getenv("SSQ_TILE_FFT"), "rocfft"));
+    int64_t y_entries = 0;
     for (int c = 0; c < d.n_classes; ++c) {
-        cls[c] = {d.classes[4 * c], d.classes[4 * c + 1], d.classes[4 * c + 2]};
+        cls[c] = {d.classes[4 * c], d.classes[4 * c + 1], d.classes[4 * c + 2], 0, 0, 0};
         SSQ_REQUIRE(cls[c].L >= 2 && (cls[c].L & (cls[c].L - 1)) == 0 && cls[c].nrows >= 1, "bad tile class %d", c);
         lmax = std::max(lmax, cls[c].L);
+        int lg = 0;
+        while (((int64_t)1 << lg) < cls[c].L) ++lg;
+        if (own_fft && lg >= 14 && lg <= 22) {
+            cls[c].B = 1 << ((lg + 1) / 2); cls[c].A = 1 << (lg / 2);
+            y_entries = std::max(y_entries, (int64_t)group * cls[c].nrows * cls[c].L);
+        }
     }
-    std::vector<TileIRow> hi((size_t)n_irows);
-    for (int r = 0; r < n_irows; ++r) {
-        const int64_t* q = d.irows + 8 * r;
-        const int c = (int)q[6];
-        SSQ_REQUIRE(c >= 0 && c < d.n_classes && q[4] == cls[c].L && q[2] >= 1 && 2 * q[2] <= q[4]
-                    && q[1] >= 0 && q[1] + q[2] <= M / 2 + 1 && q[5] >= 0 && q[5] + q[2] <= d.n_tbank,
-                    "bad tile row %d", r);
-        hi[r] = {(int32_t)q[0], (int32_t)q[1], (int32_t)q[2], (int32_t)q[3], (int32_t)q[4], (int32_t)q[5],
-                 (int32_t)((int64_t)group * cls[c].upre + q[7] * cls[c].L), (int32_t)(cls[c].nrows * cls[c].L)};
-    }
+    std::vector<TileIRow> hi;
+    hi.reserve((size_t)n_irows);
+    for (int pass = 0; pass < 2; ++pass)            // rows sorted by class, the four-step classes first
+        for (int c = 0; c < d.n_classes; ++c) {
+            if ((cls[c].A > 0) != (pass == 0)) continue;
+            if (pass == 1 && n_irows_fft == 0) first_irow_fft = (int)hi.size();
+            cls[c].first = (int)hi.size();
+            for (int r = 0; r < n_irows; ++r) {
+                const int64_t* q = d.irows + 8 * r;
+                if ((int)q[6] != c) continue;
+                SSQ_REQUIRE(q[4] == cls[c].L && q[2] >= 1 && 2 * q[2] <= q[4]
+                            && q[1] >= 0 && q[1] + q[2] <= M / 2 + 1 && q[5] >= 0 && q[5] + q[2] <= d.n_tbank
+                            && q[7] >= 0 && q[7] < cls[c].nrows, "bad tile row %d", r);
+                hi.push_back({(int32_t)q[0], (int32_t)q[1], (int32_t)q[2], (int32_t)q[3], (int32_t)q[4], (int32_t)q[5],
+                              (int32_t)((int64_t)group * cls[c].upre + q[7] * cls[c].L), (int32_t)(cls[c].nrows * cls[c].L)});
+            }
+            SSQ_REQUIRE((int64_t)hi.size() - cls[c].first == cls[c].nrows, "tile class %d: %lld rows listed, %lld declared",
+                        c, (long long)((int64_t)hi.size() - cls[c].first), (long long)cls[c].nrows);
+            if (pass == 1) n_irows_fft += (int)cls[c].nrows;
+        }
+    SSQ_REQUIRE((int)hi.size() == n_irows, "tile rows of unknown classes");
     if ((rc = up((void**)&irows, hi.data(), sizeof(TileIRow) * n_irows))) return rc;
+    if (y_entries) {
+        SSQ_CHECK_HIP(hipMalloc(&Y, (size_t)8 * y_entries)); bytes += 8 * y_entries;
+        std::vector<float> tw;
+        for (int s = 0; s < 5; ++s) {
+            const int Lp = 128 << s;
+            ftw_off[s] = (int64_t)tw.size() / 2;
+            for (int q = 0; q < Lp; ++q) {
+                const double a = 6.283185307179586 * (double)q / (double)Lp;
+                tw.push_back((float)std::cos(a)); tw.push_back((float)std::sin(a));
+            }
+        }
+        if ((rc = up(&ftw, tw.data(), tw.size() * 4))) return rc;
+    }
     SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * group * u_total)); bytes += 8 * group * u_total;
     SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * group * u_total));
     SSQ_CHECK_HIP(hipMalloc((void**)&counters, 64));
     SSQ_CHECK_HIP(hipMemset(counters, 0, 64));
     for (size_t c = 0; c < cls.size(); ++c) {
         FftPlan fp;
-        rc = fp.create(1, SSQ_F32, (size_t)cls[c].L, (size_t)(group * cls[c].nrows), 1.0);
-        if (rc) return rc;
-        bytes += (int64_t)fp.work_bytes;
+        if (!cls[c].A) {
+            rc = fp.create(1, SSQ_F32, (size_t)cls[c].L, (size_t)(group * cls[c].nrows), 1.0);
+            if (rc) return rc;
+            bytes += (int64_t)fp.work_bytes;
+        }
         ffts.push_back(fp);
     }
     for (int t = 0; t < 5; ++t) n_items_tile[t] = d.n_items_tile[t];
@@ -684,18 +834,64 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters};
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = nullptr;
+    steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = Y = ftw = nullptr;
     counters = nullptr;
 }
 
+template <int LB, int G, int R1, int R2, int R3>
+static void launch_tilefft1(const TileFftArgs& E, int nsig, hipStream_t stream) {
+    hipLaunchKernelGGL((tilefft_pass1_kernel<LB, G, R1, R2, R3>), dim3((unsigned)(E.A / G), (unsigned)E.nrows, (unsigned)nsig),
+                       dim3(NT), 0, stream, E);
+}
+template <int LA, int G, int R1, int R2, int R3>
+static void launch_tilefft2(const TileFftArgs& E, int nsig, hipStream_t stream) {
+    hipLaunchKernelGGL((tilefft_pass2_kernel<LA, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)E.nrows, (unsigned)nsig),
+                       dim3(NT), 0, stream, E);
+}
+
 int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
-    const dim3 grid((unsigned)std::min<int64_t>((lmax + 255) / 256, 64), (unsigned)n_irows, (unsigned)nsig);
+    // four-step classes: band -> samples in two kernels
+    for (size_t c = 0; c < cls.size(); ++c) {
+        if (!cls[c].A) continue;
+        TileFftArgs E;
+        E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
+        E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
+        E.Y = (c32*)Y; E.U = (c32*)U;
+        E.A = cls[c].A; E.B = cls[c].B; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows;
+        E.G2 = D_POINTS / E.A;                         // q2 columns per pass-2 workgroup
+        E.inv_l = 1.0f / (float)cls[c].L;
+        int sa = 0, sb = 0;
+        while ((128 << sa) < E.A) ++sa;
+        while ((128 << sb) < E.B) ++sb;
+        E.ftw1 = (const c32*)ftw + ftw_off[sb]; E.ftw2 = (const c32*)ftw + ftw_off[sa];
+        switch (sb) {
+            case 0: launch_tilefft1<128, 32, 16, 8, 1>(E, nsig, stream); break;
+            case 1: launch_tilefft1<256, 16, 16, 16, 1>(E, nsig, stream); break;
+            case 2: launch_tilefft1<512, 8, 8, 8, 8>(E, nsig, stream); break;
+            case 3: launch_tilefft1<1024, 4, 16, 8, 8>(E, nsig, stream); break;
+            default: launch_tilefft1<2048, 2, 16, 16, 8>(E, nsig, stream); break;
+        }
+        SSQ_LAUNCH_CHECK();
+        switch (sa) {
+            case 0: launch_tilefft2<128, 32, 16, 8, 1>(E, nsig, stream); break;
+            case 1: launch_tilefft2<256, 16, 16, 16, 1>(E, nsig, stream); break;
+            case 2: launch_tilefft2<512, 8, 8, 8, 8>(E, nsig, stream); break;
+            case 3: launch_tilefft2<1024, 4, 16, 8, 8>(E, nsig, stream); break;
+            default: launch_tilefft2<2048, 2, 16, 16, 8>(E, nsig, stream); break;
+        }
+        SSQ_LAUNCH_CHECK();
+    }
+    if (!n_irows_fft) return 0;
+    int64_t lmax_fft = 0;
+    for (size_t c = 0; c < cls.size(); ++c) if (!cls[c].A) lmax_fft = std::max(lmax_fft, cls[c].L);
+    const dim3 grid((unsigned)std::min<int64_t>((lmax_fft + 255) / 256, 64), (unsigned)n_irows_fft, (unsigned)nsig);
     hipLaunchKernelGGL(tile_spectra_kernel, grid, dim3(256), 0, stream, (const float2*)xh_all, M / 2 + 1, sig,
-                       irows, (const float*)tbank, (float2*)U);
+                       irows + first_irow_fft, (const float*)tbank, (float2*)U);
     SSQ_LAUNCH_CHECK();
     for (size_t c = 0; c < cls.size(); ++c) {
+        if (cls[c].A) continue;
         // the planned batch covers `group` signals; slots past nsig hold stale finite data
         int rc = ffts[c].execute((float2*)U + (size_t)group * cls[c].upre, nullptr, stream);
         if (rc) return rc;
