@@ -29,6 +29,18 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 #define SSQ_BPERMUTE_OFF(d, addr, v, off) asm volatile("ds_bpermute_b32 %0, %1, %2 offset:%3" : "=v"(d) : "v"(addr), "v"(v), "n"(off))
 // bitfield insert: d = (m & a) | (~m & b) in one instruction (the compiler spells the select out as four)
 #define SSQ_BFI(d, m, a, b) asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b))
+// complex product d = a b of two (re, im) register pairs in two packed instructions:
+//   t = (a.x b.x, a.x b.y);  d = (-a.y b.y + t.x, a.y b.x + t.y)
+// (hipcc spells a complex product out as two multiplies and two multiply-adds, or as packed
+// operations fed by v_mov shuffles; -DSSQ_NO_CMUL_PK restores that form for A/B builds).
+// The s_nop is the wait state gfx950 requires between a transcendental instruction (v_sin_f32,
+// v_cos_f32: twiddles) and a vector instruction that reads its result: the compiler inserts it for
+// its own instructions and cannot see into this block -- without it the product read stale
+// registers whenever the twiddle came straight out of v_sin / v_cos (caught by the GPU suite).
+#define SSQ_CMUL_PK(d, a, b) do { ssq_f2 t_;                                                               \
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t_) : "v"(a), "v"(b));                  \
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                       \
+        : "=v"(d) : "v"(a), "v"(b), "v"(t_)); } while (0)
 #define SSQ_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SSQ_LDS_WAITN(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
 #endif

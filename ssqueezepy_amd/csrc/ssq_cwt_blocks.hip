@@ -217,17 +217,17 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
                 c32 z = {0.f, 0.f}, dz = {0.f, 0.f};
                 if constexpr (STAGE) {
                     // zero-padded band: slots past KP hold zeros, no branch needed
-                    c32 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
-                    if (offu >= L) cw = cmul(cw, wf);
-                    z = cmul(bandW[off], cw);
-                    dz = cmul(bandD[off], cw);
+                    c32 cw = (k == 0) ? cw0 : cmul_v(cw0, spow[k * G + g]);
+                    if (offu >= L) cw = cmul_v(cw, wf);
+                    z = cmul_v(bandW[off], cw);
+                    dz = cmul_v(bandD[off], cw);
                 } else if (off < r.KP) {
                     const float p = psi[off] * invP;
                     const c32 X = xb[r.klo + off];
-                    c32 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
-                    if (offu >= L) cw = cmul(cw, wf);
+                    c32 cw = (k == 0) ? cw0 : cmul_v(cw0, spow[k * G + g]);
+                    if (offu >= L) cw = cmul_v(cw, wf);
                     const c32 bz = {p * X.x, p * X.y};
-                    z = cmul(bz, cw);
+                    z = cmul_v(bz, cw);
                     const float mm = pxi[off] * A.inv_dt;
                     dz = {-(z.y * mm), z.x * mm};
                 }
@@ -347,9 +347,9 @@ __global__ __launch_bounds__(FftGeom<double>::NT) void blockzoom_f64_kernel(Bloc
                 const c64 X = xb[r.klo + oc];
                 const double mm = pxi[oc] * A.inv_dt;
                 c64 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
-                if (offu >= L) cw = cmul(cw, wf);
+                if (offu >= L) cw = cmul_v(cw, wf);
                 const c64 bz = {p * X.x, p * X.y};
-                const c64 zz = cmul(bz, cw);
+                const c64 zz = cmul_v(bz, cw);
                 c64 z = {0.0, 0.0}, dz = {0.0, 0.0};
                 if (in) { z = zz; dz = {-(zz.y * mm), zz.x * mm}; }
                 zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(NT) void exact_pass1_kernel(ExactArgs E) {
 #pragma unroll
             for (int k = 0; k < RL; ++k) {
                 const int n2 = u + k * STRL;
-                const c32 tw = cmul(thi[g * NH + (n2 >> 5)], tlo[g * 32 + (n2 & 31)]);
-                buf[g * (L + 1) + n2] = cmul(v[it * RL + k], tw);
+                const c32 tw = cmul_v(thi[g * NH + (n2 >> 5)], tlo[g * 32 + (n2 & 31)]);
+                buf[g * (L + 1) + n2] = cmul_v(v[it * RL + k], tw);
             }
         }
         __syncthreads();

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
             // k1 q2 < A B = L <= 2^22: the phase is exact in integers and in float
             const float rev = (float)((c0 + g) * q2) * E.inv_l;
             const c32 tw = {__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)};
-            buf[g * (LB + 1) + q2] = cmul(z[it * RL + k], tw);
+            buf[g * (LB + 1) + q2] = cmul_v(z[it * RL + k], tw);
         }
     }
     __syncthreads();
@@ -215,7 +215,14 @@ __global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
 }
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+#ifdef SSQ_NO_CMUL_PK
     return make_float2(__builtin_fmaf(a.x, b.x, -(a.y * b.y)), __builtin_fmaf(a.x, b.y, a.y * b.x));
+#else
+    ssq_f2 av, bv, dv;
+    av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
+    SSQ_CMUL_PK(dv, av, bv);
+    return make_float2(dv.x, dv.y);
+#endif
 }
 
 // workgroup-scope synchronisation through LDS words (all wavefronts of a workgroup share the

@@ -6,6 +6,7 @@
 // kernel (ssq_stft.hip). Device code only; include inside a .hip translation unit.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "ssq_common.h"
 
 namespace ssq {
 
@@ -19,6 +20,19 @@ __device__ __forceinline__ double fma_(double a, double b, double c) { return __
 template <typename R> __device__ __forceinline__ cx<R> cmul(cx<R> a, cx<R> b) {
     return {fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)};
 }
+// the same product for operands that live in registers (twiddles from tables, data): float32 in two
+// packed instructions (SSQ_CMUL_PK; rounds the a.x products first, where `cmul` rounds the a.y ones)
+__device__ __forceinline__ cx<float> cmul_v(cx<float> a, cx<float> b) {
+#ifdef SSQ_NO_CMUL_PK
+    return cmul(a, b);
+#else
+    ssq_f2 av, bv, dv;
+    av.x = a.x; av.y = a.y; bv.x = b.x; bv.y = b.y;
+    SSQ_CMUL_PK(dv, av, bv);
+    return {dv.x, dv.y};
+#endif
+}
+__device__ __forceinline__ cx<double> cmul_v(cx<double> a, cx<double> b) { return cmul(a, b); }
 template <typename R> __device__ __forceinline__ cx<R> cadd(cx<R> a, cx<R> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename R> __device__ __forceinline__ cx<R> csub(cx<R> a, cx<R> b) { return {a.x - b.x, a.y - b.y}; }
 // multiply by +i (inverse-transform rotation)
@@ -129,7 +143,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             int kk = u % Ns;
             constexpr int TW = L / (Ns * R2);
 #pragma unroll
-            for (int k = 1; k < R2; ++k) t[it][k] = cmul(t[it][k], ftw[kk * k * TW]);
+            for (int k = 1; k < R2; ++k) t[it][k] = cmul_v(t[it][k], ftw[kk * k * TW]);
             Dft<R2>::run(t[it]);
             if (three) {
                 int j0 = (u / Ns) * Ns * R2 + kk;
@@ -152,7 +166,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             for (int k = 0; k < R3; ++k) t[k] = buf[(u + k * STR) * G + g];
             int kk = u % Ns;                       // == u (Ns*R3 == L)
 #pragma unroll
-            for (int k = 1; k < R3; ++k) t[k] = cmul(t[k], ftw[kk * k]);
+            for (int k = 1; k < R3; ++k) t[k] = cmul_v(t[k], ftw[kk * k]);
             Dft<R3>::run(t);
 #pragma unroll
             for (int k = 0; k < R3; ++k) v[it * R3 + k] = t[k];

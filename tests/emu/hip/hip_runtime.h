@@ -35,6 +35,8 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 #define SSQ_PK_FMA_LO(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).x, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).x, (acc).y); } while (0)
 #define SSQ_PK_FMA_HI(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).y, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).y, (acc).y); } while (0)
 #define SSQ_BPERMUTE_OFF(d, addr, v, off) ((d) = emu_ds_bpermute((addr) + (off), (v)))
+#define SSQ_CMUL_PK(d, a, b) do { const float tx_ = (a).x * (b).x, ty_ = (a).x * (b).y;                      \
+    (d).x = __builtin_fmaf(-(a).y, (b).y, tx_); (d).y = __builtin_fmaf((a).y, (b).x, ty_); } while (0)
 #define SSQ_BFI(d, m, a, b) ((d) = ((m) & (a)) | (~(m) & (b)))
 #define SSQ_LDS_WAIT() ((void)0)
 #define SSQ_LDS_WAITN(n) ((void)0)
