@@ -293,6 +293,39 @@ def test_full_size_bin_map_exact(S, orc):
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
+@pytest.mark.parametrize('N,nv,wavelet', [(20011, 8, 'gmw'), (70001, 4, 'morlet')])
+def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, monkeypatch):
+    """Rows cut by the Nyquist bin: continued past it and run by the block kernels over the
+    analytic signal (default; _blocks.extend_past_nyquist) -- and, with SSQ_CWT_NYQ_EXT=0, on the
+    exact paths they had before (float32: four-step kernels, float64: banded multiply + rocFFT).
+    Both against the oracle of the reference's full-length algorithm, and against each other."""
+    from ssqueezepy_amd import _cwt
+    tol = 1e-5 if dtype == 'float32' else 1e-12
+    x = two_chirps(N, seed=N)
+    wav = S.Wavelet((wavelet, {'dtype': dtype}))
+    r = oracle_ssq_cwt(orc, x, dtype, wavelet=wavelet, scales='log', nv=nv, typing=1)
+    out = {}
+    for ext in ('1', '0'):
+        monkeypatch.setenv('SSQ_CWT_NYQ_EXT', ext)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        if ext == '1':
+            assert plan.extended_rows >= 3 and plan.block_rows == len(sc), (plan.algo, plan.extended_rows)
+            assert 'fourstep' not in plan.algo and 'rocfft' not in plan.algo, plan.algo
+        else:
+            assert plan.extended_rows == 0 and plan.block_rows < len(sc)
+            assert ('fourstep' if dtype == 'float32' else 'rocfft') in plan.algo, plan.algo
+        eW, eD = relmax(Wx, r['Wx']), relmax(dWx, r['dWx'])
+        assert eW <= tol and eD <= tol, (ext, eW, eD)
+        check_Tx(orc, Tx, Wx, dWx, r, dtype)
+        out[ext] = (Wx, plan.extended_rows)
+    n_ext = out['1'][1]
+    assert relmax(out['1'][0][:n_ext], out['0'][0][:n_ext]) <= tol
+    _cwt.clear_plan_cache()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
 @pytest.mark.parametrize('N,nv', [(6000, 16), (20000, 8), (40000, 4)])
 def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
     """The block ("overlap-save zoom") fast path -- active once the padded length
