@@ -20,7 +20,7 @@ from ._lib import check, F32, F64, CwtDesc, CwtBlocksDesc, CwtTilesDesc
 from . import algos
 from ._bank import banded_bank, support_hull
 from ._blocks import plan_blocks, L_MIN
-from ._tiles import plan_tiles, RSUB as _tiles_rsub
+from ._tiles import plan_tiles, RSUB as _tiles_rsub, R_MIN as _tiles_rmin
 from .padding import pad_geometry, PADTYPES
 from .scales import process_scales, _process_fs_and_t
 from .wavelets import Wavelet
@@ -136,8 +136,10 @@ class CwtPlan():
         # block kernels when `Tx` is requested -- their items go to the end of each list
         tp = None
         if self.dtype == 'float32' and os.environ.get('SSQ_CWT_TILES', '1') != '0':
+            # (SSQ_TILE_RMIN: least decimation for which a row leaves the block kernels; tuning aid)
             tp = plan_tiles(vals, off, lo, self.M, self.N, self.n1, self.dt, rows[:, 0] >= 0,
-                            self.group, row_scale=self._bank[3])
+                            self.group, row_scale=self._bank[3],
+                            r_min=int(os.environ.get('SSQ_TILE_RMIN', _tiles_rmin)))
         n_items_tile = [0] * 5
         keep = [cls, rows, pbank, pxi, ctw, ctw_off, ftw, gen]
         d = CwtBlocksDesc()

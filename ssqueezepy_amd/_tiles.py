@@ -50,7 +50,8 @@ R_MIN = 4             # least decimation for which a row leaves the block kernel
 R_MAX = 4096
 L_MINLEN = 64         # shortest decimated row
 COLS = 64             # columns per workgroup of the tile kernel (one per lane)
-RSUB = 4              # rows per step (TILE_G of the kernel)
+RSUB = int(__import__('os').environ.get('SSQ_TILE_RSUB', '4'))   # rows per step (TILE_G of the kernel; the
+                      # environment override pairs with an A/B build -DSSQ_TILE_G=n)
 STEPS_PER_TICKET = 1  # (steps are handed out one at a time)
 KIND_READBACK, KIND_INTERP = 0, 1
 

@@ -54,7 +54,10 @@ namespace ssq {
 #include "ssq_point_math.inl"
 
 constexpr int TILE_COLS = 64;     // columns per workgroup (one per lane)
-constexpr int TILE_G = 4;         // rows per step
+#ifndef SSQ_TILE_G
+#define SSQ_TILE_G 4
+#endif
+constexpr int TILE_G = SSQ_TILE_G;   // rows per step (the host's RSUB, _tiles.py)
 constexpr int TILE_W = 8;         // taps
 constexpr int TILE_NOBIN = 0xFFFF;
 // tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
