@@ -218,6 +218,37 @@ def test_batches_larger_than_a_launch_group(S):
         assert torch.equal(Tb[s], T1) and torch.equal(Wb[s], W1), s
 
 
+@pytest.mark.parametrize('N', [100000, 1 << 20])
+def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
+    """The long classes of the tile path's intermediates on the four-step kernels (default) against
+    the same transform with every class on rocFFT (SSQ_TILE_FFT=rocfft): N = 100 000 covers
+    L = 2^14 .. 2^16, N = 2^20 (padded to 2^21) the factors up to 512 x 1024; batched == single."""
+    from ssqueezepy_amd import _cwt
+    nv = 2
+    x = two_chirps(N, seed=N)
+    wav = S.Wavelet()
+    res = {}
+    for mode in ('own', 'rocfft'):
+        monkeypatch.setenv('SSQ_TILE_FFT', mode)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan.tiles_done() == _tiles_of(N)
+        res[mode] = (Wx, dWx)
+        lmax = int(plan.tile_plan['classes'][:, 0].max())
+    assert lmax >= (1 << 16)
+    for k in range(2):
+        d = np.abs(res['own'][k] - res['rocfft'][k]).max() / np.abs(res['rocfft'][k]).max()
+        assert d <= 2e-6, (k, d)
+    monkeypatch.setenv('SSQ_TILE_FFT', 'own')
+    _cwt.clear_plan_cache()
+    xb = np.stack([x, x[::-1].copy()])
+    Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
+    T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
+    assert np.array_equal(Wb[1], W1) and np.array_equal(Tb[1], T1)
+    _cwt.clear_plan_cache()
+
+
 def test_tile_path_with_few_scales_and_many_tiles(S, orc):
     """Few scales (wavefronts of the tile kernel without a step of their own) and a length that
     gives every persistent workgroup several tiles, the last one partial."""

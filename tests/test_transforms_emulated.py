@@ -196,6 +196,45 @@ def test_tile_path_emulated_vs_oracle():
         assert np.array_equal(Tb[1], T1) and np.array_equal(Wb[1], W1)
 
 
+def test_tile_intermediates_four_step_emulated(monkeypatch):
+    """The long classes of the tile path's intermediates (L >= 2^14) through the four-step
+    kernels of ssq_cwt_tiles.hip (pruned first pass from the signal's spectrum, hardware sin / cos
+    twiddles, blocked intermediate, second pass) under the emulator: L = 65 536 (256 x 256),
+    32 768 (128 x 256) and 16 384 (128 x 128) in one transform, against the same transform with
+    every class on the DFT that stands in for rocFFT, against the oracle, and -- two signals --
+    batched == single."""
+    import emu_backend
+    from oracle import oracle as orc
+    from pipeline import oracle_ssq_cwt
+    from conftest import two_chirps
+    N, nv = 100000, 1
+    x = two_chirps(N, seed=N)
+    with emu_backend.emulated() as S:
+        from ssqueezepy_amd import _cwt
+        wav = S.Wavelet()
+        res = {}
+        for mode in ('own', 'rocfft'):
+            monkeypatch.setenv('SSQ_TILE_FFT', mode)
+            _cwt.clear_plan_cache()
+            Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
+            plan = next(iter(_cwt._PLAN_CACHE.values()))
+            assert plan.tiles_done() == (N + 63) // 64
+            assert {65536, 32768, 16384} <= set(int(v) for v in plan.tile_plan['classes'][:, 0])
+            res[mode] = (Wx, dWx, Tx)
+        r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
+        for k in range(2):
+            assert relmax(res['own'][k], res['rocfft'][k]) <= 1e-6
+        assert relmax(res['own'][0], r['Wx']) <= 1e-5 and relmax(res['own'][1], r['dWx']) <= 1e-5
+        monkeypatch.setenv('SSQ_TILE_FFT', 'own')
+        _cwt.clear_plan_cache()
+        xb = np.stack([x, x[::-1].copy()])
+        Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
+        assert np.array_equal(Wb[0], res['own'][0]) and np.array_equal(Tb[0], res['own'][2])
+        T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
+        assert np.array_equal(Wb[1], W1) and np.array_equal(Tb[1], T1)
+        _cwt.clear_plan_cache()
+
+
 def test_tile_path_emulated_partial_launch_group():
     """More signals than a launch group holds, under the emulator: the partial last group and
     the workspaces reused between groups (see tests/test_gpu_edge_cases.py)."""
