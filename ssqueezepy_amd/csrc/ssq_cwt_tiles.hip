@@ -176,7 +176,7 @@ __global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
     }
     __syncthreads();
     const int G2 = E.G2, lg2 = __ffs(G2) - 1;
-    constexpr int LG = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : 5;
+    constexpr int LG = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6;
     c32* Yt = E.Y + ((int64_t)blockIdx.z * E.nrows + r) * E.L;
 #pragma unroll
     for (int it = 0; it < PPT; ++it) {
@@ -214,6 +214,66 @@ __global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
 #pragma unroll
         for (int k = 0; k < RL; ++k)
             u_out[(bx * G + g) + E.B * (u + k * STR)] = z[it * RL + k];
+    }
+}
+
+// The short classes (64 .. 4096 entries per row) in one kernel: G (row, signal) pairs of a class
+// per workgroup, band -> LDS transform -> samples, transposed through LDS so that every row is
+// written as a run. Replaces the spectra kernel (a write of the zero-padded band) + a rocFFT launch
+// per class.
+template <int L, int G, int R1, int R2, int R3>
+__global__ __launch_bounds__(NT) void tilefft_small_kernel(TileFftArgs E, int npairs) {
+    __shared__ c32 buf[D_POINTS + 64];
+    constexpr int RL = (R3 > 1) ? R3 : R2;
+    constexpr int LGL = (L == 64) ? 6 : (L == 128) ? 7 : (L == 256) ? 8 : (L == 512) ? 9 : (L == 1024) ? 10 : (L == 2048) ? 11 : 12;
+    const int tid = threadIdx.x;
+    const int half = L >> 1;
+    c32 z[PPT];
+    {
+        constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+            const int j = (int)blockIdx.x * G + g;             // (row, signal) pair: row fastest
+            const bool live = j < npairs;
+            const int jr = live ? j % E.nrows : 0, js = live ? j / E.nrows : 0;
+            const TileIRow row = E.irows[jr];
+            const c32* xh = E.xh + (int64_t)(E.sig0 + js) * E.xh_stride;
+            const float* tb = E.tbank + row.tb_off;
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int p = u + k * STR;
+                const int kk = p < half ? p : p - L;
+                const int t = row.kc + kk - row.lo;
+                c32 v = {0.f, 0.f};
+                if (live && t >= 0 && t < row.K) {
+                    const c32 X = xh[row.lo + t];
+                    const float b = tb[t];
+                    v = {X.x * b, X.y * b};
+                }
+                z[it * R1 + k] = v;
+            }
+        }
+    }
+    lds_ifft<L, G, R1, R2, R3>(z, buf, E.ftw1, tid);
+    __syncthreads();
+    constexpr int NBL = PPT / RL, STRL = L / RL;
+#pragma unroll
+    for (int it = 0; it < NBL; ++it) {
+        const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+        for (int k = 0; k < RL; ++k) buf[g * (L + 1) + u + k * STRL] = z[it * RL + k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PPT; ++it) {
+        const int idx = tid + it * NT, q = idx & (L - 1), g = idx >> LGL;
+        const int j = (int)blockIdx.x * G + g;
+        if (j < npairs) {
+            const int jr = j % E.nrows, js = j / E.nrows;
+            const TileIRow row = E.irows[jr];
+            E.U[row.ubase + (int64_t)js * row.sig_stride + q] = buf[g * (L + 1) + q];
+        }
     }
 }
 
@@ -775,16 +835,18 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         lmax = std::max(lmax, cls[c].L);
         int lg = 0;
         while (((int64_t)1 << lg) < cls[c].L) ++lg;
-        if (own_fft && lg >= 14 && lg <= 22) {
+        if (own_fft && lg >= 13 && lg <= 22) {
             cls[c].B = 1 << ((lg + 1) / 2); cls[c].A = 1 << (lg / 2);
             y_entries = std::max(y_entries, (int64_t)group * cls[c].nrows * cls[c].L);
+        } else if (own_fft && lg >= 6 && lg <= 12) {
+            cls[c].B = 1;                              // one-pass kernel
         }
     }
     std::vector<TileIRow> hi;
     hi.reserve((size_t)n_irows);
     for (int pass = 0; pass < 2; ++pass)            // rows sorted by class, the four-step classes first
         for (int c = 0; c < d.n_classes; ++c) {
-            if ((cls[c].A > 0) != (pass == 0)) continue;
+            if ((cls[c].A > 0 || cls[c].B > 0) != (pass == 0)) continue;
             if (pass == 1 && n_irows_fft == 0) first_irow_fft = (int)hi.size();
             cls[c].first = (int)hi.size();
             for (int r = 0; r < n_irows; ++r) {
@@ -802,11 +864,11 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
     SSQ_REQUIRE((int)hi.size() == n_irows, "tile rows of unknown classes");
     if ((rc = up((void**)&irows, hi.data(), sizeof(TileIRow) * n_irows))) return rc;
-    if (y_entries) {
-        SSQ_CHECK_HIP(hipMalloc(&Y, (size_t)8 * y_entries)); bytes += 8 * y_entries;
+    if (own_fft) {
+        SSQ_CHECK_HIP(hipMalloc(&Y, (size_t)8 * std::max<int64_t>(y_entries, 1))); bytes += 8 * y_entries;
         std::vector<float> tw;
-        for (int s = 0; s < 5; ++s) {
-            const int Lp = 128 << s;
+        for (int s = 0; s < 7; ++s) {
+            const int Lp = 64 << s;
             ftw_off[s] = (int64_t)tw.size() / 2;
             for (int q = 0; q < Lp; ++q) {
                 const double a = 6.283185307179586 * (double)q / (double)Lp;
@@ -821,7 +883,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     SSQ_CHECK_HIP(hipMemset(counters, 0, 64));
     for (size_t c = 0; c < cls.size(); ++c) {
         FftPlan fp;
-        if (!cls[c].A) {
+        if (!cls[c].A && !cls[c].B) {
             rc = fp.create(1, SSQ_F32, (size_t)cls[c].L, (size_t)(group * cls[c].nrows), 1.0);
             if (rc) return rc;
             bytes += (int64_t)fp.work_bytes;
@@ -861,7 +923,36 @@ static void launch_tilefft2(const TileFftArgs& E, int nsig, hipStream_t stream) 
                        dim3(NT), 0, stream, E);
 }
 
+template <int L, int G, int R1, int R2, int R3>
+static void launch_tilefft_small(const TileFftArgs& E, int nsig, hipStream_t stream) {
+    const int npairs = E.nrows * nsig;
+    hipLaunchKernelGGL((tilefft_small_kernel<L, G, R1, R2, R3>), dim3((unsigned)((npairs + G - 1) / G)), dim3(NT), 0, stream,
+                       E, npairs);
+}
+
 int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
+    // short classes: band -> samples in one kernel
+    for (size_t c = 0; c < cls.size(); ++c) {
+        if (cls[c].A || !cls[c].B) continue;
+        TileFftArgs E;
+        E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
+        E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
+        E.Y = nullptr; E.U = (c32*)U;
+        E.A = 0; E.B = 0; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows; E.G2 = 0; E.inv_l = 0.f;
+        int sl = 0;
+        while ((64 << sl) < E.L) ++sl;
+        E.ftw1 = (const c32*)ftw + ftw_off[sl]; E.ftw2 = nullptr;
+        switch (sl) {
+            case 0: launch_tilefft_small<64, 64, 8, 8, 1>(E, nsig, stream); break;
+            case 1: launch_tilefft_small<128, 32, 16, 8, 1>(E, nsig, stream); break;
+            case 2: launch_tilefft_small<256, 16, 16, 16, 1>(E, nsig, stream); break;
+            case 3: launch_tilefft_small<512, 8, 8, 8, 8>(E, nsig, stream); break;
+            case 4: launch_tilefft_small<1024, 4, 16, 8, 8>(E, nsig, stream); break;
+            case 5: launch_tilefft_small<2048, 2, 16, 16, 8>(E, nsig, stream); break;
+            default: launch_tilefft_small<4096, 1, 16, 16, 16>(E, nsig, stream); break;
+        }
+        SSQ_LAUNCH_CHECK();
+    }
     // four-step classes: band -> samples in two kernels
     for (size_t c = 0; c < cls.size(); ++c) {
         if (!cls[c].A) continue;
@@ -872,36 +963,37 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
         E.A = cls[c].A; E.B = cls[c].B; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows;
         E.G2 = D_POINTS / E.A;                         // q2 columns per pass-2 workgroup
         E.inv_l = 1.0f / (float)cls[c].L;
-        int sa = 0, sb = 0;
-        while ((128 << sa) < E.A) ++sa;
-        while ((128 << sb) < E.B) ++sb;
+        int sa = 0, sb = 0;                            // table slots: L' = 64 << slot
+        while ((64 << sa) < E.A) ++sa;
+        while ((64 << sb) < E.B) ++sb;
         E.ftw1 = (const c32*)ftw + ftw_off[sb]; E.ftw2 = (const c32*)ftw + ftw_off[sa];
-        switch (sb) {
-            case 0: launch_tilefft1<128, 32, 16, 8, 1>(E, nsig, stream); break;
-            case 1: launch_tilefft1<256, 16, 16, 16, 1>(E, nsig, stream); break;
-            case 2: launch_tilefft1<512, 8, 8, 8, 8>(E, nsig, stream); break;
-            case 3: launch_tilefft1<1024, 4, 16, 8, 8>(E, nsig, stream); break;
+        switch (sb) {                                  // B >= 128 (L >= 2^13, B >= A)
+            case 1: launch_tilefft1<128, 32, 16, 8, 1>(E, nsig, stream); break;
+            case 2: launch_tilefft1<256, 16, 16, 16, 1>(E, nsig, stream); break;
+            case 3: launch_tilefft1<512, 8, 8, 8, 8>(E, nsig, stream); break;
+            case 4: launch_tilefft1<1024, 4, 16, 8, 8>(E, nsig, stream); break;
             default: launch_tilefft1<2048, 2, 16, 16, 8>(E, nsig, stream); break;
         }
         SSQ_LAUNCH_CHECK();
         switch (sa) {
-            case 0: launch_tilefft2<128, 32, 16, 8, 1>(E, nsig, stream); break;
-            case 1: launch_tilefft2<256, 16, 16, 16, 1>(E, nsig, stream); break;
-            case 2: launch_tilefft2<512, 8, 8, 8, 8>(E, nsig, stream); break;
-            case 3: launch_tilefft2<1024, 4, 16, 8, 8>(E, nsig, stream); break;
+            case 0: launch_tilefft2<64, 64, 8, 8, 1>(E, nsig, stream); break;
+            case 1: launch_tilefft2<128, 32, 16, 8, 1>(E, nsig, stream); break;
+            case 2: launch_tilefft2<256, 16, 16, 16, 1>(E, nsig, stream); break;
+            case 3: launch_tilefft2<512, 8, 8, 8, 8>(E, nsig, stream); break;
+            case 4: launch_tilefft2<1024, 4, 16, 8, 8>(E, nsig, stream); break;
             default: launch_tilefft2<2048, 2, 16, 16, 8>(E, nsig, stream); break;
         }
         SSQ_LAUNCH_CHECK();
     }
     if (!n_irows_fft) return 0;
     int64_t lmax_fft = 0;
-    for (size_t c = 0; c < cls.size(); ++c) if (!cls[c].A) lmax_fft = std::max(lmax_fft, cls[c].L);
+    for (size_t c = 0; c < cls.size(); ++c) if (!cls[c].A && !cls[c].B) lmax_fft = std::max(lmax_fft, cls[c].L);
     const dim3 grid((unsigned)std::min<int64_t>((lmax_fft + 255) / 256, 64), (unsigned)n_irows_fft, (unsigned)nsig);
     hipLaunchKernelGGL(tile_spectra_kernel, grid, dim3(256), 0, stream, (const float2*)xh_all, M / 2 + 1, sig,
                        irows + first_irow_fft, (const float*)tbank, (float2*)U);
     SSQ_LAUNCH_CHECK();
     for (size_t c = 0; c < cls.size(); ++c) {
-        if (cls[c].A) continue;
+        if (cls[c].A || cls[c].B) continue;
         // the planned batch covers `group` signals; slots past nsig hold stale finite data
         int rc = ffts[c].execute((float2*)U + (size_t)group * cls[c].upre, nullptr, stream);
         if (rc) return rc;

@@ -45,14 +45,16 @@ struct TilePlan {
     void* U = nullptr;                      // group x u_total complex64
     unsigned long long* counters = nullptr; // [0]: tiles the kernel has finished since plan creation
     // A, B > 0: a long class transformed by the four-step kernels of ssq_cwt_tiles.hip (L = A B);
-    // first: its rows in `irows` (sorted by class, the four-step classes first)
+    // A = 0, B = 1: a short class (64 .. 4096 entries) transformed by the one-pass kernel;
+    // A = B = 0: rocFFT. first: its rows in `irows` (sorted by class, the classes of our own
+    // kernels first)
     struct Cls { int64_t L, nrows, upre; int A, B, first; };
     std::vector<Cls> cls;
     std::vector<FftPlan> ffts;              // one batched inverse per class (unused for four-step classes)
     int n_irows_fft = 0, first_irow_fft = 0;   // rows of the rocFFT classes (the spectra kernel's)
     void* Y = nullptr;                      // four-step intermediate of the largest class (group x rows x L)
-    void* ftw = nullptr;                    // e^{2 pi i q / L'}, L' = 128 .. 2048, concatenated
-    int64_t ftw_off[5] = {0, 0, 0, 0, 0};
+    void* ftw = nullptr;                    // e^{2 pi i q / L'}, L' = 64 .. 4096, concatenated
+    int64_t ftw_off[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t n_items_tile[5] = {0, 0, 0, 0, 0};
     std::vector<unsigned char> class_need;   // block classes the remaining block rows use
     // the intermediates (a spectra kernel + small FFTs) run on a side stream, beside the block /
