@@ -45,7 +45,7 @@ extern "C" {
 #define SSQ_PAD_WRAP 4
 
 /* ------------------------------------------------------------------ runtime */
-int         ssq_version(void);
+int         ssq_version(void);          /* 101 (100: block classes without the `analytic` column) */
 const char* ssq_last_error(void);
 int         ssq_device_count(int* count);
 int         ssq_set_device(int device);

@@ -127,6 +127,9 @@ EXPORTS = tuple(_PROTOS)
 _lib = None
 
 
+ABI_VERSION = 101     # include/ssq_hip.h: ssq_version()
+
+
 def load(build_if_missing=True):
     """Load (building first if necessary) libssq_hip.so and declare prototypes."""
     global _lib
@@ -148,6 +151,10 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)       # AttributeError here = ABI/header mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.ssq_version() < ABI_VERSION:
+        raise SsqError("%s is an older build (ABI %d, this package needs %d: the layout of "
+                       "ssq_cwt_blocks_desc changed); rebuild with `python -m ssqueezepy_amd.build`"
+                       % (LIB_PATH, lib.ssq_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -39,6 +39,7 @@ def emulated():
     for name, (res, args) in _lib._PROTOS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    assert lib.ssq_version() >= _lib.ABI_VERSION, "stale emulated library: make -C tests/emu clean"
     cpu = torch.device('cpu')
     patches = []
 
