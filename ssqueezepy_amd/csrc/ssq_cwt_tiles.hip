@@ -222,8 +222,7 @@ __global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
 // written as a run. Replaces the spectra kernel (a write of the zero-padded band) + a rocFFT launch
 // per class.
 template <int L, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(NT) void tilefft_small_kernel(TileFftArgs E, int npairs) {
-    __shared__ c32 buf[D_POINTS + 64];
+__device__ __forceinline__ void tilefft_small_body(const TileFftArgs& E, int npairs, int block, c32* buf) {
     constexpr int RL = (R3 > 1) ? R3 : R2;
     constexpr int LGL = (L == 64) ? 6 : (L == 128) ? 7 : (L == 256) ? 8 : (L == 512) ? 9 : (L == 1024) ? 10 : (L == 2048) ? 11 : 12;
     const int tid = threadIdx.x;
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(NT) void tilefft_small_kernel(TileFftArgs E, int np
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
-            const int j = (int)blockIdx.x * G + g;             // (row, signal) pair: row fastest
+            const int j = block * G + g;             // (row, signal) pair: row fastest
             const bool live = j < npairs;
             const int jr = live ? j % E.nrows : 0, js = live ? j / E.nrows : 0;
             const TileIRow row = E.irows[jr];
@@ -268,12 +267,37 @@ __global__ __launch_bounds__(NT) void tilefft_small_kernel(TileFftArgs E, int np
 #pragma unroll
     for (int it = 0; it < PPT; ++it) {
         const int idx = tid + it * NT, q = idx & (L - 1), g = idx >> LGL;
-        const int j = (int)blockIdx.x * G + g;
+        const int j = block * G + g;
         if (j < npairs) {
             const int jr = j % E.nrows, js = j / E.nrows;
             const TileIRow row = E.irows[jr];
             E.U[row.ubase + (int64_t)js * row.sig_stride + q] = buf[g * (L + 1) + q];
         }
+    }
+}
+
+// all short classes of a launch group in ONE launch: each class alone is a few dozen workgroups
+// (32 rows x 16 signals / G), far too few to fill 256 CUs -- launched one after the other they
+// cost ~190 us per group, side by side what the longest of them takes
+struct TileSmallArgs {
+    TileFftArgs E[7];
+    int first_block[8];      // workgroups before class c
+    int npairs[7], slot[7];  // (row, signal) pairs of the class; L = 64 << slot
+    int ncls;
+};
+__global__ __launch_bounds__(NT) void tilefft_small_kernel(TileSmallArgs A) {
+    __shared__ c32 buf[D_POINTS + 64];
+    int b = (int)blockIdx.x, c = 0;
+    while (c + 1 < A.ncls && b >= A.first_block[c + 1]) ++c;
+    b -= A.first_block[c];
+    switch (A.slot[c]) {
+        case 0: tilefft_small_body<64, 64, 8, 8, 1>(A.E[c], A.npairs[c], b, buf); break;
+        case 1: tilefft_small_body<128, 32, 16, 8, 1>(A.E[c], A.npairs[c], b, buf); break;
+        case 2: tilefft_small_body<256, 16, 16, 16, 1>(A.E[c], A.npairs[c], b, buf); break;
+        case 3: tilefft_small_body<512, 8, 8, 8, 8>(A.E[c], A.npairs[c], b, buf); break;
+        case 4: tilefft_small_body<1024, 4, 16, 8, 8>(A.E[c], A.npairs[c], b, buf); break;
+        case 5: tilefft_small_body<2048, 2, 16, 16, 8>(A.E[c], A.npairs[c], b, buf); break;
+        default: tilefft_small_body<4096, 1, 16, 16, 16>(A.E[c], A.npairs[c], b, buf); break;
     }
 }
 
@@ -923,35 +947,32 @@ static void launch_tilefft2(const TileFftArgs& E, int nsig, hipStream_t stream) 
                        dim3(NT), 0, stream, E);
 }
 
-template <int L, int G, int R1, int R2, int R3>
-static void launch_tilefft_small(const TileFftArgs& E, int nsig, hipStream_t stream) {
-    const int npairs = E.nrows * nsig;
-    hipLaunchKernelGGL((tilefft_small_kernel<L, G, R1, R2, R3>), dim3((unsigned)((npairs + G - 1) / G)), dim3(NT), 0, stream,
-                       E, npairs);
-}
-
 int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
-    // short classes: band -> samples in one kernel
-    for (size_t c = 0; c < cls.size(); ++c) {
-        if (cls[c].A || !cls[c].B) continue;
-        TileFftArgs E;
-        E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
-        E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
-        E.Y = nullptr; E.U = (c32*)U;
-        E.A = 0; E.B = 0; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows; E.G2 = 0; E.inv_l = 0.f;
-        int sl = 0;
-        while ((64 << sl) < E.L) ++sl;
-        E.ftw1 = (const c32*)ftw + ftw_off[sl]; E.ftw2 = nullptr;
-        switch (sl) {
-            case 0: launch_tilefft_small<64, 64, 8, 8, 1>(E, nsig, stream); break;
-            case 1: launch_tilefft_small<128, 32, 16, 8, 1>(E, nsig, stream); break;
-            case 2: launch_tilefft_small<256, 16, 16, 16, 1>(E, nsig, stream); break;
-            case 3: launch_tilefft_small<512, 8, 8, 8, 8>(E, nsig, stream); break;
-            case 4: launch_tilefft_small<1024, 4, 16, 8, 8>(E, nsig, stream); break;
-            case 5: launch_tilefft_small<2048, 2, 16, 16, 8>(E, nsig, stream); break;
-            default: launch_tilefft_small<4096, 1, 16, 16, 16>(E, nsig, stream); break;
+    // short classes: band -> samples, all of them in one launch (the longest rows first)
+    {
+        TileSmallArgs S;
+        S.ncls = 0; S.first_block[0] = 0;
+        for (int want = 6; want >= 0; --want)
+            for (size_t c = 0; c < cls.size() && S.ncls < 7; ++c) {
+                if (cls[c].A || !cls[c].B) continue;
+                int sl = 0;
+                while ((64 << sl) < cls[c].L) ++sl;
+                if (sl != want) continue;
+                TileFftArgs& E = S.E[S.ncls];
+                E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
+                E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
+                E.Y = nullptr; E.U = (c32*)U;
+                E.A = 0; E.B = 0; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows; E.G2 = 0; E.inv_l = 0.f;
+                E.ftw1 = (const c32*)ftw + ftw_off[sl]; E.ftw2 = nullptr;
+                const int G = D_POINTS / (int)cls[c].L, npairs = E.nrows * nsig;
+                S.npairs[S.ncls] = npairs; S.slot[S.ncls] = sl;
+                S.first_block[S.ncls + 1] = S.first_block[S.ncls] + (npairs + G - 1) / G;
+                ++S.ncls;
+            }
+        if (S.ncls) {
+            hipLaunchKernelGGL(tilefft_small_kernel, dim3((unsigned)S.first_block[S.ncls]), dim3(NT), 0, stream, S);
+            SSQ_LAUNCH_CHECK();
         }
-        SSQ_LAUNCH_CHECK();
     }
     // four-step classes: band -> samples in two kernels
     for (size_t c = 0; c < cls.size(); ++c) {
