@@ -128,14 +128,14 @@ struct TileFftArgs {
     float inv_l;
 };
 
+// (bx, r, z): workgroup inside the class -- k1 group (pass 1) or q2 group (pass 2), row, signal
 template <int LB, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
-    __shared__ c32 buf[D_POINTS + 64];
+__device__ __forceinline__ void tilefft_pass1_body(const TileFftArgs& E, int bx, int r, int z_sig, c32* buf) {
     constexpr int RL = (R3 > 1) ? R3 : R2;
-    const int tid = threadIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x;
     const TileIRow row = E.irows[r];
-    const int c0 = blockIdx.x * G;                          // first k1 of this workgroup
-    const c32* xh = E.xh + (int64_t)(E.sig0 + (int)blockIdx.z) * E.xh_stride;
+    const int c0 = bx * G;                                  // first k1 of this workgroup
+    const c32* xh = E.xh + (int64_t)(E.sig0 + z_sig) * E.xh_stride;
     const float* tb = E.tbank + row.tb_off;
     const int half = E.L >> 1;
     c32 z[PPT];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
     __syncthreads();
     const int G2 = E.G2, lg2 = __ffs(G2) - 1;
     constexpr int LG = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : (G == 16) ? 4 : (G == 32) ? 5 : 6;
-    c32* Yt = E.Y + ((int64_t)blockIdx.z * E.nrows + r) * E.L;
+    c32* Yt = E.Y + ((int64_t)z_sig * E.nrows + r) * E.L;
 #pragma unroll
     for (int it = 0; it < PPT; ++it) {
         // consecutive lanes: q2 % G2 fastest, then this workgroup's k1 -> runs of G * G2 entries
@@ -188,12 +188,11 @@ __global__ __launch_bounds__(NT) void tilefft_pass1_kernel(TileFftArgs E) {
 }
 
 template <int LA, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
-    __shared__ c32 buf[D_POINTS];
+__device__ __forceinline__ void tilefft_pass2_body(const TileFftArgs& E, int bx, int r, int z_sig, c32* buf) {
     constexpr int RL = (R3 > 1) ? R3 : R2;
-    const int tid = threadIdx.x, r = blockIdx.y, bx = blockIdx.x;
+    const int tid = threadIdx.x;
     const TileIRow row = E.irows[r];
-    const c32* Yr = E.Y + ((int64_t)blockIdx.z * E.nrows + r) * E.L;
+    const c32* Yr = E.Y + ((int64_t)z_sig * E.nrows + r) * E.L;
     c32 z[PPT];
     {
         constexpr int NB = PPT / R1, STR = LA / R1;
@@ -206,7 +205,7 @@ __global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
         }
     }
     lds_ifft<LA, G, R1, R2, R3>(z, buf, E.ftw2, tid);
-    c32* u_out = E.U + row.ubase + (int64_t)blockIdx.z * row.sig_stride;
+    c32* u_out = E.U + row.ubase + (int64_t)z_sig * row.sig_stride;
     constexpr int NB = PPT / RL, STR = LA / RL;
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -214,6 +213,43 @@ __global__ __launch_bounds__(NT) void tilefft_pass2_kernel(TileFftArgs E) {
 #pragma unroll
         for (int k = 0; k < RL; ++k)
             u_out[(bx * G + g) + E.B * (u + k * STR)] = z[it * RL + k];
+    }
+}
+
+// all four-step classes of a launch group in one launch per pass (the shorter classes alone do not
+// fill the chip, and every launch has a tail): workgroup -> class by ranges, then (group, row, signal)
+struct TileFourArgs {
+    TileFftArgs E[10];
+    int first_block[11];     // workgroups before class c
+    int nx[10], slot[10];    // k1 / q2 groups per (row, signal); transform length = 64 << slot
+    int ncls;
+};
+template <int PASS>
+__global__ __launch_bounds__(NT) void tilefft_four_kernel(TileFourArgs A) {
+    __shared__ c32 buf[D_POINTS + 64];
+    int b = (int)blockIdx.x, c = 0;
+    while (c + 1 < A.ncls && b >= A.first_block[c + 1]) ++c;
+    b -= A.first_block[c];
+    const TileFftArgs& E = A.E[c];
+    const int nx = A.nx[c];
+    const int bx = b % nx, rz = b / nx, r = rz % E.nrows, z_sig = rz / E.nrows;
+    if (PASS == 1) {
+        switch (A.slot[c]) {
+            case 1: tilefft_pass1_body<128, 32, 16, 8, 1>(E, bx, r, z_sig, buf); break;
+            case 2: tilefft_pass1_body<256, 16, 16, 16, 1>(E, bx, r, z_sig, buf); break;
+            case 3: tilefft_pass1_body<512, 8, 8, 8, 8>(E, bx, r, z_sig, buf); break;
+            case 4: tilefft_pass1_body<1024, 4, 16, 8, 8>(E, bx, r, z_sig, buf); break;
+            default: tilefft_pass1_body<2048, 2, 16, 16, 8>(E, bx, r, z_sig, buf); break;
+        }
+    } else {
+        switch (A.slot[c]) {
+            case 0: tilefft_pass2_body<64, 64, 8, 8, 1>(E, bx, r, z_sig, buf); break;
+            case 1: tilefft_pass2_body<128, 32, 16, 8, 1>(E, bx, r, z_sig, buf); break;
+            case 2: tilefft_pass2_body<256, 16, 16, 16, 1>(E, bx, r, z_sig, buf); break;
+            case 3: tilefft_pass2_body<512, 8, 8, 8, 8>(E, bx, r, z_sig, buf); break;
+            case 4: tilefft_pass2_body<1024, 4, 16, 8, 8>(E, bx, r, z_sig, buf); break;
+            default: tilefft_pass2_body<2048, 2, 16, 16, 8>(E, bx, r, z_sig, buf); break;
+        }
     }
 }
 
@@ -861,7 +897,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         while (((int64_t)1 << lg) < cls[c].L) ++lg;
         if (own_fft && lg >= 13 && lg <= 22) {
             cls[c].B = 1 << ((lg + 1) / 2); cls[c].A = 1 << (lg / 2);
-            y_entries = std::max(y_entries, (int64_t)group * cls[c].nrows * cls[c].L);
+            y_entries += (int64_t)group * cls[c].nrows * cls[c].L;
         } else if (own_fft && lg >= 6 && lg <= 12) {
             cls[c].B = 1;                              // one-pass kernel
         }
@@ -936,17 +972,6 @@ void TilePlan::destroy() {
     counters = nullptr;
 }
 
-template <int LB, int G, int R1, int R2, int R3>
-static void launch_tilefft1(const TileFftArgs& E, int nsig, hipStream_t stream) {
-    hipLaunchKernelGGL((tilefft_pass1_kernel<LB, G, R1, R2, R3>), dim3((unsigned)(E.A / G), (unsigned)E.nrows, (unsigned)nsig),
-                       dim3(NT), 0, stream, E);
-}
-template <int LA, int G, int R1, int R2, int R3>
-static void launch_tilefft2(const TileFftArgs& E, int nsig, hipStream_t stream) {
-    hipLaunchKernelGGL((tilefft_pass2_kernel<LA, G, R1, R2, R3>), dim3((unsigned)(E.B / G), (unsigned)E.nrows, (unsigned)nsig),
-                       dim3(NT), 0, stream, E);
-}
-
 int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream) {
     // short classes: band -> samples, all of them in one launch (the longest rows first)
     {
@@ -974,37 +999,41 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
             SSQ_LAUNCH_CHECK();
         }
     }
-    // four-step classes: band -> samples in two kernels
-    for (size_t c = 0; c < cls.size(); ++c) {
-        if (!cls[c].A) continue;
-        TileFftArgs E;
-        E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
-        E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
-        E.Y = (c32*)Y; E.U = (c32*)U;
-        E.A = cls[c].A; E.B = cls[c].B; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows;
-        E.G2 = D_POINTS / E.A;                         // q2 columns per pass-2 workgroup
-        E.inv_l = 1.0f / (float)cls[c].L;
-        int sa = 0, sb = 0;                            // table slots: L' = 64 << slot
-        while ((64 << sa) < E.A) ++sa;
-        while ((64 << sb) < E.B) ++sb;
-        E.ftw1 = (const c32*)ftw + ftw_off[sb]; E.ftw2 = (const c32*)ftw + ftw_off[sa];
-        switch (sb) {                                  // B >= 128 (L >= 2^13, B >= A)
-            case 1: launch_tilefft1<128, 32, 16, 8, 1>(E, nsig, stream); break;
-            case 2: launch_tilefft1<256, 16, 16, 16, 1>(E, nsig, stream); break;
-            case 3: launch_tilefft1<512, 8, 8, 8, 8>(E, nsig, stream); break;
-            case 4: launch_tilefft1<1024, 4, 16, 8, 8>(E, nsig, stream); break;
-            default: launch_tilefft1<2048, 2, 16, 16, 8>(E, nsig, stream); break;
+    // four-step classes: band -> samples, one launch per pass for all of them (the longest first)
+    {
+        TileFourArgs F1, F2;
+        F1.ncls = 0; F1.first_block[0] = 0; F2.first_block[0] = 0;
+        int64_t y_off = 0;
+        for (size_t c = 0; c < cls.size() && F1.ncls < 10; ++c) {       // (classes come longest first)
+            if (!cls[c].A) continue;
+            const int k = F1.ncls;
+            TileFftArgs E;
+            E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
+            E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
+            E.Y = (c32*)Y + y_off; E.U = (c32*)U;
+            y_off += (int64_t)group * cls[c].nrows * cls[c].L;
+            E.A = cls[c].A; E.B = cls[c].B; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows;
+            E.G2 = D_POINTS / E.A;                         // q2 columns per pass-2 workgroup
+            E.inv_l = 1.0f / (float)cls[c].L;
+            int sa = 0, sb = 0;                            // table slots: L' = 64 << slot
+            while ((64 << sa) < E.A) ++sa;
+            while ((64 << sb) < E.B) ++sb;
+            E.ftw1 = (const c32*)ftw + ftw_off[sb]; E.ftw2 = (const c32*)ftw + ftw_off[sa];
+            F1.E[k] = E; F2.E[k] = E;
+            F1.slot[k] = sb; F2.slot[k] = sa;
+            F1.nx[k] = E.A / (D_POINTS / E.B);             // k1 groups: G = 4096 / B columns each
+            F2.nx[k] = E.B / E.G2;
+            F1.first_block[k + 1] = F1.first_block[k] + F1.nx[k] * E.nrows * nsig;
+            F2.first_block[k + 1] = F2.first_block[k] + F2.nx[k] * E.nrows * nsig;
+            ++F1.ncls;
         }
-        SSQ_LAUNCH_CHECK();
-        switch (sa) {
-            case 0: launch_tilefft2<64, 64, 8, 8, 1>(E, nsig, stream); break;
-            case 1: launch_tilefft2<128, 32, 16, 8, 1>(E, nsig, stream); break;
-            case 2: launch_tilefft2<256, 16, 16, 16, 1>(E, nsig, stream); break;
-            case 3: launch_tilefft2<512, 8, 8, 8, 8>(E, nsig, stream); break;
-            case 4: launch_tilefft2<1024, 4, 16, 8, 8>(E, nsig, stream); break;
-            default: launch_tilefft2<2048, 2, 16, 16, 8>(E, nsig, stream); break;
+        F2.ncls = F1.ncls;
+        if (F1.ncls) {
+            hipLaunchKernelGGL(tilefft_four_kernel<1>, dim3((unsigned)F1.first_block[F1.ncls]), dim3(NT), 0, stream, F1);
+            SSQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(tilefft_four_kernel<2>, dim3((unsigned)F2.first_block[F2.ncls]), dim3(NT), 0, stream, F2);
+            SSQ_LAUNCH_CHECK();
         }
-        SSQ_LAUNCH_CHECK();
     }
     if (!n_irows_fft) return 0;
     int64_t lmax_fft = 0;

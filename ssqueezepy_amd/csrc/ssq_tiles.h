@@ -52,7 +52,7 @@ struct TilePlan {
     std::vector<Cls> cls;
     std::vector<FftPlan> ffts;              // one batched inverse per class (unused for four-step classes)
     int n_irows_fft = 0, first_irow_fft = 0;   // rows of the rocFFT classes (the spectra kernel's)
-    void* Y = nullptr;                      // four-step intermediate of the largest class (group x rows x L)
+    void* Y = nullptr;                      // four-step intermediates, class after class (group x rows x L each)
     void* ftw = nullptr;                    // e^{2 pi i q / L'}, L' = 64 .. 4096, concatenated
     int64_t ftw_off[7] = {0, 0, 0, 0, 0, 0, 0};
     int64_t n_items_tile[5] = {0, 0, 0, 0, 0};
