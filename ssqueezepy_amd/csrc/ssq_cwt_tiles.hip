@@ -1,14 +1,19 @@
 // ssq_cwt_tiles.hip -- the column-tile path of the fused ssq_cwt form (float32, gfx950).
 //
-// Math and planning: ssqueezepy_amd/_tiles.py. Two kernels:
+// Math and planning: ssqueezepy_amd/_tiles.py. The kernels:
 //
-//   tile_spectra_kernel   band of row i (K bins around bin kc of the M-grid) x spectrum of the
-//                         padded signal x compensated bank value -> baseband spectrum of
-//                         length L = M / R, zero outside the band; one batched rocFFT inverse
-//                         per decimation class turns it into the samples u_i[q] (plan-owned
-//                         intermediate, ~34 MB per signal at N=160k: L2 / Infinity-Cache food).
+//   tilefft_*             the intermediates: band of row i (K bins around bin kc of the M-grid) x
+//                         spectrum of the padded signal x compensated bank value, inverse FFT of
+//                         length L = M / R (R: the row's decimation) -> the samples u_i[q]
+//                         (plan-owned, ~34 MB per signal at N=160k). Classes of 64 .. 4096 entries:
+//                         `tilefft_small_kernel` (one LDS transform per row, G rows per
+//                         workgroup); classes of 2^13 .. 2^22 entries: `tilefft_four_kernel<1 / 2>`,
+//                         a four-step transform whose first pass forms the band on the fly (the
+//                         zero-padded spectrum never exists in memory). Three launches per launch
+//                         group for all classes. `tile_spectra_kernel` + a batched rocFFT inverse
+//                         per class is the older route (SSQ_TILE_FFT=rocfft).
 //
-//   tile_kernel           one persistent workgroup per CU (16 wavefronts, 4 per SIMD) walks
+//   tile_kernel           one persistent workgroup per CU (12 wavefronts, 3 per SIMD) walks
 //                         64-column tiles of one signal after the other. The 64 columns x na bins
 //                         of the tile's Tx live in LDS (which is why there is one workgroup per
 //                         CU); lane = column. The steps (4 consecutive rows) of all tiles are
@@ -37,8 +42,9 @@
 //                         against 320): a single wavefront issues a dependent instruction every
 //                         8-10 cycles, so a serial stream of ~100 instructions per step cannot keep
 //                         up with fifteen producers. What that round kept from it: loads issued
-//                         unconditionally so that the compiler's wait counts stay static, 16
-//                         wavefronts at 128 registers, the float64-weight fold, one step per ticket.
+//                         unconditionally so that the compiler's wait counts stay static, the
+//                         float64-weight fold, one step per ticket. Everything else that was
+//                         measured and dropped: DESIGN.md section 4.8, profiles/r3_ab_history.txt.
 //
 // Compiled with -ffp-contract=off (bin indices); multiply-adds that may fuse are written as
 // explicit fmaf so every instantiation rounds identically.
