@@ -36,5 +36,7 @@ def __getattr__(name):
     if name in _lazy:
         import importlib
         mod = importlib.import_module('.' + _lazy[name], __name__)
-        return getattr(mod, name)
+        obj = getattr(mod, name)
+        globals()[name] = obj          # later look-ups find it directly (the import costs ~5 us per call)
+        return obj
     raise AttributeError("module %r has no attribute %r" % (__name__, name))
