@@ -180,3 +180,22 @@ def test_admissibility_and_bounds_sweeps():
     for N in (4096, 2048, 1024, 512, 256, 128, 64):
         smin, smax = cwt_scalebounds(wavelet, N=N)
         assert 0 < smin < smax
+
+
+@pytest.mark.parametrize('family', ['gmw', 'morlet', 'bump', 'cmhat', 'hhhat'])
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_bank_evaluation_in_pieces(family, dtype, monkeypatch):
+    """Large banks are evaluated in contiguous pieces on a thread pool (`_bank._evaluate`): the
+    values must be the ones a single call gives, bit for bit (they define the transform)."""
+    from ssqueezepy_amd import _bank
+    from ssqueezepy_amd.wavelets import Wavelet
+    from ssqueezepy_amd.scales import process_scales
+    N, M = 6000, 16384
+    wav = Wavelet((family, {'dtype': dtype}))
+    sc = np.asarray(process_scales('log', N, wav, nv=16), dtype=dtype).reshape(-1)
+    whole = _bank.banded_bank(wav, sc, M)
+    monkeypatch.setattr(_bank, '_PAR_MIN', 1 << 10)        # pieces of a few hundred values, odd edges
+    pieces = _bank.banded_bank(wav, sc, M)
+    assert len(whole[0]) > (1 << 12)
+    assert np.array_equal(whole[0].view(np.uint8), pieces[0].view(np.uint8))
+    assert np.array_equal(whole[1], pieces[1]) and np.array_equal(whole[2], pieces[2])
