@@ -3,6 +3,7 @@
 #pragma once
 #include "ssq_common.h"
 #include "ssq_fft.h"
+#include "ssq_tiles.h"
 #include <algorithm>
 #include <vector>
 
@@ -48,7 +49,8 @@ struct BlockPlan {
     // analytic signal of the padded batch (classes with analytic = 1): one-sided spectrum ->
     // length-M inverse transform, in place
     void* xa = nullptr;
-    FftPlan inv_m;
+    FftPlan inv_m;                   // rocFFT route (float64, or M outside the four-step kernels' range)
+    AnalyticFft* ana = nullptr;      // four-step kernels of ssq_cwt_tiles.hip (float32)
     int n_analytic = 0;
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take

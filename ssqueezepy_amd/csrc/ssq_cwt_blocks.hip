@@ -704,9 +704,14 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
     }
     if (n_analytic) {
         SSQ_CHECK_HIP(hipMalloc(&xa, 2 * rs * (size_t)(max_batch * M))); bytes += 2 * rs * max_batch * M;
-        rc = inv_m.create(1, dtype, (size_t)M, (size_t)max_batch, 1.0 / (double)M);
-        if (rc) return rc;
-        bytes += (int64_t)inv_m.work_bytes;
+        if (AnalyticFft::supports(dtype, M)) {
+            ana = new AnalyticFft();
+            if ((rc = ana->create(M, max_batch, bytes))) return rc;
+        } else {
+            rc = inv_m.create(1, dtype, (size_t)M, (size_t)max_batch, 1.0 / (double)M);
+            if (rc) return rc;
+            bytes += (int64_t)inv_m.work_bytes;
+        }
     }
     n_generic = d.n_generic;
     return 0;
@@ -715,6 +720,7 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
 void BlockPlan::destroy() {
     for (auto& f : ffts) f.destroy();
     inv_m.destroy();
+    if (ana) { ana->destroy(); delete ana; ana = nullptr; }
     void* ptrs[] = {xa, twM, zbuf, classes, rows, pbank, pxi, ctw, ftw, xb, blocks, items[0], items[1], items[2],
                     items[3], items[4]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -753,14 +759,19 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
         } else {
             // the analytic signal of every padded signal first
             SSQ_REQUIRE(xh && xa, "analytic block classes need the half spectrum");
-            dim3 ga((unsigned)std::min<int64_t>((max_batch * M + 255) / 256, 4096));
-            if (dtype == SSQ_F32)
-                hipLaunchKernelGGL(analytic_spectrum_kernel<c32>, ga, dim3(256), 0, stream, (const c32*)xh, (c32*)xa, M, max_batch);
-            else
-                hipLaunchKernelGGL(analytic_spectrum_kernel<c64>, ga, dim3(256), 0, stream, (const c64*)xh, (c64*)xa, M, max_batch);
-            SSQ_LAUNCH_CHECK();
-            int rc = inv_m.execute(xa, nullptr, stream);
-            if (rc) return rc;
+            if (ana) {
+                int rc = ana->run(xh, xa, max_batch, stream);
+                if (rc) return rc;
+            } else {
+                dim3 ga((unsigned)std::min<int64_t>((max_batch * M + 255) / 256, 4096));
+                if (dtype == SSQ_F32)
+                    hipLaunchKernelGGL(analytic_spectrum_kernel<c32>, ga, dim3(256), 0, stream, (const c32*)xh, (c32*)xa, M, max_batch);
+                else
+                    hipLaunchKernelGGL(analytic_spectrum_kernel<c64>, ga, dim3(256), 0, stream, (const c64*)xh, (c64*)xa, M, max_batch);
+                SSQ_LAUNCH_CHECK();
+                int rc = inv_m.execute(xa, nullptr, stream);
+                if (rc) return rc;
+            }
             if (dtype == SSQ_F32)
                 hipLaunchKernelGGL((gather_blocks_kernel<c32, true>), grid, dim3(256), 0, stream, (const c32*)xa,
                                    (c32*)xb, classes + lo[1], M, n1, max_batch);

@@ -131,6 +131,7 @@ struct TileFftArgs {
     c32* Y; c32* U;
     const c32* ftw1; const c32* ftw2;  // e^{2 pi i q / B}, e^{2 pi i q / A}
     int A, B, L, G2, nrows;
+    int nyq;                           // 1: bin L / 2 counts as +L / 2 (a one-sided spectrum up to Nyquist)
     float inv_l;
 };
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ void tilefft_pass1_body(const TileFftArgs& E, int bx,
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
                 const int p = (c0 + g) + E.A * (u + k * STR);       // baseband bin, as tile_spectra_kernel
-                const int kk = p < half ? p : p - E.L;
+                const int kk = (p < half || (E.nyq && p == half)) ? p : p - E.L;
                 const int t = row.kc + kk - row.lo;
                 c32 v = {0.f, 0.f};
                 if (t >= 0 && t < row.K) {
@@ -993,7 +994,7 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
                 E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = sig;
                 E.irows = irows + cls[c].first; E.tbank = (const float*)tbank;
                 E.Y = nullptr; E.U = (c32*)U;
-                E.A = 0; E.B = 0; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows; E.G2 = 0; E.inv_l = 0.f;
+                E.A = 0; E.B = 0; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows; E.G2 = 0; E.inv_l = 0.f; E.nyq = 0;
                 E.ftw1 = (const c32*)ftw + ftw_off[sl]; E.ftw2 = nullptr;
                 const int G = D_POINTS / (int)cls[c].L, npairs = E.nrows * nsig;
                 S.npairs[S.ncls] = npairs; S.slot[S.ncls] = sl;
@@ -1020,7 +1021,7 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
             y_off += (int64_t)group * cls[c].nrows * cls[c].L;
             E.A = cls[c].A; E.B = cls[c].B; E.L = (int)cls[c].L; E.nrows = (int)cls[c].nrows;
             E.G2 = D_POINTS / E.A;                         // q2 columns per pass-2 workgroup
-            E.inv_l = 1.0f / (float)cls[c].L;
+            E.inv_l = 1.0f / (float)cls[c].L; E.nyq = 0;
             int sa = 0, sb = 0;                            // table slots: L' = 64 << slot
             while ((64 << sa) < E.A) ++sa;
             while ((64 << sb) < E.B) ++sb;
@@ -1054,6 +1055,73 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
         int rc = ffts[c].execute((float2*)U + (size_t)group * cls[c].upre, nullptr, stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+// ---- the analytic signal through the four-step kernels (ssq_tiles.h)
+bool AnalyticFft::supports(int dtype, int64_t M) {
+    if (dtype != SSQ_F32 || (M & (M - 1))) return false;
+    if (getenv("SSQ_TILE_FFT") && !strcmp(getenv("SSQ_TILE_FFT"), "rocfft")) return false;
+    return M >= ((int64_t)1 << 13) && M <= ((int64_t)1 << 22);
+}
+int AnalyticFft::create(int64_t M_, int64_t max_batch_, int64_t& bytes) {
+    M = M_; max_batch = max_batch_;
+    int lg = 0;
+    while (((int64_t)1 << lg) < M) ++lg;
+    B = 1 << ((lg + 1) / 2); A = 1 << (lg / 2);
+    auto up = [&](void** dst, const void* src, size_t nbytes) -> int {
+        SSQ_CHECK_HIP(hipMalloc(dst, nbytes));
+        SSQ_CHECK_HIP(hipMemcpy(*dst, src, nbytes, hipMemcpyHostToDevice));
+        bytes += (int64_t)nbytes;
+        return 0;
+    };
+    int rc;
+    std::vector<float> tw;
+    for (int which = 0; which < 2; ++which) {
+        const int Lp = which ? B : A;
+        (which ? off_b : off_a) = (int64_t)tw.size() / 2;
+        for (int q = 0; q < Lp; ++q) {
+            const double a = 6.283185307179586 * (double)q / (double)Lp;
+            tw.push_back((float)std::cos(a)); tw.push_back((float)std::sin(a));
+        }
+    }
+    if ((rc = up(&ftw, tw.data(), tw.size() * 4))) return rc;
+    // weights: 1 / M on bins [0, M / 2), half of it at the Nyquist bin (both exact: M is a power of two)
+    std::vector<float> w((size_t)(M / 2 + 1), 1.0f / (float)M);
+    w[(size_t)(M / 2)] = 0.5f / (float)M;
+    if ((rc = up(&tb, w.data(), w.size() * 4))) return rc;
+    const TileIRow r = {0, 0, (int32_t)(M / 2 + 1), 0, (int32_t)M, 0, 0, (int32_t)M};
+    if ((rc = up((void**)&irow, &r, sizeof(r)))) return rc;
+    SSQ_CHECK_HIP(hipMalloc(&Y, (size_t)8 * max_batch * M)); bytes += 8 * max_batch * M;
+    return 0;
+}
+void AnalyticFft::destroy() {
+    void* ptrs[] = {Y, ftw, tb, irow};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    Y = ftw = tb = nullptr; irow = nullptr;
+}
+int AnalyticFft::run(const void* xh_all, void* xa, int64_t batch, hipStream_t stream) {
+    TileFourArgs F;
+    F.ncls = 1; F.first_block[0] = 0;
+    TileFftArgs& E = F.E[0];
+    E.xh = (const c32*)xh_all; E.xh_stride = M / 2 + 1; E.sig0 = 0;
+    E.irows = irow; E.tbank = (const float*)tb;
+    E.Y = (c32*)Y; E.U = (c32*)xa;
+    E.A = A; E.B = B; E.L = (int)M; E.nrows = 1; E.G2 = D_POINTS / A; E.nyq = 1;
+    E.inv_l = 1.0f / (float)M;
+    E.ftw1 = (const c32*)ftw + off_b; E.ftw2 = (const c32*)ftw + off_a;
+    int sa = 0, sb = 0;
+    while ((64 << sa) < A) ++sa;
+    while ((64 << sb) < B) ++sb;
+    TileFourArgs F2 = F;
+    F.slot[0] = sb; F.nx[0] = A / (D_POINTS / B);
+    F.first_block[1] = F.nx[0] * (int)batch;
+    F2.slot[0] = sa; F2.nx[0] = B / E.G2;
+    F2.first_block[1] = F2.nx[0] * (int)batch;
+    hipLaunchKernelGGL(tilefft_four_kernel<1>, dim3((unsigned)F.first_block[1]), dim3(NT), 0, stream, F);
+    SSQ_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tilefft_four_kernel<2>, dim3((unsigned)F2.first_block[1]), dim3(NT), 0, stream, F2);
+    SSQ_LAUNCH_CHECK();
     return 0;
 }
 

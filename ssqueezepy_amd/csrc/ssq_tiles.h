@@ -32,6 +32,21 @@ struct TileIRow {
     int32_t sig_stride;
 };
 
+// The analytic signal of the padded batch (block classes with analytic = 1, ssq_blocks.h) through the
+// four-step kernels of ssq_cwt_tiles.hip: one-sided spectrum formed on the fly from the half spectrum
+// (Nyquist bin halved, 1 / M folded in) -> length-M inverse transform. float32, M = 2^13 .. 2^22;
+// replaces a spectrum kernel + rocFFT's two or three kernels.
+struct AnalyticFft {
+    int64_t M = 0, max_batch = 0;
+    int A = 0, B = 0;
+    void* Y = nullptr; void* ftw = nullptr; void* tb = nullptr; TileIRow* irow = nullptr;
+    int64_t off_a = 0, off_b = 0;           // twiddle tables e^{2 pi i q / A}, e^{2 pi i q / B} inside ftw
+    static bool supports(int dtype, int64_t M);
+    int create(int64_t M, int64_t max_batch, int64_t& bytes);
+    void destroy();
+    int run(const void* xh_all, void* xa, int64_t batch, hipStream_t stream);
+};
+
 struct TilePlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0;
     int group = 1;
