@@ -36,3 +36,27 @@ def test_reference_kernel_tests_through_the_c_abi():
     # every bound entry was reached by the reference's tests
     for name in rec['installed']:
         assert rec['calls'].get(name, 0) > 0, (name, rec['calls'])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'ssqueezepy')), reason="needs the reference checkout")
+def test_nyquist_rows_against_the_reference_itself():
+    """`cwt` of the reference's own CPU path against this package (kernels under the emulator) where
+    the block path is active and the rows cut by the Nyquist bin run over the analytic signal
+    (_blocks.extend_past_nyquist): 1e-5 / 1e-12 of the reference's maximum, the continued rows too."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import emu_backend
+    if not emu_backend.available():
+        pytest.skip("needs ROCm's clang++ for the emulated library")
+    emu_backend.build()
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'oracle', 'refshim'), REF]),
+               SSQ_GPU='0', MPLBACKEND='Agg')
+    env.pop('SSQ_CWT_NYQ_EXT', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'refbinding', 'cwt_vs_reference.py')],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(rec) == 3
+    for r in rec:
+        tol = 1e-5 if r['dtype'] == 'float32' else 1e-12
+        assert r['scales_equal'] and r['extended_rows'] >= 3 and 'fourstep' not in r['algo'], r
+        assert r['eW'] <= tol and r['eD'] <= tol and r['eW_extended'] <= tol, r
