@@ -120,3 +120,22 @@ def test_adaptive_margins_match_the_full_length_measurement():
     d = (fast - plain)[~nyq]
     # never short by more than the slack the classes have anyway, never long by > 2 %
     assert d.min() >= -2 and np.all(d <= 0.02 * plain[~nyq] + 8)
+
+
+def test_margins_of_rows_continued_past_nyquist():
+    """The rows continued past the Nyquist bin are measured on the adaptive grids like any other wide
+    band: against the plain full-length measurement of the same (continued) band, and they come out
+    compact (tens of samples) where the cut rows themselves never do."""
+    N, nv = 20000, 16
+    vals, off, lo, M, n1, v64 = _bank(N, nv, 'float32')
+    fn, scales, w_hi = _extension(N, nv, 'float32')
+    vx, ox, v64x, ext = _blocks.extend_past_nyquist(fn, scales, w_hi, vals, off, lo, M, v64)
+    assert ext.sum() >= 5 and np.array_equal(ext, (lo + np.diff(off)) == M // 2 + 1)
+    fast = _blocks._margins(v64x, ox, lo, M, 1e-9, extended=ext)
+    plain = _margins_plain(v64x, ox, lo, M, 1e-9)
+    d = (fast - plain)[ext]
+    assert d.min() >= -2 and np.all(d <= 0.02 * plain[ext] + 8), (fast[ext], plain[ext])
+    assert fast[ext].max() <= 128                      # fits the shortest block class (P = 4096, margin P / 32)
+    # the same rows as the reference cuts them: response ~ 1 / t, no margin below M / 4 at 1e-9
+    cut = _margins_plain(v64, off, lo, M, 1e-9)
+    assert cut[ext].min() > M // 8
