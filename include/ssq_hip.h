@@ -321,6 +321,11 @@ int  ssq_cwt_plan_group(const ssq_cwt_plan* plan);
  * adds nothing. (Tests assert on this rather than on the plan's `algo` label.) */
 int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
 
+/* Rows per step the tile kernel of this build walks (4; the host tables of
+ * ssq_cwt_plan_set_tiles must be built for the same number: `rows` holds that many records per
+ * step). */
+int  ssq_cwt_tile_rows_per_step(void);
+
 /* bytes of device memory held by the plan (bank + workspace) */
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* plan);
 /* name of the compute path the plan selected ("rocfft", "zoom+rocfft", ...) */

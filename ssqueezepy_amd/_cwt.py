@@ -175,6 +175,10 @@ class CwtPlan():
         segs, rws = c(tp['segs'], np.int32), c(tp['rows'], np.int32)
         wtab, tbank = c(tp['wtab'], np.float32), c(tp['tbank'], np.float32)
         irows, classes = c(tp['irows'], np.int64), c(tp['classes'], np.int64)
+        if self.lib.ssq_cwt_tile_rows_per_step() != _tiles_rsub:
+            raise RuntimeError("tile tables built for %d rows per step, the library walks %d "
+                               "(SSQ_TILE_RSUB goes with a -DSSQ_TILE_G build)"
+                               % (_tiles_rsub, self.lib.ssq_cwt_tile_rows_per_step()))
         d = CwtTilesDesc()
         d.n_segs, d.segs = len(segs), segs.ctypes.data
         d.n_steps, d.rows = len(rws) // _tiles_rsub, rws.ctypes.data

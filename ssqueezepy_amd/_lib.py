@@ -114,6 +114,7 @@ _PROTOS = {
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
+    'ssq_cwt_tile_rows_per_step': (c_int, []),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),
     'ssq_stft_plan_destroy': (None, [c_void_p]),
     'ssq_stft_plan_set_ssq': (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double),

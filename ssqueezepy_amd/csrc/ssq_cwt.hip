@@ -356,6 +356,7 @@ int ssq_cwt_plan_timing(ssq_cwt_plan* pl, int enable, double* stage_ms, int64_t*
 }
 
 int ssq_cwt_plan_group(const ssq_cwt_plan* pl) { return pl ? pl->group : 0; }
+int ssq_cwt_tile_rows_per_step(void) { return ssq::tile_rows_per_step(); }
 int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* pl, void* stream) {
     if (!pl || !pl->tile) return 0;
     return pl->tile->tiles_done(as_stream(stream));

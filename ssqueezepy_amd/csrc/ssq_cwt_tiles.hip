@@ -829,6 +829,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
 }
 
 // ---------------------------------------------------------------------------- host side
+int tile_rows_per_step() { return TILE_G; }
 int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_, int group_,
                      double dt_, int64_t& bytes) {
     M = M_; N = N_; n1 = n1_; na = na_; group = group_; dt = dt_;

@@ -47,6 +47,8 @@ struct AnalyticFft {
     int run(const void* xh_all, void* xa, int64_t batch, hipStream_t stream);
 };
 
+int tile_rows_per_step();               // TILE_G of ssq_cwt_tiles.hip
+
 struct TilePlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0;
     int group = 1;
