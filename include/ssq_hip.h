@@ -45,7 +45,7 @@ extern "C" {
 #define SSQ_PAD_WRAP 4
 
 /* ------------------------------------------------------------------ runtime */
-int         ssq_version(void);          /* 101 (100: block classes without the `analytic` column) */
+int         ssq_version(void);          /* 102 (101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
 const char* ssq_last_error(void);
 int         ssq_device_count(int* count);
 int         ssq_set_device(int device);
@@ -315,11 +315,17 @@ int  ssq_cwt_plan_timing(ssq_cwt_plan* plan, int enable, double* stage_ms, int64
  * groups of this size) */
 int  ssq_cwt_plan_group(const ssq_cwt_plan* plan);
 
-/* What executed: the number of 64-column tiles the column-tile kernel has finished on this
- * plan since its creation (0 without tile tables). Synchronises `stream`. An execute that took
- * the tile path adds batch * ceil(n / 64); one that took the block path + separate reassignment
- * adds nothing. (Tests assert on this rather than on the plan's `algo` label.) */
+/* What executed: the number of column tiles the column-tile kernel has finished on this plan
+ * since its creation (0 without tile tables). Synchronises `stream`. An execute that took the
+ * tile path adds batch * ceil(n / ssq_cwt_plan_tile_cols(plan)); one that took the block path +
+ * separate reassignment adds nothing. (Tests assert on this rather than on the plan's `algo`
+ * label.) */
 int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
+/* Columns per tile of the kernel the next execute launches: 32 or 16 (float64 tile in LDS,
+ * unordered ds_add_f64 accumulation -- the default), 64 with SSQ_TILE_ORDER=ordered in the
+ * environment (float32 tile, terms added in the reference's row order; na <= 318). 0 without
+ * tile tables. */
+int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
 
 /* Rows per step the tile kernel of this build walks (4; the host tables of
  * ssq_cwt_plan_set_tiles must be built for the same number: `rows` holds that many records per

@@ -207,9 +207,18 @@ class CwtPlan():
         return self.lib.ssq_cwt_plan_algo(self._h).decode()
 
     def tiles_done(self):
-        """64-column tiles the column-tile kernel has finished on this plan so far (what
-        actually executed, as opposed to what `algo` says was planned); synchronises."""
+        """Column tiles (`tile_cols` columns each) the column-tile kernel has finished on this
+        plan so far (what actually executed, as opposed to what `algo` says was planned);
+        synchronises."""
         return int(self.lib.ssq_cwt_plan_tiles_done(self._h, algos.stream()))
+
+    @property
+    def tile_cols(self):
+        """columns per tile of the tile kernel the next execute launches (0: no tile path)"""
+        return int(self.lib.ssq_cwt_plan_tile_cols(self._h))
+
+    def tiles_per_signal(self, N):
+        return -(-int(N) // self.tile_cols) if self.tile_cols else 0
 
     @property
     def device_bytes(self):

@@ -114,6 +114,7 @@ _PROTOS = {
     'ssq_cwt_plan_bytes': (c_int64, [c_void_p]),
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
+    'ssq_cwt_plan_tile_cols': (c_int, [c_void_p]),
     'ssq_cwt_tile_rows_per_step': (c_int, []),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),
     'ssq_stft_plan_destroy': (None, [c_void_p]),
@@ -128,7 +129,7 @@ EXPORTS = tuple(_PROTOS)
 _lib = None
 
 
-ABI_VERSION = 101     # include/ssq_hip.h: ssq_version()
+ABI_VERSION = 102     # include/ssq_hip.h: ssq_version()
 
 
 def load(build_if_missing=True):
@@ -148,14 +149,17 @@ def load(build_if_missing=True):
         raise SsqError("cannot load %s: %s. The ssqueezepy_amd compute path has no "
                        "CPU fallback; it needs the ROCm runtime (libamdhip64, "
                        "librocfft)." % (LIB_PATH, e))
+    # the version first: an older build lacks entry points, and the loop below would stop at the
+    # first missing one with a bare AttributeError
+    lib.ssq_version.restype, lib.ssq_version.argtypes = c_int, []
+    if lib.ssq_version() < ABI_VERSION:
+        raise SsqError("%s is an older build (ABI %d, this package needs %d); rebuild with "
+                       "`python -m ssqueezepy_amd.build`"
+                       % (LIB_PATH, lib.ssq_version(), ABI_VERSION))
     for name, (res, args) in _PROTOS.items():
         fn = getattr(lib, name)       # AttributeError here = ABI/header mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.ssq_version() < ABI_VERSION:
-        raise SsqError("%s is an older build (ABI %d, this package needs %d: the layout of "
-                       "ssq_cwt_blocks_desc changed); rebuild with `python -m ssqueezepy_amd.build`"
-                       % (LIB_PATH, lib.ssq_version(), ABI_VERSION))
     _lib = lib
     return lib
 

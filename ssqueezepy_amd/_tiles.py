@@ -49,7 +49,10 @@ SIGMA_MIN = 2.0       # least oversampling of a decimated row
 R_MIN = 4             # least decimation for which a row leaves the block kernels
 R_MAX = 4096
 L_MINLEN = 64         # shortest decimated row
-COLS = 64             # columns per workgroup of the tile kernel (one per lane)
+COLS = 64             # columns per workgroup of the ordered tile kernel (one per lane)
+NA_MAX = 512          # rows: a packed record holds 9 bits of row; the float64 tile of the default
+                      # kernel (16 B per cell) takes 32 columns up to 318 rows, 16 columns beyond
+                      # (the ordered kernel, SSQ_TILE_ORDER=ordered, stops at 318 rows)
 RSUB = int(__import__('os').environ.get('SSQ_TILE_RSUB', '4'))   # rows per step (TILE_G of the kernel; the
                       # environment override pairs with an A/B build -DSSQ_TILE_G=n)
 STEPS_PER_TICKET = 1  # (steps are handed out one at a time)
@@ -99,8 +102,8 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
     plus `interp_rows` (bool mask)."""
     na = len(lo)
     lens = np.diff(off).astype(np.int64)
-    if M & (M - 1) or M > 2 ** 23 or (na + 1) * COLS * 8 + 16 > 160 * 1024 or na * N >= 2 ** 29:
-        return None                              # the Tx tile must fit one CU's LDS
+    if M & (M - 1) or M > 2 ** 23 or na >= NA_MAX or na * N >= 2 ** 29:
+        return None                              # the Tx tile must fit one CU's LDS (see NA_MAX)
     lgR = np.full(na, -1, np.int64)
     for i in range(na):
         K = int(lens[i])

@@ -67,7 +67,9 @@ constexpr int TILE_G = SSQ_TILE_G;   // rows per step (the host's RSUB, _tiles.p
 constexpr int TILE_W = 8;         // taps
 constexpr int TILE_NOBIN = 0xFFFF;
 // tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
-// only), 4 = no arithmetic, 8 = no priorities
+// only), 4 = no arithmetic, 8 = no priorities, 32 = taps without the cross-lane gather, 64 = no
+// modulation, 128 = no bin arithmetic, 256 = no Wx store (round 4: none of 32 .. 128 changes the
+// kernel's time, 256 takes 25 us off -- profiles/r4_ab_history.txt)
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
@@ -401,12 +403,12 @@ __device__ __forceinline__ int exact_bin(float2 W, float2 D, const SsqParams& sp
 }
 
 // trace (tuning aid): [wavefront][step slot < 128][4 stamps], then 64 extra words
-constexpr int TRACE_STEPS = 128, TRACE_WORDS = 16 * TRACE_STEPS * 4 + 64;
+constexpr int TRACE_STEPS = 128, TRACE_K = 8, TRACE_WORDS = 16 * TRACE_STEPS * TRACE_K + 64;
 // (compiled in with -DSSQ_TILE_TRACE_BUILD, tools/ab_build.sh: the stamps cost registers)
 #ifdef SSQ_TILE_TRACE_BUILD
 #define TILE_STAMP(on, wave, j, k)                                                               \
     do { if (tr && (on) && (j) < TRACE_STEPS && c == 0)                                        \
-             tr[((size_t)(wave) * TRACE_STEPS + (j)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+             tr[((size_t)(wave) * TRACE_STEPS + (j)) * TRACE_K + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TILE_STAMP(on, wave, j, k) do { (void)(on); } while (0)
 #endif
@@ -665,10 +667,13 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
         constexpr int b = decltype(BB)::value;
         const int col = q.tx * TILE_COLS + c;
         const int nabs = A.n1 + (col < (int)N ? col : (int)N - 1);
-        const float4* wp = A.wtab + (int64_t)(xwoff[b] + (nabs & xmask[b])) * 4;
+        // (the table is stored tap pair by tap pair, [4][R] float4 per class: the 64 lanes of a load
+        // read one run of consecutive phases, not 64 separate 64-byte rows)
+        const float4* wp = A.wtab + (int64_t)xwoff[b] * 4 + (nabs & xmask[b]);
+        const int wstride = xmask[b] + 1;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 v = wp[t];
+            const float4 v = wp[t * wstride];
             wt[2 * t].x = v.x; wt[2 * t].y = v.y; wt[2 * t + 1].x = v.z; wt[2 * t + 1].y = v.w;
         }
     };
@@ -728,9 +733,14 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     // (a, a') = sum_t (phi_t, phi'_t) u[q0 - 3 + t]  (baseband): real and imaginary
                     // parts as two packed accumulators (a_re, a'_re), (a_im, a'_im)
                     ssq_f2 are2, aim2;
+                    if (r == 0) TILE_STAMP(trk, wv, pc.st, 4);
                     {
                         int fr[TILE_W], fi[TILE_W];
                         const int ur = __float_as_int(xu[b][r].x), ui = __float_as_int(xu[b][r].y);
+#if SSQ_TILE_EXP & 32
+#pragma unroll
+                        for (int t = 0; t < TILE_W; ++t) { fr[t] = ur + t * baddr; fi[t] = ui ^ (t * baddr); }
+#else
                         SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
                         SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
                         SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
@@ -740,6 +750,8 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                         SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
                         SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                         SSQ_LDS_WAIT();
+#endif
+                        if (r == 0) TILE_STAMP(trk, wv, pc.st, 5);
 #pragma unroll
                         for (int t = 0; t < TILE_W; ++t) {
                             ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
@@ -765,16 +777,24 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     // (M <= 2^24, checked by the host), v_sin_f32 / v_cos_f32 take revolutions (measured on
                     // the M = 2^18 circle: max abs error 1.2e-7, as good as a float table)
                     const float rev = (float)(__umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;   // (both < 2^24: full-rate multiply)
+#if SSQ_TILE_EXP & 64
+                    const float2 Wv = make_float2(are + rev, aim), Dv = make_float2(dre, dim);
+#else
                     const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
                     const float2 Wv = cmulf(tw, make_float2(are, aim));
                     const float2 Dv = cmulf(tw, make_float2(dre, dim));
+#endif
                     // (rows that only pad a step repeat the previous row -- same address, same value --
                     // and lanes past the last column repeat its point; neither contributes below)
                     const bool pad = (xrow >> 9) & 1;
                     const size_t rowoff = (size_t)((unsigned)xrow & 0x1FFu) * (nN * 8u);   // wave-uniform
-                    *reinterpret_cast<float2*>(Wx8 + rowoff + colc8) = Wv;
+                    if (!(SSQ_TILE_EXP & 256) || Wv.x == 123.456f) *reinterpret_cast<float2*>(Wx8 + rowoff + colc8) = Wv;
                     if (STORE_D) *reinterpret_cast<float2*>(dWx8 + rowoff + colc8) = Dv;
                     // phase transform and bin: as emit_point<LEAN> of the block kernels
+#if SSQ_TILE_EXP & 128
+                    int kout = (int)((unsigned)xrow & 0x1FFu);
+                    if (Dv.x == 123.456f) kout = 0;
+#else
                     const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
                     const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
                     const bool above = m2 > m2hi, below = m2 < m2lo;
@@ -790,10 +810,13 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
                     if (__builtin_amdgcn_ballot_w64(pend)) {
                         if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
                     }
+#endif
                     // (a point without contribution adds to the lane's scratch cell)
                     cell[r] = kout >= 0 ? kout * TILE_COLS + c : scratch;
                     const w_t cs = CSTK == 0 ? (w_t)A.cst0 : xc[b][CSTK == 0 ? 0 : r];
                     vx[r] = TM::make(Wv.x, cs); vy[r] = TM::make(Wv.y, cs);
+                    if (r == 0) TILE_STAMP(trk, wv, pc.st, 6);
+                    if (r == 1) TILE_STAMP(trk, wv, pc.st, 7);
                 }
                 if (SSQ_TILE_EXP & 4) {
                     load(BN, clampp(pn)); load_wt(BN, clampp(pn)); advance(pnn, NW); load_rec(clampp(pnn));
@@ -828,6 +851,352 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     write_outs_before(ntl);
 }
 
+
+// =====================================================================================
+// tile2_kernel (round 4): the same work without the ticket chain.
+//
+// What round 4 measured on the MI355X (profiles/r4_ab_history.txt): the ticketed kernel above
+// spends a quarter of every tile at its boundary and is otherwise paced by the hand-overs (177 us
+// of chain alone, 230 us of arithmetic alone, 256 us together); its time does not change when
+// the gather, the modulation or the bin arithmetic are taken out, it is the same on 64 and on 256
+// CUs (per tile), and LDS *float32* atomics, the obvious way around the tickets, take 193 cycles
+// per wavefront instruction -- while ds_add_f64 takes 13.6 and ds_add_u64 10.8
+// (tools/probes/lds_atomic_probe.hip).
+//
+// So the tile is kept in float64 and every wavefront adds its terms as soon as it has them
+// (ds_add_f64, no return value): 16 bytes per cell, hence COLS = 32 columns per tile (16 when
+// na > 318) and 64 / COLS consecutive rows per wavefront instruction (lane = sub-row h x column).
+// Nothing orders the wavefronts inside a tile, so
+//   * a wavefront owns a CONTIGUOUS block of the tile's rows (cost-balanced by the host), the
+//     same block for every tile: consecutive rows share their decimation class, and the
+//     interpolation weights of a class depend on the column only through n mod R -- the same
+//     for every tile of a persistent workgroup whose tile stride (gridDim x COLS columns) is a
+//     multiple of R: weights are re-read at class changes only, not per step;
+//   * an item (= one wavefront instruction's rows) carries 16 bytes of state (one packed
+//     record), the pipeline is: record two items ahead, samples one item ahead;
+//   * a tile ends with two hardware barriers (all terms in / tile written out and cleared)
+//     instead of 76 hand-overs.
+// The sum of a cell is the float64 sum of its float32 (or float64) terms, rounded once: it
+// differs from the reference's running float32 sum (algos.py:912-924) by that sum's own
+// rounding, ~1e-7 of the largest cell (tests bound it at 1e-6); the bins are the same integers.
+// float64 addition is not associative either, but with 300 terms of 24-bit mantissas the
+// double sum's own rounding error is ~1e-16 relative: the float32 result differs between two
+// arrival orders only when the exact sum lies within that of a float32 rounding boundary.
+template <int COLS> struct Tile2Geo {
+    static constexpr int RPI = 64 / COLS;              // rows per wavefront instruction
+    static constexpr int LGC = COLS == 32 ? 5 : 4;
+};
+__host__ __device__ inline size_t tile2_lds_bytes(int64_t na, int cols) {
+    return (size_t)(na + 1) * cols * 16;
+}
+
+struct Tile2Args {
+    const int4* items;       // [n_items][RPI]: row | pad << 9 | kind << 10 | lgR << 11 | wtab_off << 16,
+                             //                 kc | rows of the class << 22, samples' offset (class + row), row * N * 8
+    const int* wave_first;   // [NW + 1]: items of wavefront w = [wave_first[w], wave_first[w + 1])
+    const float4* wtab; const float2* U;
+    const void* cst;
+    float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
+    int64_t N, na;
+    int n_items, n1, mmask, lgM, sig0, nsig, group;
+    float inv_m, theta_scale, cst0;
+    unsigned long long* counters;
+    double gamma;
+};
+
+#ifndef SSQ_LDS_ADD_F64
+// LDS float64 add without a return value at byte offset `off` of the workgroup's LDS
+#define SSQ_LDS_ADD_F64(base, off, val) asm volatile("ds_add_f64 %0, %1" :: "v"((unsigned)(size_t)(base) + (unsigned)(off)), "v"(val) : "memory")
+// every LDS operation of this wavefront done, then the workgroup's barrier -- without the wait for
+// vector memory that __syncthreads() implies (the loads in flight belong to the next tile)
+#define SSQ_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// tuning aid (-DSSQ_TILE2_PROF, A/B builds): shader-clock time one workgroup's wavefronts spend in the
+// phases of an item, summed over the launch -> counters[8 + 8 * wavefront + phase] (dumped by TilePlan::run
+// with SSQ_TILE2_PROF_DUMP=1 in the environment). Each stamp waits for the LDS / scalar queue: perturbs.
+#ifdef SSQ_TILE2_PROF
+#define T2_STAMP(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         prof[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define T2_STAMP(k) do { } while (0)
+#endif
+template <int GRID, bool STORE_D, int NW, int CSTK, int COLS>
+__global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams sp) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int RPI = Tile2Geo<COLS>::RPI, LGC = Tile2Geo<COLS>::LGC;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & (COLS - 1), h = lane >> LGC, hb = lane & ~(COLS - 1);
+    const int64_t N = A.N;
+    const unsigned nN = (unsigned)N;
+    const int na = (int)A.na, omax = na - 1;
+    double2* T = reinterpret_cast<double2*>(lds_raw);          // (na + 1) x COLS cells, the last row: scratch
+    for (int k = threadIdx.x; k < (na + 1) * COLS; k += 64 * NW) T[k] = make_double2(0.0, 0.0);
+    __syncthreads();
+    const int scratch16 = (na * COLS + c) * 16;
+
+    const int ntx = (int)((N + COLS - 1) / COLS);
+    const int G = (int)gridDim.x;
+    const int per_sig = (int)blockIdx.x < ntx ? (ntx - (int)blockIdx.x + G - 1) / G : 0;
+    const int ntl = per_sig * A.nsig;                          // tiles of this workgroup
+    const int i0 = A.wave_first[wv], i1 = A.wave_first[wv + 1], ni = i1 - i0;
+
+    const float g2 = (float)(A.gamma * A.gamma);
+    const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
+    const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
+    using TM = TileTerm<CSTK == 2>;
+    using w_t = typename TM::wtype;
+    const w_t* cstv = (const w_t*)A.cst;
+
+    // ---- a tile's end: all terms in (barrier), every wavefront writes its share of the rows to
+    // Tx and clears them, tile free again (barrier)
+    auto finish_tile = [&](int tx, int sg) {
+        SSQ_WG_BARRIER();
+        const unsigned col = (unsigned)(tx * COLS + c);
+        const bool ok = col < nN;
+        float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
+        // (a fixed number of rounds, fully unrolled: before a loop with stores in it the compiler
+        // drains every load in flight -- the next tile's samples. Rounds past the last row fall away
+        // on a wave-uniform test; the fence keeps the rounds from being batched into 40 registers.)
+        constexpr int NA_CAP = COLS == 32 ? 320 : 512;
+        constexpr int ROUNDS = (NA_CAP + NW * RPI - 1) / (NW * RPI);
+#pragma unroll
+        for (int m = 0; m < ROUNDS; ++m) {
+            if (m * NW * RPI < na) {
+                const int k = (wv + m * NW) * RPI + h;
+                const int kc_ = k < na ? k : na;
+                const double2 v = T[kc_ * COLS + c];
+                T[kc_ * COLS + c] = make_double2(0.0, 0.0);    // (the scratch row is cleared along the way)
+                if (ok && k < na) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (threadIdx.x == 0 && A.counters)
+            __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+        SSQ_WG_BARRIER();
+    };
+
+    if (ni <= 0) {                                             // more wavefronts than items: write-outs only
+        int tx = (int)blockIdx.x, sg = 0;
+        for (int j = 0; j < ntl; ++j) {
+            finish_tile(tx, sg);
+            tx += G;
+            if (tx >= ntx) { tx = (int)blockIdx.x; ++sg; }
+        }
+        return;
+    }
+
+    // ---- the wavefront's sequence of (tile, item) positions, software-pipelined: the record of
+    // position p + 2 and the data of position p + 1 are in flight while position p is computed.
+    // Loads past the end repeat the last position (all loads unconditional, see the note in
+    // tile_kernel). Items repeat from tile to tile, so a record is a function of the item alone.
+    struct Pos { int it, tx, sg, j; };                         // item, tile position, tile number
+    auto next_pos = [&](Pos q) {
+        Pos r = q;
+        if (++r.it >= i1) {
+            r.it = i0; ++r.j; r.tx += G;
+            if (r.tx >= ntx) { r.tx = (int)blockIdx.x; ++r.sg; }
+        }
+        return r;
+    };
+    auto live = [&](const Pos& q) { return q.j < ntl; };
+    const int4* items = A.items;
+    auto load_rec = [&](const Pos& q) { return items[q.it * RPI + h]; };
+
+    // data of a position: (interpolated) the lane's sample of its sub-row's window, or (rows read
+    // back) Wx and the bin of the lane's point; the row's weight when there is one per row
+    struct Data { float2 u; int kq; w_t cs; };
+    auto load_data = [&](const int4 rec, const Pos& q) {
+        Data d;
+        const int w0 = __builtin_amdgcn_readfirstlane(rec.x);
+        const int kind = (w0 >> 10) & 1, lgR = (w0 >> 11) & 31;
+        const int col0 = q.tx * COLS, col = col0 + c;
+        const int colc = col < (int)N ? col : (int)N - 1;
+        const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
+        const int qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
+        const int wlast = ((COLS - 1) >> lgR) + TILE_W;
+        const int lmask = (A.mmask >> lgR);                    // L - 1, L = M / R
+        const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & lmask);
+        const int nrows_c = (int)((unsigned)__builtin_amdgcn_readfirstlane(rec.y) >> 22);
+        const unsigned sigoff = (unsigned)q.sg * (unsigned)(nrows_c << (A.lgM - lgR));   // entries between two signals' rows
+        const char* Ub8 = reinterpret_cast<const char*>(A.U);
+        const char* Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + q.sg) * na * N);
+        const char* kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)q.sg * na * N);
+        const unsigned wxo = (unsigned)rec.w + (unsigned)colc * 8u;
+        const size_t uo = ((size_t)((unsigned)rec.z + sigoff) + uidx) * 8u;
+        d.u = *reinterpret_cast<const float2*>(kind ? Ub8 + uo : Wx8 + (size_t)wxo);
+        // (one load either way: a conditional load costs the compiler its count of loads in flight)
+        const char* kaddr = kind ? reinterpret_cast<const char*>(A.items) : kx8 + (size_t)(wxo >> 2);
+        d.kq = (int)*reinterpret_cast<const unsigned short*>(kaddr);
+        if (CSTK != 0) d.cs = cstv[rec.x & 0x1FF];
+        else d.cs = (w_t)0;
+        return d;
+    };
+#ifndef SSQ_TILE2_WT2
+#define SSQ_TILE2_WT2 0
+#endif
+    ssq_f2 wt2[SSQ_TILE2_WT2 ? 2 : 1][TILE_W];
+    auto load_wt = [&](ssq_f2 (&wt)[TILE_W], const int4 rec, const Pos& q) {
+        const int w0 = __builtin_amdgcn_readfirstlane(rec.x);
+        const int lgR = (w0 >> 11) & 31, woff = (int)((unsigned)w0 >> 16);
+        const int col = q.tx * COLS + c;
+        const int nabs = A.n1 + (col < (int)N ? col : (int)N - 1);
+        const int R = 1 << lgR;
+        const float4* wp = A.wtab + (int64_t)woff * 4 + (nabs & (R - 1));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 v = wp[t * R];
+            wt[2 * t].x = v.x; wt[2 * t].y = v.y; wt[2 * t + 1].x = v.z; wt[2 * t + 1].y = v.w;
+        }
+    };
+    // ---- the pipeline: ring slots k, k+1, k+2, k+3 (mod 4) hold the positions p .. p+3. While
+    // position p is computed: the data of p+2 go out (their record came in during the position
+    // before), the record of p+3 goes out, the weights of p+1 go out as soon as the taps of p are
+    // done. ALL loads are issued unconditionally, on both sides of the branch on the item's kind,
+    // so that the compiler's count of loads in flight stays exact (its waits are vmcnt(n), never a
+    // drain) -- which is why weights are fetched for every position, needed or not.
+#ifdef SSQ_TILE2_PROF
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+    Pos pq[4];
+    int4 R[4]; Data D[4];
+    pq[0].it = i0; pq[0].tx = (int)blockIdx.x; pq[0].sg = 0; pq[0].j = 0;
+    if (!live(pq[0])) return;
+    Pos plast = pq[0];
+    auto clampp = [&](const Pos& q) { return live(q) ? q : plast; };
+    pq[1] = next_pos(pq[0]); pq[2] = next_pos(pq[1]); pq[3] = next_pos(pq[2]);
+    R[0] = load_rec(pq[0]); R[1] = load_rec(clampp(pq[1])); R[2] = load_rec(clampp(pq[2]));
+    D[0] = load_data(R[0], pq[0]); D[1] = load_data(R[1], clampp(pq[1]));
+    D[2] = D[0]; D[3] = D[0]; R[3] = R[0];
+    load_wt(wt2[0], R[0], pq[0]);
+    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    bool more = true;
+    auto body = [&](auto KK) {
+        constexpr int k0 = decltype(KK)::value, k1 = (k0 + 1) & 3, k2 = (k0 + 2) & 3, k3 = (k0 + 3) & 3;
+        const Pos pc = pq[k0];
+        T2_STAMP(0);                                           // (loop overhead, the previous item's tail)
+        D[k2] = load_data(R[k2], clampp(pq[k2]));
+        R[k3] = load_rec(clampp(pq[k3]));
+        T2_STAMP(1);                                           // loads of p+2 / p+3 issued (waits for the record of p+2)
+        // The weights of the next position: loads must stay out of the branch on the item's kind
+        // (inside it the compiler loses its count of loads in flight and drains them all at the
+        // join). Either into a second buffer right away (SSQ_TILE2_WT2: 16 more registers -- over
+        // 128 with 16 wavefronts), or into the same registers behind the branch, when this
+        // position's taps are done (~600 cycles before the next position's taps need them).
+#if SSQ_TILE2_WT2
+        load_wt(wt2[k1 & 1], R[k1], clampp(pq[k1]));
+        ssq_f2 (&wt)[TILE_W] = wt2[k0 & 1];
+#else
+        ssq_f2 (&wt)[TILE_W] = wt2[0];
+#endif
+        const int4 rc = R[k0];
+        const Data dc = D[k0];
+        const int w0 = __builtin_amdgcn_readfirstlane(rc.x);
+        const int kind = (w0 >> 10) & 1;
+        const int col0 = pc.tx * COLS, col = col0 + c;
+        const bool colok = col < (int)N;
+        const int colc = colok ? col : (int)N - 1;
+        const int nabs = A.n1 + colc;
+        const bool pad = (rc.x >> 9) & 1;
+        int cell16; float tvx, tvy;
+        if (kind == 0) {
+            const int kk = dc.kq & 0xFFFF;
+            const bool act = !pad && colok && kk != TILE_NOBIN;
+            cell16 = act ? (kk * COLS + c) * 16 : scratch16;
+            tvx = dc.u.x; tvy = dc.u.y;
+        } else {
+            const int lgR = (w0 >> 11) & 31;
+            const int q0 = nabs >> lgR, qb = ((A.n1 + col0) >> lgR) - (TILE_W / 2 - 1);
+            const int baddr = ((q0 - (TILE_W / 2 - 1) - qb) + hb) * 4;       // lane that holds tap 0
+            ssq_f2 are2, aim2;
+            {
+                int fr[TILE_W], fi[TILE_W];
+                int ur = __float_as_int(dc.u.x), ui = __float_as_int(dc.u.y);
+#ifdef SSQ_TILE2_PROF
+                SSQ_OPAQUE_V(ur); SSQ_OPAQUE_V(ui);
+                T2_STAMP(2);                                   // the item's samples are there
+#endif
+                SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
+                SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
+                SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
+                SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
+                SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
+                SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
+                SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
+                SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
+                SSQ_LDS_WAIT();
+                T2_STAMP(3);                                   // taps gathered
+#pragma unroll
+                for (int t = 0; t < TILE_W; ++t) {
+                    ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
+                    if (t == 0) { SSQ_PK_MUL_LO(are2, wt[0], sv); SSQ_PK_MUL_HI(aim2, wt[0], sv); }
+                    else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
+                }
+            }
+            const float are = are2.x, aim = aim2.x;
+            float dre = are2.y, dim = aim2.y;
+            const int kcs = rc.y & 0x3FFFFF;                   // centre bin of the lane's row
+            const float theta = (float)kcs * A.theta_scale;
+            dre = __builtin_fmaf(-theta, aim, dre);
+            dim = __builtin_fmaf(theta, are, dim);
+            const float rev = (float)(__umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;
+            const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+            const float2 Wv = cmulf(tw, make_float2(are, aim));
+            const float2 Dv = cmulf(tw, make_float2(dre, dim));
+            char* Wx8 = reinterpret_cast<char*>(A.Wx + (int64_t)(A.sig0 + pc.sg) * na * N);
+            const unsigned wxo = (unsigned)rc.w + (unsigned)colc * 8u;
+            if (!(SSQ_TILE_EXP & 256) || Wv.x == 123.456f) *reinterpret_cast<float2*>(Wx8 + (size_t)wxo) = Wv;
+            if (STORE_D) {
+                char* dWx8 = reinterpret_cast<char*>(A.dWx + (int64_t)(A.sig0 + pc.sg) * na * N);
+                *reinterpret_cast<float2*>(dWx8 + (size_t)wxo) = Dv;
+            }
+            // phase transform and bin: as emit_point<LEAN> of the block kernels
+            const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
+            const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
+            const bool above = m2 > m2hi, below = m2 < m2lo;
+            const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+            bool ok;
+            const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
+            const int kf = (kb ^ fx) + fa;
+            const bool livept = colok && !pad;
+            int kout = (above && livept) ? kf : -1;
+            const bool pend = livept && !(below | (above & ok));
+            if (__builtin_amdgcn_ballot_w64(pend)) {
+                if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
+            }
+            cell16 = kout >= 0 ? (kout * COLS + c) * 16 : scratch16;
+            tvx = Wv.x; tvy = Wv.y;
+            T2_STAMP(4);                                       // arithmetic, store, bin
+        }
+#if !SSQ_TILE2_WT2 && !(SSQ_TILE_EXP & 512)
+        load_wt(wt2[0], R[k1], clampp(pq[k1]));
+#endif
+        {
+            const w_t cs = CSTK == 0 ? (w_t)A.cst0 : dc.cs;
+            const double ax = (double)TM::make(tvx, cs), ay = (double)TM::make(tvy, cs);
+            SSQ_LDS_ADD_F64(lds_raw, cell16, ax);
+            SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay);
+        }
+        T2_STAMP(5);                                           // weights of p+1 issued, terms added
+        if (pq[k1].j != pc.j) { finish_tile(pc.tx, pc.sg); T2_STAMP(6); }
+        more = live(pq[k1]);
+        plast = pc;
+        pq[k0] = next_pos(pq[k3]);                             // slot k0 becomes position p + 4
+    };
+    for (;;) {
+        body(K0{}); if (!more) break;
+        body(K1{}); if (!more) break;
+        body(K2{}); if (!more) break;
+        body(K3{}); if (!more) break;
+    }
+#ifdef SSQ_TILE2_PROF
+    if (blockIdx.x == 100 % gridDim.x && lane == 0 && A.counters)
+        for (int k = 0; k < 8; ++k) A.counters[8 + 8 * wv + k] = prof[k];
+#endif
+}
+
 // ---------------------------------------------------------------------------- host side
 int tile_rows_per_step() { return TILE_G; }
 int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_t n1_, int64_t na_, int group_,
@@ -842,8 +1211,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         ncu = pr.multiProcessorCount;
         if (const char* e = getenv("SSQ_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
     }
-    SSQ_REQUIRE(tile_lds_bytes(na) <= 160 * 1024 && na * N < ((int64_t)1 << 29),
-                "na = %lld: the Tx tile exceeds the LDS", (long long)na);
+    SSQ_REQUIRE(na * N < ((int64_t)1 << 29) && na < 512, "na = %lld, N = %lld: outside the tile path's 32-bit offsets",
+                (long long)na, (long long)N);
     // the modulation phase kc * n mod M is formed with a 24-bit multiply and carried in a float
     // (and the centre bin, < M / 2, shares a word with the row: 22 bits)
     SSQ_REQUIRE(M <= ((int64_t)1 << 23), "the tile path needs a padded length <= 2^23");
@@ -890,7 +1259,68 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
         if ((rc = up((void**)&rows, hp.data(), hp.size() * 4))) return rc;
     }
-    if ((rc = up(&wtab, d.wtab, (size_t)64 * d.n_phases))) return rc;
+    {   // tile2_kernel's items: the rows of a step, 64 / COLS at a time, one packed record per row
+        const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
+        const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
+        int lgM_ = 0; while (((int64_t)1 << lgM_) < M) ++lgM_;
+        cols2 = tile2_lds_bytes(na, 32) <= 160 * 1024 ? 32 : 16;
+        SSQ_REQUIRE(tile2_lds_bytes(na, cols2) <= 160 * 1024, "na = %lld: the Tx tile exceeds the LDS", (long long)na);
+        std::vector<int32_t> hi4((size_t)nsteps * TILE_G * 4);
+        std::vector<float> cost((size_t)nsteps * TILE_G, 0.f);
+        const float rb_cost = getenv("SSQ_TILE2_RB_COST") ? (float)atof(getenv("SSQ_TILE2_RB_COST")) : 0.4f;
+        for (int i = 0; i < nsegs; ++i) {
+            SSQ_REQUIRE(sg[i].kind == 0 || (sg[i].wtab_off < 65536 && sg[i].sig_stride % ((int64_t)M >> sg[i].lgR) == 0
+                                            && sg[i].sig_stride / ((int64_t)M >> sg[i].lgR) < 1024),
+                        "tile segment %d does not fit an item record", i);
+            for (int t = 0; t < sg[i].nsteps * TILE_G; ++t) {
+                const size_t r = (size_t)sg[i].first * TILE_G + t;
+                const int32_t row = rw[r].row & 0xFFFF;
+                const int32_t nrows_c = sg[i].kind ? (int32_t)(sg[i].sig_stride / ((int64_t)M >> sg[i].lgR)) : 0;
+                hi4[4 * r] = row | (rw[r].row < 0 ? 0x200 : 0) | (sg[i].kind << 10) | (sg[i].lgR << 11)
+                             | (int32_t)((uint32_t)(sg[i].kind ? sg[i].wtab_off : 0) << 16);
+                hi4[4 * r + 1] = rw[r].kc | (int32_t)((uint32_t)nrows_c << 22);
+                hi4[4 * r + 2] = sg[i].kind ? sg[i].cls_base + rw[r].ubase : 0;
+                hi4[4 * r + 3] = (int32_t)(uint32_t)((int64_t)row * N * 8);
+                cost[r] = sg[i].kind ? 1.0f : rb_cost;              // what a row read back costs next to an interpolated one
+            }
+        }
+        if ((rc = up((void**)&items2, hi4.data(), hi4.size() * 4))) return rc;
+        // contiguous, cost-balanced blocks of items per wavefront, for both workgroup sizes
+        const int rpi = 64 / cols2;
+        n_items2 = nsteps * TILE_G / rpi;
+        std::vector<int32_t> wf;
+        for (int nw : {8, 12, 16}) {
+            std::vector<double> pre((size_t)n_items2 + 1, 0.0);
+            for (int it = 0; it < n_items2; ++it) pre[it + 1] = pre[it] + cost[(size_t)it * rpi];
+            wf.push_back(0);
+            for (int w = 1; w <= nw; ++w) {
+                const double want = pre[n_items2] * w / nw;
+                int it = wf.back();
+                while (it < n_items2 && pre[it + 1] <= want + 1e-9) ++it;
+                if (w == nw) it = n_items2;
+                wf.push_back(it);
+            }
+        }
+        if ((rc = up((void**)&wave_first2, wf.data(), wf.size() * 4))) return rc;
+    }
+    {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]
+        const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
+        const float* src = reinterpret_cast<const float*>(d.wtab);
+        std::vector<float> w((size_t)16 * d.n_phases, 0.f);
+        std::vector<char> done((size_t)d.n_phases, 0);
+        for (int i = 0; i < nsegs; ++i) {
+            if (sg[i].kind != 1) continue;
+            const int64_t R = (int64_t)1 << sg[i].lgR, o = sg[i].wtab_off;
+            SSQ_REQUIRE(o >= 0 && o + R <= d.n_phases, "tile segment %d: weights outside the table", i);
+            if (done[(size_t)o]) continue;
+            done[(size_t)o] = 1;
+            for (int64_t ph = 0; ph < R; ++ph)
+                for (int t = 0; t < 4; ++t)
+                    for (int k = 0; k < 4; ++k)
+                        w[(size_t)(16 * o + (t * R + ph) * 4 + k)] = src[(size_t)(16 * (o + ph) + 4 * t + k)];
+        }
+        if ((rc = up(&wtab, w.data(), (size_t)64 * d.n_phases))) return rc;
+    }
     if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
     cls.resize(d.n_classes);
     // classes of 2^14 entries and more: four-step kernels, L = A B with A <= B, both 128 .. 2048
@@ -947,8 +1377,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     }
     SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * group * u_total)); bytes += 8 * group * u_total;
     SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * group * u_total));
-    SSQ_CHECK_HIP(hipMalloc((void**)&counters, 64));
-    SSQ_CHECK_HIP(hipMemset(counters, 0, 64));
+    SSQ_CHECK_HIP(hipMalloc((void**)&counters, 4096));       // [0]: tiles done; [8 ..]: tuning aid (SSQ_TILE2_PROF)
+    SSQ_CHECK_HIP(hipMemset(counters, 0, 4096));
     for (size_t c = 0; c < cls.size(); ++c) {
         FftPlan fp;
         if (!cls[c].A && !cls[c].B) {
@@ -974,7 +1404,8 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw};
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw, items2, wave_first2};
+    items2 = nullptr; wave_first2 = nullptr;
     for (void* p : ptrs) if (p) (void)hipFree(p);
     steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = Y = ftw = nullptr;
     counters = nullptr;
@@ -1156,14 +1587,92 @@ static int launch_tile_nw(const TilePlan& P, const TileArgs& A, const SsqParams&
 }
 template <int GRID, bool STORE_D>
 static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
-    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 12; return v == 8 || v == 16 ? v : 12; }();
-    if (nw == 8) return launch_tile_nw<GRID, STORE_D, 8>(P, A, sp, nsig, stream);
-    if (nw == 16) return launch_tile_nw<GRID, STORE_D, 16>(P, A, sp, nsig, stream);
     return launch_tile_nw<GRID, STORE_D, 12>(P, A, sp, nsig, stream);
 }
 
+// ---- tile2_kernel launch
+template <int GRID, bool STORE_D, int NW, int CSTK, int COLS>
+static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
+    auto kern = tile2_kernel<GRID, STORE_D, NW, CSTK, COLS>;
+    const size_t lds = tile2_lds_bytes(P.na, COLS);
+    static bool attr_set = false;            // per instantiation
+    if (!attr_set) {
+        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int64_t ntx = (P.N + COLS - 1) / COLS;
+    // persistent workgroups: as many as fit a CU's LDS side by side, each walks tiles b, b + G, ...
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(32 / NW)));
+    const dim3 grid((unsigned)std::min<int64_t>(ntx, (int64_t)P.ncu * per_cu));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, A, sp);
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+template <int GRID, bool STORE_D, int NW, int COLS>
+static int launch_tile2_k(const TilePlan& P, const Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
+    const int cstk = sp.cst_f64 ? 2 : (sp.cst_uniform ? 0 : 1);
+    if (cstk == 0) return launch_tile2_c<GRID, STORE_D, NW, 0, COLS>(P, A, sp, stream);
+    if (cstk == 1) return launch_tile2_c<GRID, STORE_D, NW, 1, COLS>(P, A, sp, stream);
+    return launch_tile2_c<GRID, STORE_D, NW, 2, COLS>(P, A, sp, stream);
+}
+template <int GRID, bool STORE_D>
+static int launch_tile2(const TilePlan& P, Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
+    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 16; return v == 8 || v == 12 ? v : 16; }();
+    // wave_first2 holds the partitions for 8, 12 and 16 wavefronts one after the other
+    A.wave_first = P.wave_first2 + (nw == 8 ? 0 : nw == 12 ? 9 : 22);
+    if (P.cols2 == 32) {
+        if (nw == 8) return launch_tile2_k<GRID, STORE_D, 8, 32>(P, A, sp, stream);
+        if (nw == 12) return launch_tile2_k<GRID, STORE_D, 12, 32>(P, A, sp, stream);
+        return launch_tile2_k<GRID, STORE_D, 16, 32>(P, A, sp, stream);
+    }
+    if (nw == 8) return launch_tile2_k<GRID, STORE_D, 8, 16>(P, A, sp, stream);
+    if (nw == 12) return launch_tile2_k<GRID, STORE_D, 12, 16>(P, A, sp, stream);
+    return launch_tile2_k<GRID, STORE_D, 16, 16>(P, A, sp, stream);
+}
+
+// SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, na <= 318);
+// default: tile2_kernel (float64 tile, unordered adds)
+bool tile_ordered() {
+    const char* e = getenv("SSQ_TILE_ORDER");       // (read at every launch: tests switch it)
+    return !(e && !strcmp(e, "f64"));               // (the float64 form is opt-in until it is the faster one)
+}
+int TilePlan::tile_cols() const { return tile_ordered() ? TILE_COLS : cols2; }
+
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
+    if (!tile_ordered()) {
+        Tile2Args B;
+        B.items = reinterpret_cast<const int4*>(items2); B.wave_first = wave_first2;
+        B.wtab = (const float4*)wtab; B.U = (const float2*)U; B.cst = cst;
+        B.Wx = (float2*)Wx; B.dWx = (float2*)dWx; B.Tx = (float2*)Tx; B.kidx = kidx;
+        B.N = N; B.na = na; B.n_items = n_items2; B.n1 = (int)n1; B.mmask = (int)(M - 1);
+        B.lgM = 0; while (((int64_t)1 << B.lgM) < M) ++B.lgM;
+        B.sig0 = sig; B.nsig = nsig; B.group = group; B.inv_m = 1.0f / (float)M;
+        B.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); B.cst0 = cst0;
+        B.counters = counters; B.gamma = sp.gamma;
+#define TILE2_LAUNCH(G)                                                                     \
+        return dWx ? launch_tile2<G, true>(*this, B, sp, stream) : launch_tile2<G, false>(*this, B, sp, stream);
+        auto launch2 = [&]() -> int {
+            if (sp.grid == SSQ_GRID_LOG) { TILE2_LAUNCH(SSQ_GRID_LOG) }
+            if (sp.grid == SSQ_GRID_LOG_PIECEWISE) { TILE2_LAUNCH(SSQ_GRID_LOG_PIECEWISE) }
+            TILE2_LAUNCH(SSQ_GRID_LIN)
+        };
+        const int rc2 = launch2();
+        if (!rc2 && getenv("SSQ_TILE2_PROF_DUMP")) {         // tuning aid, see T2_STAMP
+            SSQ_CHECK_HIP(hipStreamSynchronize(stream));
+            unsigned long long h[8 + 8 * 16];
+            SSQ_CHECK_HIP(hipMemcpy(h, counters, sizeof h, hipMemcpyDeviceToHost));
+            for (int w = 0; w < 16; ++w) {
+                fprintf(stderr, "tile2 prof w%2d:", w);
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %10llu", h[8 + 8 * w + k]);
+                fprintf(stderr, "\n");
+            }
+        }
+        return rc2;
+#undef TILE2_LAUNCH
+    }
+    SSQ_REQUIRE(tile_lds_bytes(na) <= 160 * 1024, "na = %lld: the ordered tile kernel's Tx tile exceeds the LDS", (long long)na);
     TileArgs A;
     A.pstep = reinterpret_cast<const int4*>(steps); A.prow = reinterpret_cast<const int2*>(rows);
     A.wtab = (const float4*)wtab; A.U = (const float2*)U; A.cst = cst;

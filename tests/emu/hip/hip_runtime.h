@@ -39,6 +39,9 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
     (d).x = __builtin_fmaf(-(a).y, (b).y, tx_); (d).y = __builtin_fmaf((a).y, (b).x, ty_); } while (0)
 #define SSQ_BFI(d, m, a, b) ((d) = ((m) & (a)) | (~(m) & (b)))
 #define SSQ_LDS_WAIT() ((void)0)
+// LDS float64 add (ds_add_f64) and the LDS-only workgroup barrier of tile2_kernel
+#define SSQ_LDS_ADD_F64(base, off, val) (*reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(base) + (off)) += (val))
+#define SSQ_WG_BARRIER() __syncthreads()
 #define SSQ_LDS_WAITN(n) ((void)0)
 #define __global__
 #define __device__
