@@ -891,9 +891,9 @@ __host__ __device__ inline size_t tile2_lds_bytes(int64_t na, int cols) {
 }
 
 struct Tile2Args {
-    const int4* items;       // [n_items][RPI]: row | pad << 9 | kind << 10 | lgR << 11 | wtab_off << 16,
-                             //                 kc | rows of the class << 22, samples' offset (class + row), row * N * 8
-    const int* wave_first;   // [NW + 1]: items of wavefront w = [wave_first[w], wave_first[w + 1])
+    const int* items;        // [n_items][8]: row0 | npad << 9 | kind << 12 | lgR << 13, samples' offset of sub-row 0
+                             // (class + row), row0 * N * 8, entries between two signals' rows of the class, kc of the sub-rows
+    const int4* waves;       // [NW]: first item, end, first item of the wavefront's second class (= end: none), 0
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
@@ -910,6 +910,9 @@ struct Tile2Args {
 // every LDS operation of this wavefront done, then the workgroup's barrier -- without the wait for
 // vector memory that __syncthreads() implies (the loads in flight belong to the next tile)
 #define SSQ_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// a table the kernel never writes, read with a wavefront-uniform index: the constant address space
+// makes the compiler fetch it through the scalar cache (s_load) instead of the vector memory path
+#define SSQ_CONST_PTR(T, p) reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p))
 #endif
 
 // tuning aid (-DSSQ_TILE2_PROF, A/B builds): shader-clock time one workgroup's wavefronts spend in the
@@ -921,13 +924,26 @@ struct Tile2Args {
 #else
 #define T2_STAMP(k) do { } while (0)
 #endif
+
+// Both tile kernels are bound by the instructions they issue, of every kind (round 4,
+// profiles/r4_ab_history.txt: one instruction per cycle and CU; 210 per 64 points in the ticketed
+// kernel). This one is built to issue few:
+//   * an item (64 / COLS consecutive rows x COLS columns) has ONE scalar record (s_load through the
+//     constant address space: the index is wavefront-uniform): the sub-rows are consecutive rows of
+//     one class, so a lane's addresses are scalar bases + per-lane constants;
+//   * one load of samples (or Wx + bin for rows read back) and one store of Wx per item, one
+//     16-byte-per-lane store of Tx per 4 (8) rows x COLS columns of a finished tile;
+//   * the interpolation weights stay in registers for the whole launch: a wavefront's block of
+//     rows spans at most two decimation classes (the host cuts the blocks that way), and a lane's
+//     weights depend on its column only through n mod R, the same for every tile of a workgroup
+//     whose tile stride is a multiple of R (the launcher picks the grid that way).
 template <int GRID, bool STORE_D, int NW, int CSTK, int COLS>
 __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int RPI = Tile2Geo<COLS>::RPI, LGC = Tile2Geo<COLS>::LGC;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & (COLS - 1), h = lane >> LGC, hb = lane & ~(COLS - 1);
+    const int c = lane & (COLS - 1), h = lane >> LGC, hb4 = (lane & ~(COLS - 1)) * 4;
     const int64_t N = A.N;
     const unsigned nN = (unsigned)N;
     const int na = (int)A.na, omax = na - 1;
@@ -935,41 +951,77 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     for (int k = threadIdx.x; k < (na + 1) * COLS; k += 64 * NW) T[k] = make_double2(0.0, 0.0);
     __syncthreads();
     const int scratch16 = (na * COLS + c) * 16;
+    const int c16 = c * 16;
 
     const int ntx = (int)((N + COLS - 1) / COLS);
     const int G = (int)gridDim.x;
     const int per_sig = (int)blockIdx.x < ntx ? (ntx - (int)blockIdx.x + G - 1) / G : 0;
     const int ntl = per_sig * A.nsig;                          // tiles of this workgroup
-    const int i0 = A.wave_first[wv], i1 = A.wave_first[wv + 1], ni = i1 - i0;
-
+    const auto* waves = SSQ_CONST_PTR(int4, A.waves);
+    const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
+    // The wavefronts of a SIMD compete for its issue slots and the oldest wins: left alone, the four
+    // youngest wavefronts of the workgroup finish their rows of every tile last and the others wait
+    // for them at the barrier (measured: 14.7 k of 37 k cycles per tile); fixed priorities against the
+    // age only turn the order around. So the priorities rotate: the four wavefronts of a SIMD (w, w + 4,
+    // w + 8, w + 12) alternate between two levels, two high and two low at any time, swapped with every
+    // item (+2 %; four rotating levels measured the same and cost three more branches per item).
+    auto rotate_priority = [&](int step) {
+#if !(SSQ_TILE_EXP & 8)
+        if ((step ^ (wv >> 2)) & 1) __builtin_amdgcn_s_setprio(2);      // (two levels, swapped with every item)
+        else __builtin_amdgcn_s_setprio(0);
+#endif
+    };
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
     using TM = TileTerm<CSTK == 2>;
     using w_t = typename TM::wtype;
-    const w_t* cstv = (const w_t*)A.cst;
+    const auto* cstv = SSQ_CONST_PTR(w_t, A.cst);
 
     // ---- a tile's end: all terms in (barrier), every wavefront writes its share of the rows to
-    // Tx and clears them, tile free again (barrier)
+    // Tx and clears them, tile free again (barrier). A lane takes two neighbouring columns of a row:
+    // one 16-byte store, a wavefront instruction = 128 / COLS rows (N even; otherwise column by column).
     auto finish_tile = [&](int tx, int sg) {
         SSQ_WG_BARRIER();
-        const unsigned col = (unsigned)(tx * COLS + c);
-        const bool ok = col < nN;
         float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
-        // (a fixed number of rounds, fully unrolled: before a loop with stores in it the compiler
-        // drains every load in flight -- the next tile's samples. Rounds past the last row fall away
-        // on a wave-uniform test; the fence keeps the rounds from being batched into 40 registers.)
         constexpr int NA_CAP = COLS == 32 ? 320 : 512;
-        constexpr int ROUNDS = (NA_CAP + NW * RPI - 1) / (NW * RPI);
+#ifndef SSQ_TILE2_NO16
+#define SSQ_TILE2_NO16 1
+#endif
+        if (!SSQ_TILE2_NO16 && (N & 1) == 0) {
+            constexpr int HC = COLS / 2, RW = 64 / HC;         // column pairs per row, rows per instruction
+            const int j2 = (lane & (HC - 1)) * 2, rr = lane / HC;
+            const unsigned col = (unsigned)(tx * COLS + j2);
+            const bool ok = col < nN;                          // (N even: the pair is inside or outside together)
+            constexpr int ROUNDS = (NA_CAP + NW * RW - 1) / (NW * RW);
 #pragma unroll
-        for (int m = 0; m < ROUNDS; ++m) {
-            if (m * NW * RPI < na) {
-                const int k = (wv + m * NW) * RPI + h;
-                const int kc_ = k < na ? k : na;
-                const double2 v = T[kc_ * COLS + c];
-                T[kc_ * COLS + c] = make_double2(0.0, 0.0);    // (the scratch row is cleared along the way)
-                if (ok && k < na) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
-                asm volatile("" ::: "memory");
+            for (int m = 0; m < ROUNDS; ++m) {
+                if (m * NW * RW < na) {                        // (wave-uniform: rounds past the last row fall away)
+                    const int k = (wv + m * NW) * RW + rr;
+                    const int kc_ = k < na ? k : na;
+                    const double2 v0 = T[kc_ * COLS + j2], v1 = T[kc_ * COLS + j2 + 1];
+                    T[kc_ * COLS + j2] = make_double2(0.0, 0.0);       // (the scratch row is cleared along the way)
+                    T[kc_ * COLS + j2 + 1] = make_double2(0.0, 0.0);
+                    if (ok && k < na)
+                        *reinterpret_cast<float4*>(Tx + (unsigned)k * nN + col) =
+                            make_float4((float)v0.x, (float)v0.y, (float)v1.x, (float)v1.y);
+                    asm volatile("" ::: "memory");             // (keeps the rounds from being batched into registers)
+                }
+            }
+        } else {
+            const unsigned col = (unsigned)(tx * COLS + c);
+            const bool ok = col < nN;
+            constexpr int ROUNDS = (NA_CAP + NW * RPI - 1) / (NW * RPI);
+#pragma unroll
+            for (int m = 0; m < ROUNDS; ++m) {
+                if (m * NW * RPI < na) {
+                    const int k = (wv + m * NW) * RPI + h;
+                    const int kc_ = k < na ? k : na;
+                    const double2 v = T[kc_ * COLS + c];
+                    T[kc_ * COLS + c] = make_double2(0.0, 0.0);
+                    if (ok && k < na) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
+                    asm volatile("" ::: "memory");
+                }
             }
         }
         if (threadIdx.x == 0 && A.counters)
@@ -987,61 +1039,80 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         return;
     }
 
-    // ---- the wavefront's sequence of (tile, item) positions, software-pipelined: the record of
-    // position p + 2 and the data of position p + 1 are in flight while position p is computed.
-    // Loads past the end repeat the last position (all loads unconditional, see the note in
-    // tile_kernel). Items repeat from tile to tile, so a record is a function of the item alone.
-    struct Pos { int it, tx, sg, j; };                         // item, tile position, tile number
+    // ---- the wavefront's sequence of (tile, item) positions, software-pipelined over a ring of three
+    // slots (the loop is unrolled three times, the slots are compile-time): while position p is
+    // computed, the data of p + 2 go out. Loads past the end repeat the
+    // last position (all loads unconditional, see the note in tile_kernel). A position carries its
+    // tile's element offset (signal * na * N + first column), worked out when the tile changes only.
+    struct Pos { int it, tx, sg; int64_t off; };
+    // (the offset moves by constants: to the workgroup's next tile of the signal, or from its last
+    // tile of a signal to its first of the next one -- no 64-bit products per item)
+    const int64_t off_step = (int64_t)G * COLS;
+    const int64_t off_wrap = (int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS;
     auto next_pos = [&](Pos q) {
         Pos r = q;
         if (++r.it >= i1) {
-            r.it = i0; ++r.j; r.tx += G;
-            if (r.tx >= ntx) { r.tx = (int)blockIdx.x; ++r.sg; }
+            r.it = i0; r.tx += G;
+            const bool wrap = r.tx >= ntx;
+            r.off += wrap ? off_wrap : off_step;
+            if (wrap) { r.tx = (int)blockIdx.x; ++r.sg; }
         }
         return r;
     };
-    auto live = [&](const Pos& q) { return q.j < ntl; };
-    const int4* items = A.items;
-    auto load_rec = [&](const Pos& q) { return items[q.it * RPI + h]; };
+    const int total = ntl * ni;                                // positions of this wavefront
+    typedef int int8v __attribute__((ext_vector_type(8)));
+    const auto* items = SSQ_CONST_PTR(int8v, A.items);
+    // per-lane constants of the addresses: the lane's place inside an item's rows
+    const unsigned lane_row8 = (unsigned)h * nN * 8u + (unsigned)c * 8u;       // bytes: sub-row h, column c
+    const unsigned lane_col8 = (unsigned)c * 8u;
 
     // data of a position: (interpolated) the lane's sample of its sub-row's window, or (rows read
-    // back) Wx and the bin of the lane's point; the row's weight when there is one per row
-    struct Data { float2 u; int kq; w_t cs; };
-    auto load_data = [&](const int4 rec, const Pos& q) {
+    // back) Wx and the bin of the lane's point
+    struct Data { float2 u; int kq; };
+    const char* const U8 = reinterpret_cast<const char*>(A.U);
+    const char* const WX8 = reinterpret_cast<const char*>(A.Wx) + (size_t)((int64_t)A.sig0 * na * N) * 8u;
+    const char* const KX8 = reinterpret_cast<const char*>(A.kidx);
+    auto load_data = [&](const int8v R, const Pos& q) {
         Data d;
-        const int w0 = __builtin_amdgcn_readfirstlane(rec.x);
-        const int kind = (w0 >> 10) & 1, lgR = (w0 >> 11) & 31;
-        const int col0 = q.tx * COLS, col = col0 + c;
-        const int colc = col < (int)N ? col : (int)N - 1;
-        const int nabs = A.n1 + colc, nabs0 = A.n1 + col0;
-        const int qb = (nabs0 >> lgR) - (TILE_W / 2 - 1);
-        const int wlast = ((COLS - 1) >> lgR) + TILE_W;
-        const int lmask = (A.mmask >> lgR);                    // L - 1, L = M / R
-        const unsigned uidx = (unsigned)((qb + (c < wlast ? c : wlast)) & lmask);
-        const int nrows_c = (int)((unsigned)__builtin_amdgcn_readfirstlane(rec.y) >> 22);
-        const unsigned sigoff = (unsigned)q.sg * (unsigned)(nrows_c << (A.lgM - lgR));   // entries between two signals' rows
-        const char* Ub8 = reinterpret_cast<const char*>(A.U);
-        const char* Wx8 = reinterpret_cast<const char*>(A.Wx + (int64_t)(A.sig0 + q.sg) * na * N);
-        const char* kx8 = reinterpret_cast<const char*>(A.kidx + (int64_t)q.sg * na * N);
-        const unsigned wxo = (unsigned)rec.w + (unsigned)colc * 8u;
-        const size_t uo = ((size_t)((unsigned)rec.z + sigoff) + uidx) * 8u;
-        d.u = *reinterpret_cast<const float2*>(kind ? Ub8 + uo : Wx8 + (size_t)wxo);
-        // (one load either way: a conditional load costs the compiler its count of loads in flight)
-        const char* kaddr = kind ? reinterpret_cast<const char*>(A.items) : kx8 + (size_t)(wxo >> 2);
-        d.kq = (int)*reinterpret_cast<const unsigned short*>(kaddr);
-        if (CSTK != 0) d.cs = cstv[rec.x & 0x1FF];
-        else d.cs = (w_t)0;
+        const int w0 = R[0];
+        const int kind = (w0 >> 12) & 1;
+        const char* base; unsigned voff;
+        const char* kbase = reinterpret_cast<const char*>(A.items); unsigned koff = (unsigned)lane * 2u;
+        if (kind) {                                            // (wave-uniform; the loads themselves stay outside)
+            // sample (qb + min(c, wlast)) mod L of row h of the item, h * L entries on
+            const int lgR = (w0 >> 13) & 31;
+            const int qb = ((A.n1 + q.tx * COLS) >> lgR) - (TILE_W / 2 - 1);
+            const int wlast = ((COLS - 1) >> lgR) + TILE_W;
+            const int lmask = A.mmask >> lgR;                  // L - 1, L = M / R
+            voff = (((unsigned)((qb + (c < wlast ? c : wlast)) & lmask)) + ((unsigned)h << (A.lgM - lgR))) * 8u;
+            base = U8 + ((size_t)(unsigned)R[1] + (size_t)((unsigned)q.sg * (unsigned)R[3])) * 8u;
+        } else {
+            // point (row0 + h, column) -- the last column's for lanes past it, the last real row's for
+            // padded sub-rows -- and its bin
+            const int npad = (w0 >> 9) & 7;
+            unsigned lr8 = lane_row8;
+            if (RPI == 2) { if (npad) lr8 = lane_col8; }
+            else if (npad) lr8 = (unsigned)min(h, RPI - 1 - npad) * nN * 8u + lane_col8;
+            if (q.tx == ntx - 1) {                             // (the last tile may be partial)
+                const int col = q.tx * COLS + c;
+                if (col >= (int)N) lr8 -= (unsigned)(col - ((int)N - 1)) * 8u;
+            }
+            voff = lr8;
+            base = WX8 + ((size_t)q.off * 8u + (unsigned)R[2]);
+            kbase = KX8 + ((size_t)q.off * 2u + ((unsigned)R[2] >> 2));
+            koff = lr8 >> 2;
+        }
+        d.u = *reinterpret_cast<const float2*>(base + (size_t)voff);
+        // (the bin: a load either way, from a harmless address for interpolated rows -- a conditional
+        // load costs the compiler its count of loads in flight)
+        d.kq = (int)*reinterpret_cast<const unsigned short*>(kbase + (size_t)koff);
         return d;
     };
-#ifndef SSQ_TILE2_WT2
-#define SSQ_TILE2_WT2 0
-#endif
-    ssq_f2 wt2[SSQ_TILE2_WT2 ? 2 : 1][TILE_W];
-    auto load_wt = [&](ssq_f2 (&wt)[TILE_W], const int4 rec, const Pos& q) {
-        const int w0 = __builtin_amdgcn_readfirstlane(rec.x);
-        const int lgR = (w0 >> 11) & 31, woff = (int)((unsigned)w0 >> 16);
-        const int col = q.tx * COLS + c;
-        const int nabs = A.n1 + (col < (int)N ? col : (int)N - 1);
+    // the weights of the wavefront's (up to) two classes, for the lane's column phase: once
+    ssq_f2 wta[TILE_W], wtb[TILE_W];
+    auto load_wt = [&](ssq_f2 (&wt)[TILE_W], int it, int woff) {
+        const int lgR = (items[it][0] >> 13) & 31;
+        const int nabs = A.n1 + (int)blockIdx.x * COLS + c;    // (every tile of this workgroup: the same n mod R)
         const int R = 1 << lgR;
         const float4* wp = A.wtab + (int64_t)woff * 4 + (nabs & (R - 1));
 #pragma unroll
@@ -1050,66 +1121,54 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             wt[2 * t].x = v.x; wt[2 * t].y = v.y; wt[2 * t + 1].x = v.z; wt[2 * t + 1].y = v.w;
         }
     };
-    // ---- the pipeline: ring slots k, k+1, k+2, k+3 (mod 4) hold the positions p .. p+3. While
-    // position p is computed: the data of p+2 go out (their record came in during the position
-    // before), the record of p+3 goes out, the weights of p+1 go out as soon as the taps of p are
-    // done. ALL loads are issued unconditionally, on both sides of the branch on the item's kind,
-    // so that the compiler's count of loads in flight stays exact (its waits are vmcnt(n), never a
-    // drain) -- which is why weights are fetched for every position, needed or not.
+    load_wt(wta, i0, waves[wv].w & 0xFFFF);
+    load_wt(wtb, isp < i1 ? isp : i0, (int)((unsigned)waves[wv].w >> 16));
+
 #ifdef SSQ_TILE2_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-    Pos pq[4];
-    int4 R[4]; Data D[4];
-    pq[0].it = i0; pq[0].tx = (int)blockIdx.x; pq[0].sg = 0; pq[0].j = 0;
-    if (!live(pq[0])) return;
-    Pos plast = pq[0];
-    auto clampp = [&](const Pos& q) { return live(q) ? q : plast; };
-    pq[1] = next_pos(pq[0]); pq[2] = next_pos(pq[1]); pq[3] = next_pos(pq[2]);
-    R[0] = load_rec(pq[0]); R[1] = load_rec(clampp(pq[1])); R[2] = load_rec(clampp(pq[2]));
-    D[0] = load_data(R[0], pq[0]); D[1] = load_data(R[1], clampp(pq[1]));
-    D[2] = D[0]; D[3] = D[0]; R[3] = R[0];
-    load_wt(wt2[0], R[0], pq[0]);
+    Pos pq[3];
+    Data D[3];
+    pq[0].it = i0; pq[0].tx = (int)blockIdx.x; pq[0].sg = 0; pq[0].off = (int64_t)blockIdx.x * COLS;
+    if (total <= 0) return;
+    int pidx = 0;                                              // index of the position in hand
+    // (positions past the end repeat the last one: the loads issued for them are valid and unused)
+    int nidx = 0;                                              // index of the newest position in the ring
+    auto advance = [&](const Pos& q) { if (nidx + 1 < total) { ++nidx; return next_pos(q); } return q; };
+    pq[1] = advance(pq[0]); pq[2] = advance(pq[1]);
+    // the records of the position in hand and of the one whose data go out next: asked for (through
+    // the scalar cache) at the end of the position before, so that they are there when it starts
+    int8v Rc = items[pq[0].it];
+    D[0] = load_data(Rc, pq[0]);
+    D[1] = load_data(items[pq[1].it], pq[1]);
+    D[2] = D[0];
+    int8v Rn = items[pq[2].it];
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
+    using K2 = std::integral_constant<int, 2>;
     bool more = true;
     auto body = [&](auto KK) {
-        constexpr int k0 = decltype(KK)::value, k1 = (k0 + 1) & 3, k2 = (k0 + 2) & 3, k3 = (k0 + 3) & 3;
+        constexpr int k0 = decltype(KK)::value, k1 = (k0 + 1) % 3, k2 = (k0 + 2) % 3;
         const Pos pc = pq[k0];
         T2_STAMP(0);                                           // (loop overhead, the previous item's tail)
-        D[k2] = load_data(R[k2], clampp(pq[k2]));
-        R[k3] = load_rec(clampp(pq[k3]));
-        T2_STAMP(1);                                           // loads of p+2 / p+3 issued (waits for the record of p+2)
-        // The weights of the next position: loads must stay out of the branch on the item's kind
-        // (inside it the compiler loses its count of loads in flight and drains them all at the
-        // join). Either into a second buffer right away (SSQ_TILE2_WT2: 16 more registers -- over
-        // 128 with 16 wavefronts), or into the same registers behind the branch, when this
-        // position's taps are done (~600 cycles before the next position's taps need them).
-#if SSQ_TILE2_WT2
-        load_wt(wt2[k1 & 1], R[k1], clampp(pq[k1]));
-        ssq_f2 (&wt)[TILE_W] = wt2[k0 & 1];
-#else
-        ssq_f2 (&wt)[TILE_W] = wt2[0];
-#endif
-        const int4 rc = R[k0];
+        rotate_priority(pidx);
+        D[k2] = load_data(Rn, pq[k2]);                          // the data of p + 2
+        T2_STAMP(1);                                           // loads of p + 2 issued
         const Data dc = D[k0];
-        const int w0 = __builtin_amdgcn_readfirstlane(rc.x);
-        const int kind = (w0 >> 10) & 1;
-        const int col0 = pc.tx * COLS, col = col0 + c;
-        const bool colok = col < (int)N;
-        const int colc = colok ? col : (int)N - 1;
-        const int nabs = A.n1 + colc;
-        const bool pad = (rc.x >> 9) & 1;
+        const int w0 = Rc[0];
+        const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
+        const int col0 = pc.tx * COLS;
+        const int nabs = A.n1 + col0 + c;                      // (lanes past the last column: results unused)
+        bool livept = h < RPI - npad;
+        if (pc.tx == ntx - 1) livept = livept && col0 + c < (int)N;
         int cell16; float tvx, tvy;
         if (kind == 0) {
             const int kk = dc.kq & 0xFFFF;
-            const bool act = !pad && colok && kk != TILE_NOBIN;
-            cell16 = act ? (kk * COLS + c) * 16 : scratch16;
+            cell16 = (livept && kk != TILE_NOBIN) ? kk * (COLS * 16) + c16 : scratch16;
             tvx = dc.u.x; tvy = dc.u.y;
         } else {
-            const int lgR = (w0 >> 11) & 31;
-            const int q0 = nabs >> lgR, qb = ((A.n1 + col0) >> lgR) - (TILE_W / 2 - 1);
-            const int baddr = ((q0 - (TILE_W / 2 - 1) - qb) + hb) * 4;       // lane that holds tap 0
+            const int lgR = (w0 >> 13) & 31;
+            const int qb3 = ((A.n1 + col0) >> lgR);            // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
+            const int baddr = (((nabs >> lgR) - qb3) << 2) + hb4;
             ssq_f2 are2, aim2;
             {
                 int fr[TILE_W], fi[TILE_W];
@@ -1128,16 +1187,27 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                 SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                 SSQ_LDS_WAIT();
                 T2_STAMP(3);                                   // taps gathered
+                if (pc.it < isp) {                             // (wave-uniform: the wavefront's first or second class)
 #pragma unroll
-                for (int t = 0; t < TILE_W; ++t) {
-                    ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
-                    if (t == 0) { SSQ_PK_MUL_LO(are2, wt[0], sv); SSQ_PK_MUL_HI(aim2, wt[0], sv); }
-                    else { SSQ_PK_FMA_LO(are2, wt[t], sv); SSQ_PK_FMA_HI(aim2, wt[t], sv); }
+                    for (int t = 0; t < TILE_W; ++t) {
+                        ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
+                        if (t == 0) { SSQ_PK_MUL_LO(are2, wta[0], sv); SSQ_PK_MUL_HI(aim2, wta[0], sv); }
+                        else { SSQ_PK_FMA_LO(are2, wta[t], sv); SSQ_PK_FMA_HI(aim2, wta[t], sv); }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TILE_W; ++t) {
+                        ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
+                        if (t == 0) { SSQ_PK_MUL_LO(are2, wtb[0], sv); SSQ_PK_MUL_HI(aim2, wtb[0], sv); }
+                        else { SSQ_PK_FMA_LO(are2, wtb[t], sv); SSQ_PK_FMA_HI(aim2, wtb[t], sv); }
+                    }
                 }
             }
             const float are = are2.x, aim = aim2.x;
             float dre = are2.y, dim = aim2.y;
-            const int kcs = rc.y & 0x3FFFFF;                   // centre bin of the lane's row
+            int kcs = Rc[4];                                    // centre bin of the lane's row
+#pragma unroll
+            for (int k = 1; k < RPI; ++k) if (h == k) kcs = Rc[4 + k];
             const float theta = (float)kcs * A.theta_scale;
             dre = __builtin_fmaf(-theta, aim, dre);
             dim = __builtin_fmaf(theta, are, dim);
@@ -1145,12 +1215,13 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
             const float2 Wv = cmulf(tw, make_float2(are, aim));
             const float2 Dv = cmulf(tw, make_float2(dre, dim));
-            char* Wx8 = reinterpret_cast<char*>(A.Wx + (int64_t)(A.sig0 + pc.sg) * na * N);
-            const unsigned wxo = (unsigned)rc.w + (unsigned)colc * 8u;
-            if (!(SSQ_TILE_EXP & 256) || Wv.x == 123.456f) *reinterpret_cast<float2*>(Wx8 + (size_t)wxo) = Wv;
+            // (lanes past the last column hold another column's weights, padded sub-rows another row's
+            // samples: their values go nowhere)
+            char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off * 8u + (unsigned)Rc[2]);
+            if (livept && (!(SSQ_TILE_EXP & 256) || Wv.x == 123.456f)) *reinterpret_cast<float2*>(wx8 + (size_t)lane_row8) = Wv;
             if (STORE_D) {
-                char* dWx8 = reinterpret_cast<char*>(A.dWx + (int64_t)(A.sig0 + pc.sg) * na * N);
-                *reinterpret_cast<float2*>(dWx8 + (size_t)wxo) = Dv;
+                char* dwx8 = reinterpret_cast<char*>(A.dWx) + ((size_t)((int64_t)A.sig0 * na * N + pc.off) * 8u + (unsigned)Rc[2]);
+                if (livept) *reinterpret_cast<float2*>(dwx8 + (size_t)lane_row8) = Dv;
             }
             // phase transform and bin: as emit_point<LEAN> of the block kernels
             const float cc = Wv.x, dd = Wv.y, aa = Dv.x, bb = Dv.y;
@@ -1160,36 +1231,39 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             bool ok;
             const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
             const int kf = (kb ^ fx) + fa;
-            const bool livept = colok && !pad;
             int kout = (above && livept) ? kf : -1;
             const bool pend = livept && !(below | (above & ok));
             if (__builtin_amdgcn_ballot_w64(pend)) {
                 if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
             }
-            cell16 = kout >= 0 ? (kout * COLS + c) * 16 : scratch16;
+            cell16 = kout >= 0 ? kout * (COLS * 16) + c16 : scratch16;
             tvx = Wv.x; tvy = Wv.y;
             T2_STAMP(4);                                       // arithmetic, store, bin
         }
-#if !SSQ_TILE2_WT2 && !(SSQ_TILE_EXP & 512)
-        load_wt(wt2[0], R[k1], clampp(pq[k1]));
-#endif
         {
-            const w_t cs = CSTK == 0 ? (w_t)A.cst0 : dc.cs;
+            w_t cs = (w_t)A.cst0;
+            if (CSTK != 0) {
+                const int row0 = w0 & 0x1FF;
+                cs = cstv[row0];
+#pragma unroll
+                for (int k = 1; k < RPI; ++k) { const w_t ck = cstv[min(row0 + k, omax)]; if (h == k) cs = ck; }
+            }
             const double ax = (double)TM::make(tvx, cs), ay = (double)TM::make(tvy, cs);
             SSQ_LDS_ADD_F64(lds_raw, cell16, ax);
             SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay);
         }
-        T2_STAMP(5);                                           // weights of p+1 issued, terms added
-        if (pq[k1].j != pc.j) { finish_tile(pc.tx, pc.sg); T2_STAMP(6); }
-        more = live(pq[k1]);
-        plast = pc;
-        pq[k0] = next_pos(pq[k3]);                             // slot k0 becomes position p + 4
+        T2_STAMP(5);                                           // terms added
+        const bool tile_end = pq[k1].off != pc.off || pidx + 1 >= total;
+        more = ++pidx < total;
+        pq[k0] = advance(pq[k2]);                              // slot k0 becomes position p + 3
+        Rc = items[pq[k1].it];                                 // the next position's records (see above)
+        Rn = items[pq[k0].it];
+        if (tile_end) { finish_tile(pc.tx, pc.sg); T2_STAMP(6); }
     };
     for (;;) {
         body(K0{}); if (!more) break;
         body(K1{}); if (!more) break;
         body(K2{}); if (!more) break;
-        body(K3{}); if (!more) break;
     }
 #ifdef SSQ_TILE2_PROF
     if (blockIdx.x == 100 % gridDim.x && lane == 0 && A.counters)
@@ -1259,49 +1333,84 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
         if ((rc = up((void**)&rows, hp.data(), hp.size() * 4))) return rc;
     }
-    {   // tile2_kernel's items: the rows of a step, 64 / COLS at a time, one packed record per row
+    {   // tile2_kernel's items: 64 / COLS consecutive rows of a step, one record of 8 words per item:
+        // row0 | padded sub-rows << 9 | kind << 12 | lgR << 13, samples of sub-row 0 (class offset + row
+        // in class * L), row0 * N * 8, entries between two signals' rows of the class, centre bins
         const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
-        int lgM_ = 0; while (((int64_t)1 << lgM_) < M) ++lgM_;
         cols2 = tile2_lds_bytes(na, 32) <= 160 * 1024 ? 32 : 16;
         SSQ_REQUIRE(tile2_lds_bytes(na, cols2) <= 160 * 1024, "na = %lld: the Tx tile exceeds the LDS", (long long)na);
-        std::vector<int32_t> hi4((size_t)nsteps * TILE_G * 4);
-        std::vector<float> cost((size_t)nsteps * TILE_G, 0.f);
-        const float rb_cost = getenv("SSQ_TILE2_RB_COST") ? (float)atof(getenv("SSQ_TILE2_RB_COST")) : 0.4f;
-        for (int i = 0; i < nsegs; ++i) {
-            SSQ_REQUIRE(sg[i].kind == 0 || (sg[i].wtab_off < 65536 && sg[i].sig_stride % ((int64_t)M >> sg[i].lgR) == 0
-                                            && sg[i].sig_stride / ((int64_t)M >> sg[i].lgR) < 1024),
-                        "tile segment %d does not fit an item record", i);
-            for (int t = 0; t < sg[i].nsteps * TILE_G; ++t) {
-                const size_t r = (size_t)sg[i].first * TILE_G + t;
-                const int32_t row = rw[r].row & 0xFFFF;
-                const int32_t nrows_c = sg[i].kind ? (int32_t)(sg[i].sig_stride / ((int64_t)M >> sg[i].lgR)) : 0;
-                hi4[4 * r] = row | (rw[r].row < 0 ? 0x200 : 0) | (sg[i].kind << 10) | (sg[i].lgR << 11)
-                             | (int32_t)((uint32_t)(sg[i].kind ? sg[i].wtab_off : 0) << 16);
-                hi4[4 * r + 1] = rw[r].kc | (int32_t)((uint32_t)nrows_c << 22);
-                hi4[4 * r + 2] = sg[i].kind ? sg[i].cls_base + rw[r].ubase : 0;
-                hi4[4 * r + 3] = (int32_t)(uint32_t)((int64_t)row * N * 8);
-                cost[r] = sg[i].kind ? 1.0f : rb_cost;              // what a row read back costs next to an interpolated one
-            }
-        }
-        if ((rc = up((void**)&items2, hi4.data(), hi4.size() * 4))) return rc;
-        // contiguous, cost-balanced blocks of items per wavefront, for both workgroup sizes
         const int rpi = 64 / cols2;
+        SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
         n_items2 = nsteps * TILE_G / rpi;
-        std::vector<int32_t> wf;
-        for (int nw : {8, 12, 16}) {
-            std::vector<double> pre((size_t)n_items2 + 1, 0.0);
-            for (int it = 0; it < n_items2; ++it) pre[it + 1] = pre[it] + cost[(size_t)it * rpi];
-            wf.push_back(0);
-            for (int w = 1; w <= nw; ++w) {
-                const double want = pre[n_items2] * w / nw;
-                int it = wf.back();
-                while (it < n_items2 && pre[it + 1] <= want + 1e-9) ++it;
-                if (w == nw) it = n_items2;
-                wf.push_back(it);
+        std::vector<int32_t> hi8((size_t)n_items2 * 8, 0);
+        std::vector<float> cost((size_t)n_items2, 0.f);
+        std::vector<int32_t> icls((size_t)n_items2, 0), woff((size_t)n_items2, 0);
+        const float rb_cost = getenv("SSQ_TILE2_RB_COST") ? (float)atof(getenv("SSQ_TILE2_RB_COST")) : 0.7f;
+        tile2_ok = true;
+        lgr_max2 = 0;
+        for (int i = 0; i < nsegs; ++i) {
+            const int64_t L = (int64_t)M >> sg[i].lgR;
+            if (sg[i].kind && (sg[i].wtab_off >= 65536 || sg[i].sig_stride % L)) tile2_ok = false;
+            if (sg[i].kind) lgr_max2 = std::max(lgr_max2, (int)sg[i].lgR);
+            for (int t = 0; t < sg[i].nsteps * TILE_G / rpi; ++t) {
+                const size_t it = (size_t)sg[i].first * TILE_G / rpi + t;
+                const TileRow* r = rw + it * rpi;
+                int npad = 0;
+                for (int k = 0; k < rpi; ++k) {
+                    if (r[k].row < 0) ++npad;
+                    else if (npad) tile2_ok = false;                  // padding trails
+                    // the sub-rows are consecutive rows of the class (the padding repeats the last one)
+                    if (r[k].row >= 0 && ((r[k].row & 0xFFFF) != (r[0].row & 0xFFFF) + k
+                                          || (sg[i].kind && r[k].ubase != r[0].ubase + k * L))) tile2_ok = false;
+                    hi8[8 * it + 4 + k] = r[k].kc;
+                }
+                const int32_t row0 = r[0].row & 0xFFFF;
+                hi8[8 * it] = row0 | (npad << 9) | (sg[i].kind << 12) | (sg[i].lgR << 13);
+                hi8[8 * it + 1] = sg[i].kind ? sg[i].cls_base + r[0].ubase : 0;
+                hi8[8 * it + 2] = (int32_t)(uint32_t)((int64_t)row0 * N * 8);
+                hi8[8 * it + 3] = sg[i].kind ? sg[i].sig_stride : 0;
+                cost[it] = sg[i].kind ? 1.0f : rb_cost;               // what rows read back cost next to interpolated ones
+                icls[it] = sg[i].kind ? 1 + sg[i].lgR : 0;
+                woff[it] = sg[i].kind ? sg[i].wtab_off : 0;
             }
         }
-        if ((rc = up((void**)&wave_first2, wf.data(), wf.size() * 4))) return rc;
+        if ((rc = up((void**)&items2, hi8.data(), hi8.size() * 4))) return rc;
+        // Contiguous, cost-balanced blocks of items per wavefront, each spanning at most TWO classes
+        // (kind / decimation): the kernel keeps the weights of two classes in registers. Tables for
+        // 12 and 16 wavefronts, [nw][4] = first item, end, first item of the second class, the
+        // weights' table offsets of the two classes (16 bits each).
+        std::vector<int> run_start;                        // maximal runs of one class
+        for (int it = 0; it < n_items2; ++it)
+            if (it == 0 || icls[it] != icls[it - 1]) run_start.push_back(it);
+        const int nruns = (int)run_start.size();
+        run_start.push_back(n_items2);
+        std::vector<double> pre((size_t)n_items2 + 1, 0.0);
+        for (int it = 0; it < n_items2; ++it) pre[it + 1] = pre[it] + cost[it];
+        std::vector<int32_t> wt_;
+        for (int nw : {12, 16}) {
+            int cur = 0;
+            for (int w = 0; w < nw; ++w) {
+                if (cur >= n_items2) { wt_.insert(wt_.end(), {n_items2, n_items2, n_items2, 0}); continue; }
+                int r0 = 0;
+                while (run_start[r0 + 1] <= cur) ++r0;
+                const int maxe = run_start[std::min(r0 + 2, nruns)];          // at most the rest of this run and the next
+                const int rem = nw - w - 1;
+                const int rmin = std::max(r0, nruns - 2 * rem);               // the rest must fit the remaining wavefronts
+                int mine = rem == 0 ? n_items2 : run_start[std::min(rmin, nruns)];
+                mine = std::max(mine, cur + 1);
+                int e = cur;
+                const double want = pre[n_items2] * (w + 1) / nw;
+                while (e < n_items2 && pre[e + 1] <= want + 1e-9) ++e;
+                e = std::min(std::max(e, mine), maxe);
+                if (rem == 0) { e = n_items2; if (e > maxe) tile2_ok = false; }
+                const int isp = run_start[r0 + 1] < e ? run_start[r0 + 1] : e;
+                wt_.insert(wt_.end(), {cur, e, isp, woff[cur] | (woff[std::min(isp, n_items2 - 1)] << 16)});
+                cur = e;
+            }
+            if (cur < n_items2) tile2_ok = false;
+        }
+        if ((rc = up((void**)&wave_first2, wt_.data(), wt_.size() * 4))) return rc;
     }
     {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
@@ -1375,8 +1484,9 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
         if ((rc = up(&ftw, tw.data(), tw.size() * 4))) return rc;
     }
-    SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * group * u_total)); bytes += 8 * group * u_total;
-    SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * group * u_total));
+    // (+ 4 rows of slack: tile2_kernel's padded sub-rows read, and discard, the rows behind a class's last)
+    SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * (group * u_total + 4 * lmax))); bytes += 8 * (group * u_total + 4 * lmax);
+    SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * (group * u_total + 4 * lmax)));
     SSQ_CHECK_HIP(hipMalloc((void**)&counters, 4096));       // [0]: tiles done; [8 ..]: tuning aid (SSQ_TILE2_PROF)
     SSQ_CHECK_HIP(hipMemset(counters, 0, 4096));
     for (size_t c = 0; c < cls.size(); ++c) {
@@ -1602,10 +1712,15 @@ static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams
         attr_set = true;
     }
     const int64_t ntx = (P.N + COLS - 1) / COLS;
-    // persistent workgroups: as many as fit a CU's LDS side by side, each walks tiles b, b + G, ...
+    // Persistent workgroups: as many as fit a CU's LDS side by side, workgroup b walks tiles b, b + G,
+    // ... of every signal. The kernel keeps a lane's interpolation weights for the whole launch, so
+    // the columns of a workgroup's tiles must agree mod R for every class: G * COLS a multiple of the
+    // largest R (or a single tile per signal and workgroup).
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds, (size_t)(32 / NW)));
-    const dim3 grid((unsigned)std::min<int64_t>(ntx, (int64_t)P.ncu * per_cu));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, A, sp);
+    const int64_t cap = (int64_t)P.ncu * per_cu;
+    const int64_t q = std::max<int64_t>(1, ((int64_t)1 << P.lgr_max2) / COLS);
+    const int64_t G = ntx <= cap ? ntx : std::max<int64_t>(q, cap / q * q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, A, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
@@ -1618,32 +1733,30 @@ static int launch_tile2_k(const TilePlan& P, const Tile2Args& A, const SsqParams
 }
 template <int GRID, bool STORE_D>
 static int launch_tile2(const TilePlan& P, Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
-    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 16; return v == 8 || v == 12 ? v : 16; }();
-    // wave_first2 holds the partitions for 8, 12 and 16 wavefronts one after the other
-    A.wave_first = P.wave_first2 + (nw == 8 ? 0 : nw == 12 ? 9 : 22);
+    static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 16; return v == 12 ? 12 : 16; }();
+    // wave_first2 holds the blocks for 12 and for 16 wavefronts one after the other
+    A.waves = reinterpret_cast<const int4*>(P.wave_first2) + (nw == 12 ? 0 : 12);
     if (P.cols2 == 32) {
-        if (nw == 8) return launch_tile2_k<GRID, STORE_D, 8, 32>(P, A, sp, stream);
         if (nw == 12) return launch_tile2_k<GRID, STORE_D, 12, 32>(P, A, sp, stream);
         return launch_tile2_k<GRID, STORE_D, 16, 32>(P, A, sp, stream);
     }
-    if (nw == 8) return launch_tile2_k<GRID, STORE_D, 8, 16>(P, A, sp, stream);
     if (nw == 12) return launch_tile2_k<GRID, STORE_D, 12, 16>(P, A, sp, stream);
     return launch_tile2_k<GRID, STORE_D, 16, 16>(P, A, sp, stream);
 }
 
-// SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, na <= 318);
-// default: tile2_kernel (float64 tile, unordered adds)
+// SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
+// 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
 bool tile_ordered() {
     const char* e = getenv("SSQ_TILE_ORDER");       // (read at every launch: tests switch it)
-    return !(e && !strcmp(e, "f64"));               // (the float64 form is opt-in until it is the faster one)
+    return e && !strcmp(e, "ordered");
 }
-int TilePlan::tile_cols() const { return tile_ordered() ? TILE_COLS : cols2; }
+int TilePlan::tile_cols() const { return (tile_ordered() || !tile2_ok) ? TILE_COLS : cols2; }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
-    if (!tile_ordered()) {
+    if (!tile_ordered() && tile2_ok) {
         Tile2Args B;
-        B.items = reinterpret_cast<const int4*>(items2); B.wave_first = wave_first2;
+        B.items = reinterpret_cast<const int*>(items2); B.waves = nullptr;
         B.wtab = (const float4*)wtab; B.U = (const float2*)U; B.cst = cst;
         B.Wx = (float2*)Wx; B.dWx = (float2*)dWx; B.Tx = (float2*)Tx; B.kidx = kidx;
         B.N = N; B.na = na; B.n_items = n_items2; B.n1 = (int)n1; B.mmask = (int)(M - 1);

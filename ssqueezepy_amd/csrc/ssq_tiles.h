@@ -62,9 +62,11 @@ struct TilePlan {
     void* U = nullptr;                      // group x u_total complex64
     unsigned long long* counters = nullptr; // [0]: tiles the kernel has finished since plan creation
     // tile2_kernel (float64 tile, unordered adds): packed item records, [steps * 4] int4; the
-    // partitions of the items among 8 / 12 / 16 wavefronts (9 + 13 + 17 entries); columns per tile
+    // wavefronts' blocks of items for 12 and 16 wavefronts ([12 + 16][4]); columns per tile
     void* items2 = nullptr; int32_t* wave_first2 = nullptr;
     int n_items2 = 0, cols2 = 32;
+    int lgr_max2 = 0;                       // largest decimation (log2) among the interpolated classes
+    bool tile2_ok = false;                  // the items could be cut into blocks of at most two classes
     int tile_cols() const;                  // columns per tile of the kernel that `run` launches
     // A, B > 0: a long class transformed by the four-step kernels of ssq_cwt_tiles.hip (L = A B);
     // A = 0, B = 1: a short class (64 .. 4096 entries) transformed by the one-pass kernel;

@@ -91,6 +91,63 @@ def orc():
     return oracle
 
 
+# ---- Tx of the fused ssq_cwt on the column-tile path -----------------------------------------
+# The default tile kernel (csrc/ssq_cwt_tiles.hip: tile2_kernel) adds a cell's terms in float64, in
+# the order the wavefronts get to them, and rounds once: the BINS are the integers of the CPU loop,
+# the sums differ from the reference's running float32 sums (algos.py:912-924) by those sums' own
+# rounding -- ~1e-7 of the largest cell (measured 2.4e-7 at config 2), bounded here at 1e-6.
+# SSQ_TILE_ORDER=ordered selects the ticketed kernel, whose sums are the CPU loop's bit for bit; the
+# tests that check Tx against the oracle run in both modes.
+TX_SUM_TOL = 1e-6
+
+
+def tile_order():
+    return 'ordered' if os.environ.get('SSQ_TILE_ORDER') == 'ordered' else 'f64'
+
+
+@pytest.fixture(params=['f64', 'ordered'])
+def tile_mode(request, monkeypatch):
+    monkeypatch.setenv('SSQ_TILE_ORDER', request.param)
+    return request.param
+
+
+def tiles_in_play():
+    """True when a cached CWT plan carries the column-tile tables (the fused float32 `ssq_cwt`
+    may have run on the tile kernels); False keeps the comparisons bit for bit."""
+    from ssqueezepy_amd import _cwt
+    return any(getattr(p, 'tile_rows', 0) > 0 for p in _cwt._PLAN_CACHE.values())
+
+
+def assert_tx_vs_oracle(Tx, ref, tiles=None, what=''):
+    """`Tx` against the oracle's reassignment (reference order, float32 sums) of the device's own
+    (Wx, dWx). Bit for bit unless the unordered tile kernel produced it (`tiles` and default mode): a
+    point in a wrong bin would move |Wx| * const -- 1e-3 .. 1 of the largest cell -- so 1e-6 of the
+    largest cell still pins every bin that matters, and the sums to float32 rounding."""
+    if tiles is None:
+        tiles = tiles_in_play() and Tx.dtype == np.complex64
+    if not tiles or tile_order() == 'ordered':
+        assert np.array_equal(Tx, ref), what
+        return 0.0
+    err = float(np.abs(Tx - ref).max() / np.abs(ref).max())
+    assert err <= TX_SUM_TOL, (what, err)
+    return err
+
+
+def assert_tx_repeat(T1, T2, tiles=None, what=''):
+    """Two runs of the same kernel on the same data (batched / single, lean / full build, ...). The
+    float64 sums of the default tile kernel round the same way in any arrival order except when the
+    exact sum sits within ~1e-16 of a float32 rounding boundary: identical but for a stray last bit."""
+    if tiles is None:
+        tiles = tiles_in_play() and T1.dtype == np.complex64
+    if not tiles or tile_order() == 'ordered':
+        assert np.array_equal(T1, T2), what
+        return
+    ne = T1 != T2
+    assert ne.mean() <= 1e-6, (what, float(ne.mean()))
+    if ne.any():
+        assert np.abs(T1 - T2).max() <= TX_SUM_TOL * np.abs(T2).max(), what
+
+
 def report_measured(test, **values):
     """Print the measured parity figures of a test and append them to
     ``gpurun_out/parity_measured.jsonl`` (when that directory exists): the bounds asserted in the

@@ -42,6 +42,7 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 // LDS float64 add (ds_add_f64) and the LDS-only workgroup barrier of tile2_kernel
 #define SSQ_LDS_ADD_F64(base, off, val) (*reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(base) + (off)) += (val))
 #define SSQ_WG_BARRIER() __syncthreads()
+#define SSQ_CONST_PTR(T, p) reinterpret_cast<const T*>(p)
 #define SSQ_LDS_WAITN(n) ((void)0)
 #define __global__
 #define __device__

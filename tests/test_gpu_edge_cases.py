@@ -5,7 +5,7 @@ time vectors, odd n_fft, short windows, single-scale banks, plan-cache reuse."""
 import os
 import numpy as np
 import pytest
-from conftest import two_chirps
+from conftest import two_chirps, assert_tx_vs_oracle, assert_tx_repeat, tile_mode  # noqa: F401
 from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
 
 pytestmark = pytest.mark.gpu
@@ -34,7 +34,7 @@ def test_cwt_odd_and_boundary_lengths(S, orc, N):
         assert relmax(Wx, r['Wx']) <= tol and relmax(dWx, r['dWx']) <= tol
         ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                            True, typing=NUMBA)
-        assert np.array_equal(Tx, ref)
+        assert_tx_vs_oracle(Tx, ref)
 
 
 def test_cwt_unpadded_custom_scales_and_time_vector(S, orc):
@@ -216,7 +216,8 @@ def test_batches_larger_than_a_launch_group(S):
     Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=16)
     for s in (0, 7, 15, 16, 20):
         T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=16)
-        assert torch.equal(Tb[s], T1) and torch.equal(Wb[s], W1), s
+        assert torch.equal(Wb[s], W1), s
+        assert_tx_repeat(Tb[s].cpu().numpy(), T1.cpu().numpy(), what=s)
 
 
 @pytest.mark.parametrize('N', [100000, 1 << 20])
@@ -236,7 +237,7 @@ def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
         _cwt.clear_plan_cache()
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
-        assert plan.tiles_done() == _tiles_of(N)
+        assert plan.tiles_done() == plan.tiles_per_signal(N)
         res[mode] = (Wx, dWx)
         lmax = int(plan.tile_plan['classes'][:, 0].max())
     assert lmax >= (1 << 16)
@@ -248,13 +249,15 @@ def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
     xb = np.stack([x, x[::-1].copy()])
     Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
     T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
-    assert np.array_equal(Wb[1], W1) and np.array_equal(Tb[1], T1)
+    assert np.array_equal(Wb[1], W1)
+    assert_tx_repeat(Tb[1], T1)
     _cwt.clear_plan_cache()
 
 
-def test_tile_path_with_few_scales_and_many_tiles(S, orc):
-    """Few scales (wavefronts of the tile kernel without a step of their own) and a length that
-    gives every persistent workgroup several tiles, the last one partial."""
+def test_tile_path_with_few_scales_and_many_tiles(S, orc, tile_mode):
+    """Few scales (wavefronts of the tile kernels without a step / item of their own) and a length
+    that gives every persistent workgroup several tiles, the last one partial (odd lengths: the
+    float64 kernel's column-by-column write-out)."""
     from pipeline import oracle_ssq_cwt, GRIDNAME
     for N, nv in ((70001, 2), (33333, 1)):
         x = two_chirps(N, seed=N)
@@ -264,17 +267,14 @@ def test_tile_path_with_few_scales_and_many_tiles(S, orc):
         assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
         ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                            True, typing=0)
-        assert np.array_equal(Tx, ref)
-
-
-def _tiles_of(N, B=1):
-    return B * ((N + 63) // 64)
+        assert_tx_vs_oracle(Tx, ref, tiles=True)
 
 
 @pytest.mark.parametrize('case', ['log/linear', 'log/log-piecewise', 'log-piecewise', 'linear',
                                   'log/f32-weights', 'log/f64-weights'])
-def test_tile_kernel_every_instantiation(S, orc, case):
-    """Every build of the column-tile kernel, at a length where the block path (M >= 4096) and
+def test_tile_kernel_every_instantiation(S, orc, case, tile_mode):
+    """Every build of both column-tile kernels (`tile_mode`: the float64 tile with unordered adds --
+    the default -- and the ticketed float32 tile), at a length where the block path (M >= 4096) and
     the tile (na <= 316) are both active: the three frequency-grid kinds x the three kinds of
     reassignment weights (one float32; a float32 per row; a float64 per row -- the reference's
     default 'log-piecewise' scales and its 'linear' scales, ssqueezing.py:126-128 ->
@@ -329,11 +329,44 @@ def test_tile_kernel_every_instantiation(S, orc, case):
         out = plan.execute(xd, want_Tx=True)
         T2, W2 = out['Tx'].cpu().numpy(), out['Wx'].cpu().numpy()
         n_calls = 2
-    if plan.tile_rows > 0:
-        assert plan.tiles_done() == n_calls * _tiles_of(N), (plan.tiles_done(), plan.algo)
-    if case != 'linear':
-        assert plan.tile_rows > 0.5 * plan.na, (plan.tile_rows, plan.na)
     ref = orc.ssqueeze(Wx, dWx, GRIDNAME[grid], params, const, gamma, True, typing=0)
-    assert np.array_equal(Tx, ref)
+    if case == 'linear':
+        # 'linear' SCALES leave no row decimated enough for the tile kernels (GRID_LIN on the tile
+        # path is what 'log/linear' covers): this case is the block rows + the separate reassignment
+        # kernel with float64 per-row weights, bit for bit
+        assert plan.tile_rows == 0 and plan.tiles_done() == 0, (plan.tile_rows, plan.algo)
+        assert np.array_equal(Tx, ref) and np.array_equal(T2, Tx) and np.array_equal(W2, Wx)
+        return
+    assert plan.tile_rows > 0.5 * plan.na, (plan.tile_rows, plan.na)
+    assert plan.tile_cols == (64 if tile_mode == 'ordered' else 32)
+    assert plan.tiles_done() == n_calls * plan.tiles_per_signal(N), (plan.tiles_done(), plan.algo)
+    assert_tx_vs_oracle(Tx, ref, tiles=True, what=case)
     # the lean build (no dWx stored) against the full one
-    assert np.array_equal(T2, Tx) and np.array_equal(W2, Wx)
+    assert np.array_equal(W2, Wx)
+    assert_tx_repeat(T2, Tx, tiles=True, what=case)
+
+
+def test_more_rows_than_the_32_column_tile_holds(S, orc):
+    """456 rows -- `process_scales('log', N, nv=32)` without the `[:300]` of the benchmark --
+    exceed the 318 rows a 32-column float64 tile (and the ticketed kernel's 64-column float32 tile)
+    can keep in a CU's LDS: the default tile kernel then runs 16-column tiles, four rows per
+    wavefront instruction. What executed is asserted on, and the result against the oracle."""
+    from ssqueezepy_amd import _cwt
+    from pipeline import oracle_ssq_cwt, GRIDNAME
+    N = 20000 if os.environ.get('SSQ_EMULATE') == '1' else 160000
+    wav = S.Wavelet()
+    scales = S.process_scales('log', N, wav, nv=32 if N == 160000 else 40)
+    x = two_chirps(N, seed=11)
+    _cwt.clear_plan_cache()
+    Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True, astensor=False)
+    plan = next(iter(_cwt._PLAN_CACHE.values()))
+    assert plan.na == len(scales) > 318
+    assert plan.tile_cols == 16 and plan.tile_rows > 0.5 * plan.na
+    assert plan.tiles_done() == plan.tiles_per_signal(N), (plan.tiles_done(), plan.algo)
+    r = oracle_ssq_cwt(orc, x, 'float32', scales=scales)
+    assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
+    assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()
+    ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'], True, typing=0,
+                       parallel=True)
+    assert_tx_vs_oracle(Tx, ref, tiles=True)
+    _cwt.clear_plan_cache()

@@ -13,7 +13,7 @@ column sums; and elementwise with the reference's tolerance.
 """
 import numpy as np
 import pytest
-from conftest import golden, two_chirps
+from conftest import golden, two_chirps, assert_tx_vs_oracle, assert_tx_repeat
 from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
 
 pytestmark = pytest.mark.gpu
@@ -40,7 +40,9 @@ def check_Tx(orc, Tx, Wx, dWx, r, dtype, flipud=True, Sfs=None, grid=None):
     grid = GRIDNAME[r['grid']] if grid is None else grid
     ref = orc.ssqueeze(Wx, dWx, grid, r['params'], r['const'], r['gamma'], flipud,
                        Sfs=Sfs, typing=NUMBA)
-    assert np.array_equal(Tx, ref)
+    # (bit for bit, except for a Tx the unordered tile kernel produced: conftest.assert_tx_vs_oracle)
+    from conftest import assert_tx_vs_oracle
+    assert_tx_vs_oracle(Tx, ref, tiles=None if Sfs is None else False)
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
@@ -101,7 +103,7 @@ def test_ssq_cwt_options(S, orc, dtype):
     # flipud=False
     Tx2, Wx2, *_ = S.ssq_cwt(x, wav, scales='log', nv=16, flipud=False, astensor=False)
     Txf, *_ = S.ssq_cwt(x, wav, scales='log', nv=16, astensor=False)
-    assert np.array_equal(Tx2, Txf[::-1])
+    assert_tx_repeat(Tx2, Txf[::-1])
     # fs != 1 (derivative scaling by 1/dt)
     x = g['x/300']
     Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=8, fs=400.,
@@ -117,7 +119,8 @@ def test_ssq_cwt_options(S, orc, dtype):
     assert Txb.shape == g['Tx/batch200'].shape
     for b in range(len(xb)):
         Tx1, Wx1, *_ = S.ssq_cwt(xb[b], wav, scales='log', nv=8, astensor=False)
-        assert np.array_equal(Txb[b], Tx1) and np.array_equal(Wxb[b], Wx1)
+        assert np.array_equal(Wxb[b], Wx1)
+        assert_tx_repeat(Txb[b], Tx1)
         assert relmax(Wxb[b], g['Wx/batch200'][b]) <= RTOL[dtype]
 
 
@@ -283,13 +286,14 @@ def test_full_size_bin_map_exact(S, orc):
     x = two_chirps(N, seed=3)
     Tx, Wx, sf, sc = S.ssq_cwt(x, wav, scales=scales, astensor=False)          # lean kernels
     Tx2, Wx2, _, _, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True, astensor=False)
-    assert np.array_equal(Wx, Wx2) and np.array_equal(Tx, Tx2)
+    assert np.array_equal(Wx, Wx2)
+    assert_tx_repeat(Tx, Tx2)
     from ssqueezepy_amd.ssqueezing import ssq_grid_params
     kind, p = ssq_grid_params(sf[::-1], True)      # ssq_cwt returns the flipped (descending) grid
     st = {0: 'log', 1: 'log-piecewise'}[kind]
     gamma = 10 * np.finfo(np.float32).eps
     ref = orc.ssqueeze(Wx, dWx, st, p, np.log(2) / 32, gamma, True, typing=0, parallel=True)
-    assert np.array_equal(Tx, ref)
+    assert_tx_vs_oracle(Tx2, ref)
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
@@ -367,9 +371,11 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
     assert relmax(out[1], Wx) <= tol / 2      # two-step form: every row on the block kernels
     xb = np.stack([x, x[::-1].copy()])
     Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
-    assert np.array_equal(Wxb[0], Wx) and np.array_equal(Txb[0], Tx)
+    assert np.array_equal(Wxb[0], Wx)
+    assert_tx_repeat(Txb[0], Tx)
     T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
-    assert np.array_equal(Wxb[1], W1) and np.array_equal(Txb[1], T1)
+    assert np.array_equal(Wxb[1], W1)
+    assert_tx_repeat(Txb[1], T1)
 
 
 def test_ssqueeze_squeezing_modes_and_stft_config3(S, orc):

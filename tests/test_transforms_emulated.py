@@ -162,16 +162,17 @@ def test_custom_wavelet_functions_do_not_share_cached_plans():
     assert outs[0].shape == outs[1].shape and np.abs(outs[0] - outs[1]).max() > 1e-3
 
 
-def test_tile_path_emulated_vs_oracle():
-    """The column-tile path of the fused ssq_cwt (persistent workgroups, ordered ticket
-    updates, several tiles per workgroup) under the emulator: Wx / dWx against the oracle,
-    Tx bit for bit against the oracle's reassignment of the device's own Wx / dWx, lean ==
-    full instantiation, batched == single; odd length (last tile partial) and both
-    exponential grids."""
+def test_tile_path_emulated_vs_oracle(tile_mode):
+    """The column-tile path of the fused ssq_cwt (persistent workgroups, several tiles per
+    workgroup; both tile kernels: float64 tile with unordered adds, ticketed float32 tile) under
+    the emulator: Wx / dWx against the oracle, Tx against the oracle's reassignment of the device's
+    own Wx / dWx (bit for bit in the ordered mode, to float32 rounding otherwise), lean == full
+    instantiation, batched == single; odd length (last tile partial, column-by-column write-out) and
+    both exponential grids."""
     import emu_backend
     from oracle import oracle as orc
     from pipeline import oracle_ssq_cwt, GRIDNAME
-    from conftest import two_chirps
+    from conftest import two_chirps, assert_tx_vs_oracle, assert_tx_repeat
     with emu_backend.emulated() as S:
         from ssqueezepy_amd import _cwt
         for N, st in ((5003, 'log-piecewise'), (2500, 'log')):
@@ -180,20 +181,24 @@ def test_tile_path_emulated_vs_oracle():
             _cwt.clear_plan_cache()
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=st, nv=16, get_dWx=True, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
-            assert plan.tile_rows > 0.5 * plan.na and plan.tiles_done() == (N + 63) // 64
+            assert plan.tile_cols == (64 if tile_mode == 'ordered' else 32)
+            assert plan.tile_rows > 0.5 * plan.na and plan.tiles_done() == plan.tiles_per_signal(N)
             r = oracle_ssq_cwt(orc, x, 'float32', scales=st, nv=16)
             assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
             assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()
             ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                                True, typing=0)
-            assert np.array_equal(Tx, ref)
+            assert_tx_vs_oracle(Tx, ref)
             T2, W2, *_ = S.ssq_cwt(x, wav, scales=st, nv=16, astensor=False)
-            assert np.array_equal(T2, Tx) and np.array_equal(W2, Wx)
+            assert_tx_repeat(T2, Tx)
+            assert np.array_equal(W2, Wx)
         xb = np.stack([x, x[::-1].copy()])
         Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales=st, nv=16, astensor=False)
-        assert np.array_equal(Tb[0], Tx) and np.array_equal(Wb[0], Wx)
+        assert_tx_repeat(Tb[0], Tx)
+        assert np.array_equal(Wb[0], Wx)
         T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales=st, nv=16, astensor=False)
-        assert np.array_equal(Tb[1], T1) and np.array_equal(Wb[1], W1)
+        assert_tx_repeat(Tb[1], T1)
+        assert np.array_equal(Wb[1], W1)
 
 
 def test_tile_intermediates_four_step_emulated(monkeypatch):
@@ -218,7 +223,7 @@ def test_tile_intermediates_four_step_emulated(monkeypatch):
             _cwt.clear_plan_cache()
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
-            assert plan.tiles_done() == (N + 63) // 64
+            assert plan.tiles_done() == plan.tiles_per_signal(N)
             assert {65536, 32768, 16384} <= set(int(v) for v in plan.tile_plan['classes'][:, 0])
             res[mode] = (Wx, dWx, Tx)
         r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
@@ -229,9 +234,12 @@ def test_tile_intermediates_four_step_emulated(monkeypatch):
         _cwt.clear_plan_cache()
         xb = np.stack([x, x[::-1].copy()])
         Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
-        assert np.array_equal(Wb[0], res['own'][0]) and np.array_equal(Tb[0], res['own'][2])
+        from conftest import assert_tx_repeat
+        assert np.array_equal(Wb[0], res['own'][0])
+        assert_tx_repeat(Tb[0], res['own'][2])
         T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log', nv=nv, astensor=False)
-        assert np.array_equal(Wb[1], W1) and np.array_equal(Tb[1], T1)
+        assert np.array_equal(Wb[1], W1)
+        assert_tx_repeat(Tb[1], T1)
         _cwt.clear_plan_cache()
 
 
@@ -239,7 +247,7 @@ def test_tile_path_emulated_partial_launch_group():
     """More signals than a launch group holds, under the emulator: the partial last group and
     the workspaces reused between groups (see tests/test_gpu_edge_cases.py)."""
     import emu_backend
-    from conftest import two_chirps
+    from conftest import two_chirps, assert_tx_repeat
     N, B = 2200, 18
     xb = np.stack([two_chirps(N, seed=300 + s) for s in range(B)])
     with emu_backend.emulated() as S:
@@ -247,16 +255,17 @@ def test_tile_path_emulated_partial_launch_group():
         Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=8, astensor=False)
         for s in (0, 15, 16, 17):
             T1, W1, *_ = S.ssq_cwt(xb[s], wav, scales='log', nv=8, astensor=False)
-            assert np.array_equal(Tb[s], T1) and np.array_equal(Wb[s], W1), s
+            assert np.array_equal(Wb[s], W1), s
+            assert_tx_repeat(Tb[s], T1, what=s)
 
 
-def test_tile_path_emulated_fewer_steps_than_wavefronts():
-    """Very few scales: some wavefronts of the tile kernel have no step at all and only take
+def test_tile_path_emulated_fewer_steps_than_wavefronts(tile_mode):
+    """Very few scales: some wavefronts of the tile kernels have no step / item at all and only take
     part in the write-out of each tile."""
     import emu_backend
     from oracle import oracle as orc
     from pipeline import oracle_ssq_cwt, GRIDNAME
-    from conftest import two_chirps
+    from conftest import two_chirps, assert_tx_vs_oracle
     with emu_backend.emulated() as S:
         from ssqueezepy_amd import _cwt
         for N, nv in ((4500, 2), (8000, 1)):
@@ -265,9 +274,9 @@ def test_tile_path_emulated_fewer_steps_than_wavefronts():
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, S.Wavelet(), scales='log', nv=nv, get_dWx=True,
                                             astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
-            assert plan.tiles_done() == (N + 63) // 64 and plan.na < 32
+            assert plan.tiles_done() == plan.tiles_per_signal(N) and plan.na < 32
             r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv)
             assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
             ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                                True, typing=0)
-            assert np.array_equal(Tx, ref)
+            assert_tx_vs_oracle(Tx, ref)

@@ -14,6 +14,11 @@ from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
 from conftest import two_chirps
 
 
+def tx_ok(Tx, ref):
+    """bit for bit, or -- the default tile kernel's float64 sums -- to float32 rounding of the reference's"""
+    return np.array_equal(Tx, ref) or np.abs(Tx - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
 def relmax(a, b):
     return np.abs(a - b).max() / np.abs(b).max()
 
@@ -44,12 +49,12 @@ def main(n_cases=30, seed=0):
             eW, eD = relmax(Wx, r['Wx']), relmax(dWx, r['dWx'])
             ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'],
                                r['gamma'], True, typing=0)
-            ok = eW <= tol and eD <= tol and np.array_equal(Tx, ref) and \
+            ok = eW <= tol and eD <= tol and tx_ok(Tx, ref) and \
                 np.array_equal(sf, r['ssq_freqs'])
             if ok and rng.random() < 0.4:             # batched == single, get_w == oracle phase
                 xb = np.stack([x, x[::-1].copy(), 2 * x])
                 Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales=st, nv=nv, padtype=pad, astensor=False)
-                ok = np.array_equal(Wb[0], Wx) and np.array_equal(Tb[0], Tx)
+                ok = np.array_equal(Wb[0], Wx) and tx_ok(Tb[0], Tx)
                 # (the two-step form runs every row on the block kernels: its own Wx / dWx)
                 out = S.ssq_cwt(x, wav, scales=st, nv=nv, padtype=pad, get_w=True, get_dWx=True,
                                 astensor=False)
