@@ -20,9 +20,11 @@ Prints ONE JSON line on rank 0: transforms/s (whole job), ms per step, plus
                timed region, for the whole transform (all of its kernels); `traffic` is
                the PMC figure of the same command (profiles/pmc_traffic.json).
   dominant_kernel
-               the column-tile kernel (interpolation + reassignment, ~2/3 of the time):
-               its own bytes / its own time from the plan's HIP-event stage timing;
-               rocprofv3 --kernel-trace --stats of this command: profiles/r3*_kernel_stats.txt.
+               the column-tile kernel (interpolation + reassignment, ~2/3 of the time; round 4:
+               ssq::tile2_kernel -- float64 tile, unordered ds_add_f64; SSQ_TILE_ORDER=ordered in the
+               environment selects the ticketed ssq::tile_kernel): its own bytes / its own time
+               from the plan's HIP-event stage timing; rocprofv3 --kernel-trace --stats of this
+               command: profiles/r4*_kernel_stats.txt.
   per_gpu      transforms/s, signals and output bytes per step and GPU (--batch 64 is
                BASELINE config 4's per-GPU shape: 49 GB of Tx + Wx per step).
 `--scales log-piecewise` runs the reference's default scales (float64 per-row weights) instead.
@@ -262,7 +264,7 @@ def main():
         bytes_alg = N * 4 + 2 * na * N * 8          # per transform
         t_transform = (gpu_ms / 1e3) / (args.steps * B)   # per GPU, event-timed
         achieved = bytes_alg / t_transform / 1e9
-        traffic = None
+        traffic = traffic_sha = None
         tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.isfile(tfile) and (N, na) == (160000, 300):
             # HBM bytes per transform from rocprofv3 PMC passes of this same command
@@ -270,7 +272,9 @@ def main():
             # gfx950 guide prescribes, calibrated on the reassignment kernel's known
             # read volume). Measured offline, not in this run.
             with open(tfile) as fh:
-                traffic = json.load(fh).get('bytes_per_transform')
+                tj = json.load(fh)
+            traffic = tj.get('bytes_per_transform')
+            traffic_sha = tj.get('git_sha')
         line = {
             "metric": "ssq_cwt transforms/sec (N=160k, 300 scales, f32)",
             "value": value, "unit": "transforms/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1),
@@ -285,10 +289,12 @@ def main():
                        "signals_per_gpu_per_step": B,
                        "sharding": "independent signals per rank, no data-path "
                                    "collective; one all_gather of checksums",
-                       "algo": plan.algo},
+                       "algo": plan.algo,
+                       "tile_kernel": ("ordered (ticketed float32 tile)" if os.environ.get('SSQ_TILE_ORDER') == 'ordered'
+                                       else "float64 tile, unordered ds_add_f64") if 'tiles' in plan.algo else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_measured_at": traffic_sha,
                          "scope": "whole transform (all kernels), HIP-event timed",
                          "bytes_alg_per_transform": bytes_alg,
                          "us_per_transform": t_transform * 1e6},
@@ -305,7 +311,7 @@ def main():
             if tiles:
                 # the column-tile kernel: writes Wx of the rows it interpolates and all of Tx,
                 # reads Wx + 2-byte bin of the rows the block / exact kernels left in HBM
-                kname = "ssq::tile_kernel"
+                kname = "ssq::tile_kernel" if os.environ.get('SSQ_TILE_ORDER') == 'ordered' else "ssq::tile2_kernel"
                 acc_bytes = N * (plan.tile_rows * 8 + na * 8 + (na - plan.tile_rows) * 10)
             else:
                 # the reassignment: Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point

@@ -299,7 +299,7 @@ typedef struct {
     const int64_t* classes;      /* n_classes x 4: L, rows, entries per signal before it, log2 R */
     int64_t        u_total;      /* complex entries of the intermediate per signal             */
     int64_t        n_items_tile[5]; /* per L': leading block items that remain (rows read back) */
-    int32_t        reserved;
+    int32_t        reserved;     /* rows per step of `rows` (0 = 4): must equal ssq_cwt_tile_rows_per_step() */
 } ssq_cwt_tiles_desc;
 
 int  ssq_cwt_plan_set_tiles(ssq_cwt_plan* plan, const ssq_cwt_tiles_desc* desc);

@@ -142,6 +142,10 @@ def _margins(vals, off, lo, M, tol, chunk=32, denoise=False, extended=None):
     return out
 
 
+NYQ_EXT_GAIN = 8.0    # a continued row's weights past Nyquist: at most this many times its largest in-band weight
+                      # (banks at the usual densities stay below 3.5; a coarse bank's first row reaches 16 .. 400)
+
+
 def extend_past_nyquist(fn, scales, w_hi, vals, off, lo, M, vals64=None):
     """Continue the Nyquist-cut rows of the banded bank past the Nyquist bin (module
     docstring). `fn`: the wavelet's frequency-domain function, evaluated here in float64
@@ -179,6 +183,15 @@ def extend_past_nyquist(fn, scales, w_hi, vals, off, lo, M, vals64=None):
                     # smooth step 1 -> 0 over (M/2, k_end): equals 1 to 1e-17 at the Nyquist
                     # bin, a Gaussian-shaped response in time
                     e = e * (0.5 * erfc(6 * (2 * (k - half) / float(k_end - half) - 1)))
+                # The bins of x_a above Nyquist are rounding noise (~eps |X|), not zeros: a
+                # continuation much larger than the in-band weights would amplify it -- a wavelet
+                # whose PEAK lies past Nyquist (e.g. the smallest 'bump' scales: in-band weights
+                # ~2e-3 of the peak) would lose three digits of its row. Such rows keep the exact path.
+                inband = float(np.abs(b64).max()) * (2.0 if len(b64) == 1 else 1.0)
+                inband = max(inband, float(np.abs(b64[-1]) * 2))
+                if len(e) and float(np.abs(e).max()) > NYQ_EXT_GAIN * inband:
+                    bands.append(band); bands64.append(b64)
+                    continue
                 band = band.copy(); b64 = b64.copy()
                 band[-1] = band[-1] * 2; b64[-1] = b64[-1] * 2   # the halving moves into X_a (exact)
                 band = np.concatenate([band, e.astype(band.dtype)])

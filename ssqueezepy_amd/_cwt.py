@@ -137,7 +137,10 @@ class CwtPlan():
         tp = None
         if self.dtype == 'float32' and os.environ.get('SSQ_CWT_TILES', '1') != '0':
             # (SSQ_TILE_RMIN: least decimation for which a row leaves the block kernels; tuning aid)
-            tp = plan_tiles(vals, off, lo, self.M, self.N, self.n1, self.dt, rows[:, 0] >= 0,
+            # (candidates: block rows whose band lies below Nyquist -- the rows continued past it are
+            # described by another band than the one plan_tiles is given, and stay block rows)
+            tp = plan_tiles(vals, off, lo, self.M, self.N, self.n1, self.dt,
+                            (rows[:, 0] >= 0) & ~np.asarray(bp['extended'], bool),
                             self.group, row_scale=self._bank[3],
                             r_min=int(os.environ.get('SSQ_TILE_RMIN', _tiles_rmin)))
         n_items_tile = [0] * 5
@@ -187,6 +190,7 @@ class CwtPlan():
         d.n_irows, d.irows = len(irows), irows.ctypes.data
         d.n_classes, d.classes = len(classes), classes.ctypes.data
         d.u_total = tp['u_total']
+        d.reserved = _tiles_rsub                 # rows per step of `rows` (the library checks it against its own)
         for slot in range(5):
             d.n_items_tile[slot] = n_items_tile[slot]
         check(self.lib.ssq_cwt_plan_set_tiles(self._h, ctypes.byref(d)))

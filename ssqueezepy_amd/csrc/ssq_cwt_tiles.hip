@@ -1044,18 +1044,20 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // computed, the data of p + 2 go out. Loads past the end repeat the
     // last position (all loads unconditional, see the note in tile_kernel). A position carries its
     // tile's element offset (signal * na * N + first column), worked out when the tile changes only.
-    struct Pos { int it, tx, sg; int64_t off; };
-    // (the offset moves by constants: to the workgroup's next tile of the signal, or from its last
-    // tile of a signal to its first of the next one -- no 64-bit products per item)
-    const int64_t off_step = (int64_t)G * COLS;
-    const int64_t off_wrap = (int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS;
+    // A position carries its tile as the kernel uses it: n of the tile's first column (n1 + first
+    // column), the signal, and the byte offset of (signal, row 0, first column) in Wx -- moved by
+    // constants from tile to tile (no 64-bit products per item).
+    struct Pos { int it, nabs0, sg; int64_t off8; };
+    const int nabs_step = G * COLS, nabs_first = A.n1 + (int)blockIdx.x * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
+    const int64_t off8_step = (int64_t)G * COLS * 8;
+    const int64_t off8_wrap = ((int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS) * 8;
     auto next_pos = [&](Pos q) {
         Pos r = q;
         if (++r.it >= i1) {
-            r.it = i0; r.tx += G;
-            const bool wrap = r.tx >= ntx;
-            r.off += wrap ? off_wrap : off_step;
-            if (wrap) { r.tx = (int)blockIdx.x; ++r.sg; }
+            r.it = i0; r.nabs0 += nabs_step;
+            const bool wrap = r.nabs0 > nabs_last;
+            r.off8 += wrap ? off8_wrap : off8_step;
+            if (wrap) { r.nabs0 = nabs_first; ++r.sg; }
         }
         return r;
     };
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         if (kind) {                                            // (wave-uniform; the loads themselves stay outside)
             // sample (qb + min(c, wlast)) mod L of row h of the item, h * L entries on
             const int lgR = (w0 >> 13) & 31;
-            const int qb = ((A.n1 + q.tx * COLS) >> lgR) - (TILE_W / 2 - 1);
+            const int qb = (q.nabs0 >> lgR) - (TILE_W / 2 - 1);
             const int wlast = ((COLS - 1) >> lgR) + TILE_W;
             const int lmask = A.mmask >> lgR;                  // L - 1, L = M / R
             voff = (((unsigned)((qb + (c < wlast ? c : wlast)) & lmask)) + ((unsigned)h << (A.lgM - lgR))) * 8u;
@@ -1093,13 +1095,13 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             unsigned lr8 = lane_row8;
             if (RPI == 2) { if (npad) lr8 = lane_col8; }
             else if (npad) lr8 = (unsigned)min(h, RPI - 1 - npad) * nN * 8u + lane_col8;
-            if (q.tx == ntx - 1) {                             // (the last tile may be partial)
-                const int col = q.tx * COLS + c;
+            if (q.nabs0 == nabs_last) {                        // (the last tile may be partial)
+                const int col = q.nabs0 - A.n1 + c;
                 if (col >= (int)N) lr8 -= (unsigned)(col - ((int)N - 1)) * 8u;
             }
             voff = lr8;
-            base = WX8 + ((size_t)q.off * 8u + (unsigned)R[2]);
-            kbase = KX8 + ((size_t)q.off * 2u + ((unsigned)R[2] >> 2));
+            base = WX8 + ((size_t)q.off8 + (unsigned)R[2]);
+            kbase = KX8 + (((size_t)q.off8 + (unsigned)R[2]) >> 2);
             koff = lr8 >> 2;
         }
         d.u = *reinterpret_cast<const float2*>(base + (size_t)voff);
@@ -1129,7 +1131,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
 #endif
     Pos pq[3];
     Data D[3];
-    pq[0].it = i0; pq[0].tx = (int)blockIdx.x; pq[0].sg = 0; pq[0].off = (int64_t)blockIdx.x * COLS;
+    pq[0].it = i0; pq[0].nabs0 = nabs_first; pq[0].sg = 0; pq[0].off8 = (int64_t)blockIdx.x * COLS * 8;
     if (total <= 0) return;
     int pidx = 0;                                              // index of the position in hand
     // (positions past the end repeat the last one: the loads issued for them are valid and unused)
@@ -1156,10 +1158,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         const Data dc = D[k0];
         const int w0 = Rc[0];
         const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
-        const int col0 = pc.tx * COLS;
-        const int nabs = A.n1 + col0 + c;                      // (lanes past the last column: results unused)
+        const int nabs = pc.nabs0 + c;                         // (lanes past the last column: results unused)
         bool livept = h < RPI - npad;
-        if (pc.tx == ntx - 1) livept = livept && col0 + c < (int)N;
+        if (pc.nabs0 == nabs_last) livept = livept && nabs - A.n1 < (int)N;
         int cell16; float tvx, tvy;
         if (kind == 0) {
             const int kk = dc.kq & 0xFFFF;
@@ -1167,7 +1168,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             tvx = dc.u.x; tvy = dc.u.y;
         } else {
             const int lgR = (w0 >> 13) & 31;
-            const int qb3 = ((A.n1 + col0) >> lgR);            // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
+            const int qb3 = pc.nabs0 >> lgR;                   // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
             const int baddr = (((nabs >> lgR) - qb3) << 2) + hb4;
             ssq_f2 are2, aim2;
             {
@@ -1217,10 +1218,10 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             const float2 Dv = cmulf(tw, make_float2(dre, dim));
             // (lanes past the last column hold another column's weights, padded sub-rows another row's
             // samples: their values go nowhere)
-            char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off * 8u + (unsigned)Rc[2]);
+            char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off8 + (unsigned)Rc[2]);
             if (livept && (!(SSQ_TILE_EXP & 256) || Wv.x == 123.456f)) *reinterpret_cast<float2*>(wx8 + (size_t)lane_row8) = Wv;
             if (STORE_D) {
-                char* dwx8 = reinterpret_cast<char*>(A.dWx) + ((size_t)((int64_t)A.sig0 * na * N + pc.off) * 8u + (unsigned)Rc[2]);
+                char* dwx8 = reinterpret_cast<char*>(A.dWx) + ((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]);
                 if (livept) *reinterpret_cast<float2*>(dwx8 + (size_t)lane_row8) = Dv;
             }
             // phase transform and bin: as emit_point<LEAN> of the block kernels
@@ -1253,12 +1254,12 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay);
         }
         T2_STAMP(5);                                           // terms added
-        const bool tile_end = pq[k1].off != pc.off || pidx + 1 >= total;
+        const bool tile_end = pq[k1].off8 != pc.off8 || pidx + 1 >= total;
         more = ++pidx < total;
         pq[k0] = advance(pq[k2]);                              // slot k0 becomes position p + 3
         Rc = items[pq[k1].it];                                 // the next position's records (see above)
         Rn = items[pq[k0].it];
-        if (tile_end) { finish_tile(pc.tx, pc.sg); T2_STAMP(6); }
+        if (tile_end) { finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg); T2_STAMP(6); }
     };
     for (;;) {
         body(K0{}); if (!more) break;
@@ -1278,12 +1279,19 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     M = M_; N = N_; n1 = n1_; na = na_; group = group_; dt = dt_;
     nsegs = d.n_segs; nsteps = d.n_steps; n_irows = d.n_irows; u_total = d.u_total;
     SSQ_REQUIRE(nsegs >= 1 && nsteps >= 1 && n_irows >= 1 && d.n_classes >= 1, "empty tile tables");
+    SSQ_REQUIRE((d.reserved ? d.reserved : 4) == TILE_G, "tile tables hold %d rows per step, this build walks %d",
+                d.reserved ? d.reserved : 4, TILE_G);
     {
         int dev = 0; hipDeviceProp_t pr;
         SSQ_CHECK_HIP(hipGetDevice(&dev));
         SSQ_CHECK_HIP(hipGetDeviceProperties(&pr, dev));
         ncu = pr.multiProcessorCount;
         if (const char* e = getenv("SSQ_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
+        // both tile kernels keep a tile of up to 160 KB in a workgroup's LDS (gfx950); a device with
+        // less refuses the tile path here instead of failing at the first launch
+        SSQ_REQUIRE((size_t)pr.maxSharedMemoryPerMultiProcessor >= 160 * 1024,
+                    "the tile path needs 160 KB of LDS per workgroup, the device has %zu",
+                    (size_t)pr.maxSharedMemoryPerMultiProcessor);
     }
     SSQ_REQUIRE(na * N < ((int64_t)1 << 29) && na < 512, "na = %lld, N = %lld: outside the tile path's 32-bit offsets",
                 (long long)na, (long long)N);

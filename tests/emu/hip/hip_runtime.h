@@ -77,7 +77,8 @@ typedef void* hipEvent_t;
 constexpr hipError_t hipSuccess = 0;
 constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 0;
 constexpr int hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3;
-struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem;
+                         size_t maxSharedMemoryPerMultiProcessor; };
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
@@ -86,7 +87,7 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     strcpy(p->name, "host emulation"); strcpy(p->gcnArchName, "host");
-    p->multiProcessorCount = 3; p->totalGlobalMem = 0;
+    p->multiProcessorCount = 3; p->totalGlobalMem = 0; p->maxSharedMemoryPerMultiProcessor = 160 * 1024;
     return hipSuccess;
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : 2; }

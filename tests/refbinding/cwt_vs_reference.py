@@ -22,7 +22,7 @@ out = []
 with emu_backend.emulated() as S:
     from ssqueezepy_amd import _cwt
     for fam, dtype, N, nv in (('gmw', 'float32', 6000, 8), ('gmw', 'float64', 6000, 8),
-                              ('morlet', 'float32', 9000, 4)):
+                              ('morlet', 'float32', 9000, 8), ('morlet', 'float32', 9000, 4)):
         x = two_chirps(N, seed=N)
         rw = R.Wavelet((fam, {'dtype': dtype}))
         Wr, sr, dWr = R.cwt(x, rw, scales='log', nv=nv, derivative=True)
@@ -31,8 +31,9 @@ with emu_backend.emulated() as S:
                             astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
         ne = plan.extended_rows
-        out.append(dict(family=fam, dtype=dtype, N=N, na=len(sa), extended_rows=ne, algo=plan.algo,
+        cut = int(((plan._bank[2] + np.diff(plan._bank[1])) == plan.M // 2 + 1).sum())
+        out.append(dict(family=fam, dtype=dtype, N=N, nv=nv, na=len(sa), extended_rows=ne, cut_rows=cut, algo=plan.algo,
                         scales_equal=bool(np.array_equal(np.asarray(sr).squeeze(), np.asarray(sa).squeeze())),
                         eW=relmax(Wa, Wr), eD=relmax(dWa, dWr),
-                        eW_extended=relmax(Wa[:ne], np.asarray(Wr)[:ne]) if ne else None))
+                        eW_extended=relmax(Wa[cut - ne:cut], np.asarray(Wr)[cut - ne:cut]) if ne else None))
 print(json.dumps(out))

@@ -55,8 +55,13 @@ def test_nyquist_rows_against_the_reference_itself():
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
-    assert len(rec) == 3
+    assert len(rec) == 4
     for r in rec:
         tol = 1e-5 if r['dtype'] == 'float32' else 1e-12
-        assert r['scales_equal'] and r['extended_rows'] >= 3 and 'fourstep' not in r['algo'], r
+        assert r['scales_equal'] and r['extended_rows'] >= 3, r
+        # every cut row continued -- except the first row of the coarse Morlet bank (nv = 4), whose
+        # peak lies far past Nyquist: the gain limit leaves it on the exact (four-step) path
+        refused = r['cut_rows'] - r['extended_rows']
+        assert refused == (1 if (r['family'], r['nv']) == ('morlet', 4) else 0), r
+        assert ('fourstep' in r['algo']) == (refused > 0), r
         assert r['eW'] <= tol and r['eD'] <= tol and r['eW_extended'] <= tol, r
