@@ -37,64 +37,70 @@ def _flush_denormals(x):
     return x
 
 
-def get_window(window, win_len, n_fft=None, derivative=False, dtype=None):
-    """Length-`n_fft` analysis window (zero-padded symmetrically from `win_len`)
-    and, if `derivative`, its time derivative obtained by frequency-domain
-    differentiation ``ifft(fft(w) * 1j * xi).real``. `window`: None (DPSS, time-
-    bandwidth ``max(4, win_len//8)``), a `scipy.signal.get_window` name, or an
-    array. Reference: ssqueezepy/_stft.py:259-310."""
-    if n_fft is None:
-        pl, pr = 0, 0
-    else:
-        if win_len > n_fft:
-            raise ValueError("Can't have `win_len > n_fft` ({} > {})".format(
-                win_len, n_fft))
-        pl = (n_fft - win_len) // 2
-        pr = (n_fft - win_len - pl)
-    if window is not None:
-        if isinstance(window, str):
-            window = sig.get_window(window, win_len, fftbins=True)
-        elif isinstance(window, np.ndarray):
-            if len(window) != win_len:
-                WARN("len(window) != win_len (%s != %s)" % (len(window), win_len))
-        else:
-            raise ValueError("`window` must be string or np.ndarray "
-                             "(got %s)" % window)
-    else:
-        window = sig.windows.dpss(win_len, max(4, win_len // 8), sym=False)
-    if len(window) < (win_len + pl + pr):
-        window = np.pad(window, [pl, pr])
+def _centered(win, win_len, n_fft):
+    """`win` zero-padded by the `n_fft - win_len` samples a window of the nominal length lacks,
+    the shorter half on the left (an array of another length keeps that padding: it was
+    reported, not refused)."""
+    spare = n_fft - win_len
+    left = spare // 2
+    return np.pad(win, [left, spare - left]) if len(win) < n_fft else win
 
-    diff_window = None
-    if derivative:
-        import scipy.fft as sfft
-        nw = len(window)
-        xi = xi_grid(nw)
-        if nw % 2 == 0:
-            xi[nw // 2] = 0
-        diff_window = sfft.ifft(sfft.fft(window) * 1j * xi).real
-    if dtype is None:
-        dtype = window.dtype
-    window = _flush_denormals(np.asarray(window).astype(dtype))
-    if derivative:
-        diff_window = _flush_denormals(np.asarray(diff_window).astype(dtype))
-        return window, diff_window
-    return window
+
+def _spectral_derivative(win):
+    """d/dt of a sampled window by multiplication with 1j * xi in the DFT domain; the
+    Nyquist bin of an even length carries no derivative."""
+    import scipy.fft as sfft
+    n = len(win)
+    xi = xi_grid(n)
+    if n % 2 == 0:
+        xi[n // 2] = 0
+    return sfft.ifft(sfft.fft(win) * (1j * xi)).real
+
+
+def get_window(window, win_len, n_fft=None, derivative=False, dtype=None):
+    """The analysis window at length `n_fft` (default: `win_len`), optionally with its time
+    derivative. `window`: None -> DPSS with time-bandwidth product max(4, win_len // 8); a
+    name -> `scipy.signal.get_window(name, win_len, fftbins=True)`; an array -> taken as is
+    (a length other than `win_len` is reported, not refused). Values, padding side,
+    derivative and denormal flushing as the reference's (ssqueezepy/_stft.py:259-310);
+    pinned by tests/test_design_vs_golden.py::test_windows."""
+    if n_fft is not None and win_len > n_fft:
+        raise ValueError("Can't have `win_len > n_fft` ({} > {})".format(win_len, n_fft))
+    if window is None:
+        win = sig.windows.dpss(win_len, max(4, win_len // 8), sym=False)
+    elif isinstance(window, str):
+        win = sig.get_window(window, win_len, fftbins=True)
+    elif isinstance(window, np.ndarray):
+        win = window
+        if len(win) != win_len:
+            WARN("len(window) != win_len (%s != %s)" % (len(win), win_len))
+    else:
+        raise ValueError("`window` must be string or np.ndarray (got %s)" % window)
+    if n_fft is not None:
+        win = _centered(win, win_len, n_fft)
+    out_dtype = win.dtype if dtype is None else dtype
+    dwin = _spectral_derivative(win) if derivative else None
+    win = _flush_denormals(np.asarray(win).astype(out_dtype))
+    if not derivative:
+        return win
+    return win, _flush_denormals(np.asarray(dwin).astype(out_dtype))
 
 
 def _check_NOLA(window, hop_len, dtype=None, imprecision_strict=False):
-    if hop_len > len(window):
+    """Warn when the window / hop pair makes `istft` impossible (NOLA violated, or a hop longer
+    than the window) or -- float32 only -- inaccurate at the signal's right end (NOLA barely
+    met: tolerance 1e-3, 0.15 when `imprecision_strict`). Reference: _stft.py:313-335."""
+    n = len(window)
+    overlap = n - hop_len
+    if hop_len > n:
         WARN("`hop_len > len(window)`; STFT not invertible")
-    elif not sig.check_NOLA(window, len(window), len(window) - hop_len):
-        WARN("`window` fails Non-zero Overlap Add (NOLA) criterion; "
-             "STFT not invertible")
-    if dtype is None:
-        dtype = str(window.dtype)
-    tol = 0.15 if imprecision_strict else 1e-3
-    if dtype == 'float32' and hop_len <= len(window) and not sig.check_NOLA(
-            window, len(window), len(window) - hop_len, tol=tol):
-        WARN("Imprecision expected at right-most hop of signal, in inversion. "
-             "Lower `hop_len`, choose wider `window`, or use `dtype='float64'`.")
+    elif not sig.check_NOLA(window, n, overlap):
+        WARN("`window` fails Non-zero Overlap Add (NOLA) criterion; STFT not invertible")
+    single = (str(window.dtype) if dtype is None else dtype) == 'float32'
+    if single and hop_len <= n:
+        if not sig.check_NOLA(window, n, overlap, tol=0.15 if imprecision_strict else 1e-3):
+            WARN("Imprecision expected at right-most hop of signal, in inversion. "
+                 "Lower `hop_len`, choose wider `window`, or use `dtype='float64'`.")
 
 
 _WINDOW_CACHE = {}

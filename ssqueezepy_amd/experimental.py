@@ -64,21 +64,22 @@ def phase_ssqueeze(Wx, dWx=None, ssq_freqs=None, scales=None, Sfs=None, fs=1., t
                    was_padded=True, flipud=False, rpadded=False, padtype=None, N=None,
                    n1=None, difftype=None, difforder=None, get_w=False, get_dWx=False,
                    transform='cwt'):
-    """`phase_transform`, then `ssqueeze`, on an arbitrary CWT/STFT-like `Wx`
-    (experimental.py:146-187). Returns ``Tx, Wx, ssq_freqs, scales, Sfs, w, dWx``."""
+    """Reassign an arbitrary CWT- / STFT-like `Wx`: `phase_transform` for the instantaneous
+    frequencies (or the derivative they are formed from), then `ssqueeze`. Same argument list
+    and return tuple ``(Tx, Wx, ssq_freqs, scales, Sfs, w, dWx)`` as the reference's
+    (experimental.py:146-187); `maprange` defaults to 'peak' for a CWT and 'maximal' for an
+    STFT, and `dWx` is handed back only on request once `w` exists."""
     from .ssqueezing import ssqueeze
-    w, Wx, dWx, Sfs, gamma = phase_transform(
-        Wx, dWx, difftype, difforder=difforder, gamma=gamma, rpadded=rpadded,
-        padtype=padtype, N=N, n1=n1, get_w=get_w, fs=fs, transform=transform)
-    if w is not None and not get_dWx:
-        dWx = None
-    if maprange is None:
-        maprange = 'peak' if transform == 'cwt' else 'maximal'
-    Tx, ssq_freqs = ssqueeze(Wx, w, ssq_freqs, scales, Sfs, fs=fs, t=t,
-                             squeezing=squeezing, maprange=maprange, wavelet=wavelet,
-                             gamma=gamma, was_padded=was_padded, flipud=flipud, dWx=dWx,
-                             transform=transform)
-    return Tx, Wx, ssq_freqs, scales, Sfs, w, dWx
+    pt = phase_transform(Wx, dWx, difftype, difforder=difforder, gamma=gamma, rpadded=rpadded,
+                         padtype=padtype, N=N, n1=n1, get_w=get_w, fs=fs, transform=transform)
+    w, Wx, dWx, Sfs, gamma = pt
+    keep_dWx = get_dWx or w is None
+    Tx, ssq_freqs = ssqueeze(
+        Wx, w, ssq_freqs, scales, Sfs, fs=fs, t=t, squeezing=squeezing,
+        maprange=maprange or {'cwt': 'peak'}.get(transform, 'maximal'),
+        wavelet=wavelet, gamma=gamma, was_padded=was_padded, flipud=flipud,
+        dWx=dWx if keep_dWx else None, transform=transform)
+    return Tx, Wx, ssq_freqs, scales, Sfs, w, (dWx if keep_dWx else None)
 
 
 def phase_transform(Wx, dWx=None, difftype='trig', difforder=4, gamma=None, fs=1.,

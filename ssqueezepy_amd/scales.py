@@ -35,21 +35,22 @@ def _to_numpy(x):
 
 
 def _process_fs_and_t(fs, t, N):
-    """(dt, fs, t) from a sampling rate or a uniform time vector."""
-    if fs is not None and t is not None:
-        WARN("`t` will override `fs` (both were passed)")
-    if t is not None:
-        if len(t) != N:
-            raise Exception("`t` must be of same length as `x` "
-                            "(%s != %s)" % (len(t), N))
-        elif not np.mean(np.abs(np.diff(t, 2, axis=0))) < 1e-7:
-            raise Exception("Time vector `t` must be uniformly sampled.")
-        fs = 1 / (t[1] - t[0])
-    else:
+    """``(dt, fs, t)`` from a sampling rate or a time vector (which wins when both are given and
+    must be uniform and as long as the signal). Reference: utils/cwt_utils.py:698-716."""
+    if t is None:
         if fs is None:
-            fs = 1
-        elif fs <= 0:
+            return 1.0, 1, None
+        if fs <= 0:
             raise ValueError("`fs` must be > 0")
+        return 1 / fs, fs, None
+    if fs is not None:
+        WARN("`t` will override `fs` (both were passed)")
+    if len(t) != N:
+        raise Exception("`t` must be of same length as `x` (%s != %s)" % (len(t), N))
+    second_difference = np.abs(np.diff(t, 2, axis=0))
+    if not np.mean(second_difference) < 1e-7:
+        raise Exception("Time vector `t` must be uniformly sampled.")
+    fs = 1 / (t[1] - t[0])
     return 1 / fs, fs, t
 
 
