@@ -169,6 +169,9 @@ def main():
     dev = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
+    if world > 1:
+        # every rank designs its own plan (deterministic, no exchange): its share of the host cores
+        os.environ.setdefault('SSQ_HOST_THREADS', str(max(1, (os.cpu_count() or 1) // world)))
     import ssqueezepy_amd as S
     N, na, B = args.n, args.na, args.batch
     wav = S.Wavelet()

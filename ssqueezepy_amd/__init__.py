@@ -11,7 +11,7 @@ O(na * N) work is on the GPU and there is no CPU fallback.
 """
 __version__ = '0.1.0'
 
-from .configs import EPS32, EPS64
+from .configs import EPS32, EPS64, USE_GPU, IS_PARALLEL
 from .padding import p2up, padsignal
 from .wavelets import Wavelet, center_frequency
 from .scales import (process_scales, make_scales, cwt_scalebounds, infer_scaletype,

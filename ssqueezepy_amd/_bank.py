@@ -56,7 +56,8 @@ def _evaluate(wavelet, w_flat):
         return np.asarray(wavelet.fn(w_flat))
     import os
     from concurrent.futures import ThreadPoolExecutor
-    workers = max(1, min(32, os.cpu_count() or 1, n // (_PAR_MIN // 4)))
+    from .configs import host_threads
+    workers = max(1, min(host_threads(32), n // (_PAR_MIN // 4)))
     edges = np.linspace(0, n, 4 * workers + 1).astype(np.int64)
 
     def piece(i):

@@ -44,6 +44,7 @@ tables the kernel needs (`ssq_cwt_plan_set_blocks`, include/ssq_hip.h).
 """
 import numpy as np
 import scipy.fft as sfft
+from .configs import host_threads
 
 __all__ = ['plan_blocks']
 
@@ -127,7 +128,7 @@ def _margins(vals, off, lo, M, tol, chunk=32, denoise=False, extended=None):
                     k0 = -(-int(lo[i]) // step)
                     sub = band[k0 * step - int(lo[i])::step]
                     D[r, k0:k0 + len(sub)] = sub
-            h = np.abs(sfft.ifft(D, axis=-1, workers=-1))
+            h = np.abs(sfft.ifft(D, axis=-1, workers=host_threads(256)))
             f = h[:, :half + 1].copy()
             f[:, 1:half] += h[:, :half:-1]
             m = _tail_margin(f, tol, denoise)

@@ -4,10 +4,35 @@
 Mirrors the *values* of the reference's ``ssqueezepy/configs.ini`` (lines 1-40:
 gmw gamma=3 beta=60 bandpass order 0 float32; stft float32; downsample=4) and the
 ``gdefaults`` "fill what is None" contract (``ssqueezepy/configs.py:27-82``), but
-as a plain in-memory table: this engine has no ini file, no CPU/GPU mode switch
-(it is always the HIP path) and no thread-pool setting.
+as a plain in-memory table: this engine has no ini file and no CPU mode (it is always
+the HIP path). `USE_GPU()` / `IS_PARALLEL()` exist so that code written against the
+reference's switches (``ssqueezepy/configs.py:142-155``) imports and branches the same way.
 """
 import copy
+import os
+
+
+def USE_GPU():
+    """The reference reads ``SSQ_GPU`` here to choose between its NumPy and its CuPy / torch
+    paths (ssqueezepy/configs.py:142-147). This package has one path, the HIP one: always
+    True, whatever the variable says (the compute layer refuses to run without a GPU, see
+    `algos._require_gpu`)."""
+    return True
+
+
+def IS_PARALLEL():
+    """The reference's ``SSQ_PARALLEL`` picks its multi-threaded numba kernels
+    (configs.py:150-155); nothing here runs on host threads but the design step."""
+    return os.environ.get('SSQ_PARALLEL', '1') != '0'
+
+
+def host_threads(limit=32):
+    """Threads the host-side design step (filter bank evaluation, margin measurement) may use:
+    ``SSQ_HOST_THREADS`` if set (bench.py gives every rank of a multi-GPU job its share of the
+    cores), else the core count, capped at `limit`."""
+    n = os.environ.get('SSQ_HOST_THREADS')
+    n = int(n) if n else (os.cpu_count() or 1)
+    return max(1, min(limit, n))
 
 EPS32 = 1.1920928955078125e-07   # np.finfo(np.float32).eps
 EPS64 = 2.220446049250313e-16    # np.finfo(np.float64).eps

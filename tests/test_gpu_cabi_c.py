@@ -29,3 +29,23 @@ def test_c_program_links_and_passes(tmp_path):
     if os.environ.get('SSQ_EMULATE') == '1':
         pytest.skip("see tests/test_cabi_symbols.py::test_c_client_against_emulated_library")
     build_and_run(tmp_path, os.path.join(ROOT, 'ssqueezepy_amd'), 'libssq_hip.so')
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """`bench.py --gpus 2` end to end on a one-GPU box: two ranks (torch.distributed.run started by
+    bench.py itself, gloo, both on cuda:0 -- two RCCL ranks cannot share a device) shard the
+    signals, run their own plans and close with the one all_gather of per-signal summaries. The
+    N > 1 branch of the benchmark executes on hardware every round; RCCL itself needs N GPUs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSQ_BENCH_BACKEND='gloo', SSQ_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+                          '--warmup', '1', '--batch', '4', '--no-cpu'],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'weak'
+    assert line['per_gpu']['signals_per_step'] == 4 and line['value'] > 0
