@@ -1145,6 +1145,15 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     D[1] = load_data(items[pq[1].it], pq[1]);
     D[2] = D[0];
     int8v Rn = items[pq[2].it];
+    // the per-row reassignment weights of the position in hand (scalar loads, asked for with its records)
+    w_t csn[RPI];
+    auto load_cs = [&](int row0) {
+        if (CSTK != 0) {
+#pragma unroll
+            for (int k = 0; k < RPI; ++k) csn[k] = cstv[min(row0 + k, omax)];
+        }
+    };
+    load_cs(Rc[0] & 0x1FF);
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
     bool more = true;
@@ -1244,10 +1253,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         {
             w_t cs = (w_t)A.cst0;
             if (CSTK != 0) {
-                const int row0 = w0 & 0x1FF;
-                cs = cstv[row0];
+                cs = csn[0];
 #pragma unroll
-                for (int k = 1; k < RPI; ++k) { const w_t ck = cstv[min(row0 + k, omax)]; if (h == k) cs = ck; }
+                for (int k = 1; k < RPI; ++k) if (h == k) cs = csn[k];
             }
             const double ax = (double)TM::make(tvx, cs), ay = (double)TM::make(tvy, cs);
             SSQ_LDS_ADD_F64(lds_raw, cell16, ax);
@@ -1259,6 +1267,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         pq[k0] = advance(pq[k2]);                              // slot k0 becomes position p + 3
         Rc = items[pq[k1].it];                                 // the next position's records (see above)
         Rn = items[pq[k0].it];
+        load_cs(Rc[0] & 0x1FF);                                // ... and its rows' weights, when there is one per row
         if (tile_end) { finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg); T2_STAMP(6); }
     };
     for (;;) {

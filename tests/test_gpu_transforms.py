@@ -297,7 +297,7 @@ def test_full_size_bin_map_exact(S, orc):
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
-@pytest.mark.parametrize('N,nv,wavelet', [(20011, 8, 'gmw'), (70001, 4, 'morlet')])
+@pytest.mark.parametrize('N,nv,wavelet', [(20011, 8, 'gmw'), (70001, 8, 'morlet'), (70001, 4, 'morlet')])
 def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, monkeypatch):
     """Rows cut by the Nyquist bin: continued past it and run by the block kernels over the
     analytic signal (default; _blocks.extend_past_nyquist) -- and, with SSQ_CWT_NYQ_EXT=0, on the
@@ -315,8 +315,11 @@ def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, mo
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
         if ext == '1':
-            assert plan.extended_rows >= 3 and plan.block_rows == len(sc), (plan.algo, plan.extended_rows)
-            assert 'fourstep' not in plan.algo and 'rocfft' not in plan.algo, plan.algo
+            # every cut row continued -- except the first row of the coarse Morlet bank (nv = 4), whose
+            # peak lies far past Nyquist: the gain limit (_blocks.NYQ_EXT_GAIN) leaves it on the exact path
+            refused = 1 if (wavelet, nv) == ('morlet', 4) else 0
+            assert plan.extended_rows >= 3 and plan.block_rows == len(sc) - refused, (plan.algo, plan.extended_rows)
+            assert (('fourstep' in plan.algo) or ('rocfft' in plan.algo)) == (refused > 0), plan.algo
         else:
             assert plan.extended_rows == 0 and plan.block_rows < len(sc)
             assert ('fourstep' if dtype == 'float32' else 'rocfft') in plan.algo, plan.algo
@@ -324,8 +327,8 @@ def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, mo
         assert eW <= tol and eD <= tol, (ext, eW, eD)
         check_Tx(orc, Tx, Wx, dWx, r, dtype)
         out[ext] = (Wx, plan.extended_rows)
-    n_ext = out['1'][1]
-    assert relmax(out['1'][0][:n_ext], out['0'][0][:n_ext]) <= tol
+    n_cut = out['1'][1] + (1 if (wavelet, nv) == ('morlet', 4) else 0)
+    assert relmax(out['1'][0][:n_cut], out['0'][0][:n_cut]) <= tol
     _cwt.clear_plan_cache()
 
 
