@@ -15,6 +15,17 @@
 #define SSQ_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
 
+#ifndef SSQ_LDS_ADD_F64
+// LDS float64 add without a return value at byte offset `off` of the workgroup's LDS
+#define SSQ_LDS_ADD_F64(base, off, val) asm volatile("ds_add_f64 %0, %1" :: "v"((unsigned)(size_t)(base) + (unsigned)(off)), "v"(val) : "memory")
+// every LDS operation of this wavefront done, then the workgroup's barrier -- without the wait for
+// vector memory that __syncthreads() implies (the loads in flight belong to the next tile)
+#define SSQ_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// a table the kernel never writes, read with a wavefront-uniform index: the constant address space
+// makes the compiler fetch it through the scalar cache (s_load) instead of the vector memory path
+#define SSQ_CONST_PTR(T, p) reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p))
+#endif
+
 // Packed float32 multiply-add with one half of a register pair broadcast to both lanes of the
 // packed operation (v_pk_fma_f32 op_sel): acc.xy += w.xy * s.x  /  acc.xy += w.xy * s.y, and the
 // same for the multiply. hipcc materialises the broadcast with two v_mov per operand instead
@@ -163,6 +174,8 @@ static inline void finalize_params(SsqParams& sp) {
 }
 
 // ---- launchers implemented in ssq_kernels.hip, used by the plans --------------
+// SSQ_TILE_ORDER=ordered: reassignment sums in the CPU path's order (bit-exact kernels)
+bool reassign_ordered();
 // bin source for the accumulate kernel
 enum BinSrc { BIN_FROM_DWX = 0, BIN_FROM_W = 1, BIN_FROM_KIDX = 2 };
 

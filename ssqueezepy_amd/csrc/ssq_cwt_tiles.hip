@@ -904,17 +904,6 @@ struct Tile2Args {
     double gamma;
 };
 
-#ifndef SSQ_LDS_ADD_F64
-// LDS float64 add without a return value at byte offset `off` of the workgroup's LDS
-#define SSQ_LDS_ADD_F64(base, off, val) asm volatile("ds_add_f64 %0, %1" :: "v"((unsigned)(size_t)(base) + (unsigned)(off)), "v"(val) : "memory")
-// every LDS operation of this wavefront done, then the workgroup's barrier -- without the wait for
-// vector memory that __syncthreads() implies (the loads in flight belong to the next tile)
-#define SSQ_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// a table the kernel never writes, read with a wavefront-uniform index: the constant address space
-// makes the compiler fetch it through the scalar cache (s_load) instead of the vector memory path
-#define SSQ_CONST_PTR(T, p) reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p))
-#endif
-
 // tuning aid (-DSSQ_TILE2_PROF, A/B builds): shader-clock time one workgroup's wavefronts spend in the
 // phases of an item, summed over the launch -> counters[8 + 8 * wavefront + phase] (dumped by TilePlan::run
 // with SSQ_TILE2_PROF_DUMP=1 in the environment). Each stamp waits for the LDS / scalar queue: perturbs.
@@ -1763,10 +1752,7 @@ static int launch_tile2(const TilePlan& P, Tile2Args& A, const SsqParams& sp, hi
 
 // SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
 // 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
-bool tile_ordered() {
-    const char* e = getenv("SSQ_TILE_ORDER");       // (read at every launch: tests switch it)
-    return e && !strcmp(e, "ordered");
-}
+bool tile_ordered() { return reassign_ordered(); }
 int TilePlan::tile_cols() const { return (tile_ordered() || !tile2_ok) ? TILE_COLS : cols2; }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,

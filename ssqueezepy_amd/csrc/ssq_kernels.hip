@@ -483,6 +483,139 @@ __global__ __launch_bounds__(64, 1) void accumulate_quad_kernel(
     }
 }
 
+// --------------------------------- accumulate from a bin map, float64 tile, unordered
+// The bins are known (2-byte map written by the producer), so a point costs two LDS float64
+// adds (ds_add_f64, no return value) into a tile of `na` x COLS float64 cells held as a real and
+// an imaginary plane: no ordering between rows, hence no combining across lanes and no ticket.
+// Each cell is the float64 sum of its terms in whatever order the hardware served them, rounded
+// to the data type once at the write-out -- for float32 data that is within 1e-6 of the cell's
+// ordered float32 sum (float64 rounding, 1e-16 per add, is far below float32's), for float64
+// data within n_terms * 2^-53. SSQ_TILE_ORDER=ordered keeps the bit-exact kernels above.
+// A wavefront instruction covers 64 / COLS consecutive rows x COLS columns; loads are
+// unconditional (clamped) and refilled as consumed, NW wavefronts share a tile.
+bool reassign_ordered() {
+    const char* e = getenv("SSQ_TILE_ORDER");       // (read at every launch: tests switch it)
+    return e && !strcmp(e, "ordered");
+}
+
+template <typename T, bool CST64, int COLS, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void accumulate_f64_kernel(
+    const T* __restrict__ Wx, const unsigned short* __restrict__ kidx, T* __restrict__ Tx,
+    const void* __restrict__ cst, int cst_uniform, int na, int n) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double* plane = reinterpret_cast<double*>(lds_raw);
+    using TM = Term<T, CST64>;
+    using w_t = typename TM::wtype;
+    constexpr int RPI = 64 / COLS;                 // rows per wavefront instruction
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane % COLS, h = lane / COLS;
+    const int per = gridDim.x >> 3;                // grid.x is a multiple of 8: tiles of one XCD adjoin
+    const int tile_id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (tile_id * COLS >= n) return;
+    const int j = tile_id * COLS + c;
+    const bool col_ok = j < n;
+    const int jc = col_ok ? j : n - 1;
+    const size_t boff = (size_t)blockIdx.y * (size_t)na * (size_t)n;
+    const T* Wb = Wx + 2 * boff;
+    const unsigned short* kb = kidx + boff;
+    T* Tb = Tx + 2 * boff;
+    const int cells = na * COLS;
+    const unsigned im_off = (unsigned)cells * 8u;  // byte offset of the imaginary plane
+
+    for (int t = tid; t < 2 * cells; t += 64 * NW) plane[t] = 0.0;
+    __syncthreads();
+
+    T zc[U], zd[U];
+    w_t wt[U];
+    unsigned short kk[U];
+    const bool uni = cst_uniform != 0;
+    auto request = [&](int u, int i) {
+        const int ic = i < na ? i : na - 1;
+        const unsigned q = (unsigned)ic * (unsigned)n + (unsigned)jc;
+        if constexpr (sizeof(T) == 4) {
+            const float2 z = reinterpret_cast<const float2*>(Wb)[q];
+            zc[u] = z.x; zd[u] = z.y;
+        } else {
+            const double2 z = reinterpret_cast<const double2*>(Wb)[q];
+            zc[u] = z.x; zd[u] = z.y;
+        }
+        kk[u] = kb[q];
+        wt[u] = ((const w_t*)cst)[uni ? 0 : ic];   // (unconditional: a branch around a load costs a full drain)
+    };
+    const int step = NW * RPI;                     // rows between two groups of one wavefront
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(u, (wv + u * NW) * RPI + h);
+    for (int i0 = wv * RPI; i0 < na; i0 += U * step) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * step + h;
+            const unsigned k = kk[u];
+            const w_t wsel = wt[u];
+            // the product in the CPU path's arithmetic (float32 data x float32 weight is a float32
+            // product; a float64 weight vector makes it a float64 one), the sum in float64
+            const double tr = (double)TM::make(zc[u], wsel), ti = (double)TM::make(zd[u], wsel);
+            const bool live = col_ok && i < na && k != 0xFFFFu;
+            if (live) {
+                const unsigned off = (k * (unsigned)COLS + (unsigned)c) * 8u;
+                SSQ_LDS_ADD_F64(lds_raw, off, tr);
+                SSQ_LDS_ADD_F64(lds_raw, off + im_off, ti);
+            }
+            request(u, i + U * step);              // refill the slot
+        }
+    }
+    __syncthreads();
+    if (col_ok) {
+        for (int k = wv * RPI + h; k < na; k += step) {
+            const double re = plane[k * COLS + c], im = plane[cells + k * COLS + c];
+            const size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)j);
+            if constexpr (sizeof(T) == 4) reinterpret_cast<float2*>(Tb)[q] = make_float2((float)re, (float)im);
+            else reinterpret_cast<double2*>(Tb)[q] = make_double2(re, im);
+        }
+    }
+}
+
+// columns per tile: rows of at least 128 bytes of data per tile, two or more workgroups per CU
+// when the tile allows; 0 = the tile does not fit the LDS
+template <typename T> static int f64_tile_cols(int64_t na, size_t lds_cap) {
+    const int cmin = sizeof(T) == 4 ? 16 : 8;
+    for (int cols = 32; cols >= cmin; cols >>= 1)
+        if ((size_t)na * cols * 16 <= lds_cap / 2) return cols;
+    return (size_t)na * cmin * 16 <= lds_cap ? cmin : 0;
+}
+
+template <typename T, bool CST64, int NW>
+static int launch_accumulate_f64_w(const void* Wx, const void* kidx, void* Tx, const void* cst,
+                                   const SsqParams& sp, int64_t batch, int64_t na, int64_t n,
+                                   int cols, hipStream_t stream) {
+    constexpr int U = 4;
+    const size_t lds = (size_t)na * cols * 16;
+    dim3 grid((unsigned)(((n + cols - 1) / cols + 7) / 8 * 8), (unsigned)batch);
+#define SSQ_ACC64(C)                                                                               \
+    {                                                                                              \
+        auto kern = accumulate_f64_kernel<T, CST64, C, NW, U>;                                     \
+        SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, stream, (const T*)Wx,                   \
+                           (const unsigned short*)kidx, (T*)Tx, cst, (int)sp.cst_uniform, (int)na, \
+                           (int)n);                                                                \
+    }
+    if (cols == 32) SSQ_ACC64(32) else if (cols == 16) SSQ_ACC64(16) else SSQ_ACC64(8)
+#undef SSQ_ACC64
+    SSQ_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T, bool CST64>
+static int launch_accumulate_f64(const void* Wx, const void* kidx, void* Tx, const void* cst,
+                                 const SsqParams& sp, int64_t batch, int64_t na, int64_t n,
+                                 int cols, hipStream_t stream) {
+    // wavefronts per tile (SSQ_ACC64_NW = 4 / 8 / 16, tuning aid; default 8)
+    static const int nw = getenv("SSQ_ACC64_NW") ? atoi(getenv("SSQ_ACC64_NW")) : 8;
+    if (nw == 16) return launch_accumulate_f64_w<T, CST64, 16>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
+    if (nw == 4) return launch_accumulate_f64_w<T, CST64, 4>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
+    return launch_accumulate_f64_w<T, CST64, 8>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
+}
+
 // ---------------------------------------------- accumulate, global fallback
 // one thread per time column, serial over rows, Tx (pre-zeroed) updated in place.
 template <typename T, int BINSRC, bool STFT, bool CST64>
@@ -515,6 +648,15 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
                                int64_t na, int64_t n, int32_t* kmap, hipStream_t stream) {
     const size_t cell = 2 * sizeof(T);
     const size_t lds_cap = 160 * 1024;
+    if constexpr (BINSRC == BIN_FROM_KIDX) {
+        // known bins: the unordered float64 tile (see accumulate_f64_kernel) unless the caller
+        // asked for the ordered sums or wants the bin map back
+        int cols = f64_tile_cols<T>(na, lds_cap);
+        static const int cols_env = getenv("SSQ_ACC64_COLS") ? atoi(getenv("SSQ_ACC64_COLS")) : 0;   // (tuning aid)
+        if ((cols_env == 8 || cols_env == 16 || cols_env == 32) && (size_t)na * cols_env * 16 <= lds_cap) cols = cols_env;
+        if (!reassign_ordered() && !kmap && cols && (size_t)na * (size_t)n < ((size_t)1 << 31))
+            return launch_accumulate_f64<T, CST64>(Wx, src, Tx, cst, sp, batch, na, n, cols, stream);
+    }
     auto launch_tile = [&](auto tc_tag) -> int {
         constexpr int TC = decltype(tc_tag)::value;
         size_t lds = (size_t)na * TC * cell;

@@ -72,7 +72,9 @@ def test_block_kernels_vs_oracle(S, orc, dtype):
     check_Tx(orc, Tx, Wx, dWx, r, dtype)
     # without dWx the kernels write the bin map only (the bench configuration)
     Tx2, Wx2, *_ = S.ssq_cwt(x, wav, scales='log', nv=nv, astensor=False)
-    assert np.array_equal(Wx2, Wx) and np.array_equal(Tx2, Tx)
+    from conftest import assert_tx_repeat
+    assert np.array_equal(Wx2, Wx)
+    assert_tx_repeat(Tx2, Tx)
     _cwt.clear_plan_cache()
 
 
