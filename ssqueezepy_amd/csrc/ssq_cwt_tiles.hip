@@ -69,7 +69,8 @@ constexpr int TILE_NOBIN = 0xFFFF;
 // tuning experiments (A/B builds, tools/ab_build.sh; WRONG RESULTS): 1 = no reassignment (tickets
 // only), 4 = no arithmetic, 8 = no priorities, 32 = taps without the cross-lane gather, 64 = no
 // modulation, 128 = no bin arithmetic, 256 = no Wx store (round 4: none of 32 .. 128 changes the
-// kernel's time, 256 takes 25 us off -- profiles/r4_ab_history.txt)
+// kernel's time, 256 takes 25 us off -- profiles/r4_ab_history.txt); tile2_kernel: 8, 256, 512 = no bin
+// arithmetic, 1024 = no gather
 #ifndef SSQ_TILE_EXP
 #define SSQ_TILE_EXP 0
 #endif
@@ -954,9 +955,11 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // age only turn the order around. So the priorities rotate: the four wavefronts of a SIMD (w, w + 4,
     // w + 8, w + 12) alternate between two levels, two high and two low at any time, swapped with every
     // item (+2 %; four rotating levels measured the same and cost three more branches per item).
-    auto rotate_priority = [&](int step) {
+    int prio = (wv >> 2) & 1;
+    auto rotate_priority = [&]() {
 #if !(SSQ_TILE_EXP & 8)
-        if ((step ^ (wv >> 2)) & 1) __builtin_amdgcn_s_setprio(2);      // (two levels, swapped with every item)
+        prio ^= 1;
+        if (prio) __builtin_amdgcn_s_setprio(2);               // (two levels, swapped with every item)
         else __builtin_amdgcn_s_setprio(0);
 #endif
     };
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                     const int kc_ = k < na ? k : na;
                     const double2 v = T[kc_ * COLS + c];
                     T[kc_ * COLS + c] = make_double2(0.0, 0.0);
-                    if (ok && k < na) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
+                    if (ok && k < na && (!(SSQ_TILE_EXP & 4096) || v.x == 123.0)) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
                     asm volatile("" ::: "memory");
                 }
             }
@@ -1029,26 +1032,24 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     }
 
     // ---- the wavefront's sequence of (tile, item) positions, software-pipelined over a ring of three
-    // slots (the loop is unrolled three times, the slots are compile-time): while position p is
-    // computed, the data of p + 2 go out. Loads past the end repeat the
-    // last position (all loads unconditional, see the note in tile_kernel). A position carries its
-    // tile's element offset (signal * na * N + first column), worked out when the tile changes only.
-    // A position carries its tile as the kernel uses it: n of the tile's first column (n1 + first
-    // column), the signal, and the byte offset of (signal, row 0, first column) in Wx -- moved by
-    // constants from tile to tile (no 64-bit products per item).
-    struct Pos { int it, nabs0, sg; int64_t off8; };
+    // data slots (the loop is unrolled three times, the slots are compile-time): while position p is
+    // computed, the data of p + 2 go out. Two cursors walk the same sequence, the loads' two positions
+    // ahead of the arithmetic's; each is an item index and the tile as the kernel uses it: n of the
+    // tile's first column (n1 + first column), the signal, and the byte offset of (signal, row 0, first
+    // column) in Wx -- moved by constants when the cursor's item index wraps (no 64-bit products, and no
+    // position records copied around per item). Past the last tile the loads' cursor stays on it (all
+    // loads unconditional, see the note in tile_kernel: what they fetch there is valid and unused).
+    struct Pos { int nabs0, sg; int64_t off8; };
     const int nabs_step = G * COLS, nabs_first = A.n1 + (int)blockIdx.x * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
     const int64_t off8_step = (int64_t)G * COLS * 8;
     const int64_t off8_wrap = ((int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS) * 8;
-    auto next_pos = [&](Pos q) {
+    auto next_tile = [&](Pos q) {
         Pos r = q;
-        if (++r.it >= i1) {
-            r.it = i0; r.nabs0 += nabs_step;
-            const bool wrap = r.nabs0 > nabs_last;
-            r.off8 += wrap ? off8_wrap : off8_step;
-            if (wrap) { r.nabs0 = nabs_first; ++r.sg; }
-        }
-        return r;
+        r.nabs0 += nabs_step;
+        const bool wrap = r.nabs0 > nabs_last;
+        r.off8 += wrap ? off8_wrap : off8_step;
+        if (wrap) { r.nabs0 = nabs_first; ++r.sg; }
+        return (wrap && r.sg >= A.nsig) ? q : r;               // (the tile after the last: the last)
     };
     const int total = ntl * ni;                                // positions of this wavefront
     typedef int int8v __attribute__((ext_vector_type(8)));
@@ -1063,10 +1064,14 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     const char* const U8 = reinterpret_cast<const char*>(A.U);
     const char* const WX8 = reinterpret_cast<const char*>(A.Wx) + (size_t)((int64_t)A.sig0 * na * N) * 8u;
     const char* const KX8 = reinterpret_cast<const char*>(A.kidx);
-    auto load_data = [&](const int8v R, const Pos& q) {
+    // (ANY0: the wavefront's block holds rows read back; a wavefront of interpolated rows only -- most
+    // are -- runs a loop without the bin load and the kind tests: one vector-memory instruction less per
+    // item, and the CU's vector-memory path takes one wavefront instruction per ~20 cycles)
+    auto load_data = [&](auto any0, const int8v R, const Pos& q) {
+        constexpr bool ANY0 = decltype(any0)::value;
         Data d;
         const int w0 = R[0];
-        const int kind = (w0 >> 12) & 1;
+        const int kind = ANY0 ? (w0 >> 12) & 1 : 1;
         const char* base; unsigned voff;
         const char* kbase = reinterpret_cast<const char*>(A.items); unsigned koff = (unsigned)lane * 2u;
         if (kind) {                                            // (wave-uniform; the loads themselves stay outside)
@@ -1096,7 +1101,8 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         d.u = *reinterpret_cast<const float2*>(base + (size_t)voff);
         // (the bin: a load either way, from a harmless address for interpolated rows -- a conditional
         // load costs the compiler its count of loads in flight)
-        d.kq = (int)*reinterpret_cast<const unsigned short*>(kbase + (size_t)koff);
+        if constexpr (ANY0) d.kq = (int)*reinterpret_cast<const unsigned short*>(kbase + (size_t)koff);
+        else d.kq = 0;
         return d;
     };
     // the weights of the wavefront's (up to) two classes, for the lane's column phase: once
@@ -1118,22 +1124,26 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
 #ifdef SSQ_TILE2_PROF
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #endif
-    Pos pq[3];
+    using Yes = std::true_type; using No = std::false_type;
+    auto run = [&](auto any0) {
+    constexpr bool ANY0 = decltype(any0)::value;
     Data D[3];
-    pq[0].it = i0; pq[0].nabs0 = nabs_first; pq[0].sg = 0; pq[0].off8 = (int64_t)blockIdx.x * COLS * 8;
+    Pos tc, tl;                                                // the tile of the arithmetic's cursor, of the loads'
+    tc.nabs0 = nabs_first; tc.sg = 0; tc.off8 = (int64_t)blockIdx.x * COLS * 8;
+    tl = tc;
     if (total <= 0) return;
-    int pidx = 0;                                              // index of the position in hand
-    // (positions past the end repeat the last one: the loads issued for them are valid and unused)
-    int nidx = 0;                                              // index of the newest position in the ring
-    auto advance = [&](const Pos& q) { if (nidx + 1 < total) { ++nidx; return next_pos(q); } return q; };
-    pq[1] = advance(pq[0]); pq[2] = advance(pq[1]);
+    int it_c = i0, it_l = i0;
+    int left = total;                                          // positions not yet finished
+    auto step_loads = [&]() { if (++it_l >= i1) { it_l = i0; tl = next_tile(tl); } };
     // the records of the position in hand and of the one whose data go out next: asked for (through
     // the scalar cache) at the end of the position before, so that they are there when it starts
-    int8v Rc = items[pq[0].it];
-    D[0] = load_data(Rc, pq[0]);
-    D[1] = load_data(items[pq[1].it], pq[1]);
+    int8v Rc = items[i0];
+    D[0] = load_data(any0, Rc, tl);
+    step_loads();
+    D[1] = load_data(any0, items[it_l], tl);
+    step_loads();
     D[2] = D[0];
-    int8v Rn = items[pq[2].it];
+    int8v Rn = items[it_l];
     // the per-row reassignment weights of the position in hand (scalar loads, asked for with its records)
     w_t csn[RPI];
     auto load_cs = [&](int row0) {
@@ -1148,17 +1158,20 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     bool more = true;
     auto body = [&](auto KK) {
         constexpr int k0 = decltype(KK)::value, k1 = (k0 + 1) % 3, k2 = (k0 + 2) % 3;
-        const Pos pc = pq[k0];
+        const Pos pc = tc;
         T2_STAMP(0);                                           // (loop overhead, the previous item's tail)
-        rotate_priority(pidx);
-        D[k2] = load_data(Rn, pq[k2]);                          // the data of p + 2
+        rotate_priority();
+        if (!(SSQ_TILE_EXP & 32768)) D[k2] = load_data(any0, Rn, tl);         // the data of p + 2
+        step_loads();
         T2_STAMP(1);                                           // loads of p + 2 issued
         const Data dc = D[k0];
         const int w0 = Rc[0];
-        const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
+        const int npad = (w0 >> 9) & 7, kind = ANY0 ? (w0 >> 12) & 1 : 1;
         const int nabs = pc.nabs0 + c;                         // (lanes past the last column: results unused)
-        bool livept = h < RPI - npad;
-        if (pc.nabs0 == nabs_last) livept = livept && nabs - A.n1 < (int)N;
+        // (every lane's point counts, except in a class's last item -- padded sub-rows -- and in the last
+        // tile of a signal when N is not a multiple of the tile: a wave-uniform test keeps the rest free)
+        bool livept = true;
+        if (npad != 0 || pc.nabs0 == nabs_last) livept = h < RPI - npad && nabs - A.n1 < (int)N;
         int cell16; float tvx, tvy;
         if (kind == 0) {
             const int kk = dc.kq & 0xFFFF;
@@ -1176,6 +1189,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                 SSQ_OPAQUE_V(ur); SSQ_OPAQUE_V(ui);
                 T2_STAMP(2);                                   // the item's samples are there
 #endif
+#if SSQ_TILE_EXP & 1024
+                for (int t = 0; t < TILE_W; ++t) { fr[t] = ur + t; fi[t] = ui - t; }
+#else
                 SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
                 SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
                 SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
@@ -1185,15 +1201,20 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                 SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
                 SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                 SSQ_LDS_WAIT();
+#endif
                 T2_STAMP(3);                                   // taps gathered
-                if (pc.it < isp) {                             // (wave-uniform: the wavefront's first or second class)
+#if SSQ_TILE_EXP & 16384
+                are2.x = __int_as_float(fr[0] ^ fr[7]); are2.y = __int_as_float(fi[0] ^ fi[7]); aim2.x = __int_as_float(fr[1] ^ fr[6]); aim2.y = __int_as_float(fi[2] ^ fi[5] ^ fr[3] ^ fr[4] ^ fi[1]);
+                if (fr[2] == 77 && fr[5] == 78 && fi[3] == 7 && fi[4] == 7 && fi[6] == 1 && fi[7] == 0) are2.x = wta[0].x + wtb[3].y;
+#endif
+                if ((SSQ_TILE_EXP & 16384) == 0 && it_c < isp) {   // (wave-uniform: the wavefront's first or second class)
 #pragma unroll
                     for (int t = 0; t < TILE_W; ++t) {
                         ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
                         if (t == 0) { SSQ_PK_MUL_LO(are2, wta[0], sv); SSQ_PK_MUL_HI(aim2, wta[0], sv); }
                         else { SSQ_PK_FMA_LO(are2, wta[t], sv); SSQ_PK_FMA_HI(aim2, wta[t], sv); }
                     }
-                } else {
+                } else if ((SSQ_TILE_EXP & 16384) == 0) {
 #pragma unroll
                     for (int t = 0; t < TILE_W; ++t) {
                         ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
@@ -1227,14 +1248,16 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             const float m2 = cc * cc + dd * dd, num = bb * cc - aa * dd;
             const bool above = m2 > m2hi, below = m2 < m2lo;
             const float w32 = fabsf(num * __builtin_amdgcn_rcpf(m2 * 6.2831855f));
+#if SSQ_TILE_EXP & 512
+            int kout = (livept && w32 != 123.f) ? (kcs & 255) : -1;
+#else
             bool ok;
             const int kb = bin_screen_cwt<GRID>(w32, sp, omax, ok);
             const int kf = (kb ^ fx) + fa;
             int kout = (above && livept) ? kf : -1;
             const bool pend = livept && !(below | (above & ok));
-            if (__builtin_amdgcn_ballot_w64(pend)) {
-                if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
-            }
+            if (pend) kout = exact_bin(Wv, Dv, sp, omax, A.gamma);
+#endif
             cell16 = kout >= 0 ? kout * (COLS * 16) + c16 : scratch16;
             tvx = Wv.x; tvy = Wv.y;
             T2_STAMP(4);                                       // arithmetic, store, bin
@@ -1247,23 +1270,41 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                 for (int k = 1; k < RPI; ++k) if (h == k) cs = csn[k];
             }
             const double ax = (double)TM::make(tvx, cs), ay = (double)TM::make(tvy, cs);
+#if SSQ_TILE_EXP & 2048
+            if (ax == 123.0 && cell16 == 7) { SSQ_LDS_ADD_F64(lds_raw, cell16, ax); SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay); }
+#else
             SSQ_LDS_ADD_F64(lds_raw, cell16, ax);
             SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay);
+#endif
         }
         T2_STAMP(5);                                           // terms added
-        const bool tile_end = pq[k1].off8 != pc.off8 || pidx + 1 >= total;
-        more = ++pidx < total;
-        pq[k0] = advance(pq[k2]);                              // slot k0 becomes position p + 3
-        Rc = items[pq[k1].it];                                 // the next position's records (see above)
-        Rn = items[pq[k0].it];
+        more = --left > 0;
+        const bool tile_end = ++it_c >= i1;                    // (the block's last item: the tile is complete)
+        if (tile_end) it_c = i0;
+        Rc = items[it_c];                                      // the next position's records (see above)
+        Rn = items[it_l];
         load_cs(Rc[0] & 0x1FF);                                // ... and its rows' weights, when there is one per row
-        if (tile_end) { finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg); T2_STAMP(6); }
+        if (tile_end) {
+            if (!(SSQ_TILE_EXP & 8192) || !more) { finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg); T2_STAMP(6); }
+            tc = next_tile(tc);
+        }
     };
     for (;;) {
         body(K0{}); if (!more) break;
         body(K1{}); if (!more) break;
         body(K2{}); if (!more) break;
     }
+    };
+    // (a block spans at most two classes: its first item and the first of its second class tell)
+    const bool has0 = !((items[i0][0] >> 12) & 1) || (isp < i1 && !((items[isp][0] >> 12) & 1));
+    // (measured: a second loop without the bin load and the kind tests for the wavefronts of interpolated
+    // rows only -- one vector-memory instruction and ten scalar ones less per item -- is SLOWER, 230 vs 220 us)
+#ifdef SSQ_TILE2_TWOLOOPS
+    if (has0) run(Yes{}); else run(No{});
+#else
+    (void)has0;
+    run(Yes{});
+#endif
 #ifdef SSQ_TILE2_PROF
     if (blockIdx.x == 100 % gridDim.x && lane == 0 && A.counters)
         for (int k = 0; k < 8; ++k) A.counters[8 + 8 * wv + k] = prof[k];
