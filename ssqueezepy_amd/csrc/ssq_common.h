@@ -18,6 +18,10 @@
 #ifndef SSQ_LDS_ADD_F64
 // LDS float64 add without a return value at byte offset `off` of the workgroup's LDS
 #define SSQ_LDS_ADD_F64(base, off, val) asm volatile("ds_add_f64 %0, %1" :: "v"((unsigned)(size_t)(base) + (unsigned)(off)), "v"(val) : "memory")
+// ... at an LDS byte address worked out by the caller (SSQ_LDS_ADDR of the array, once, + its offsets), plus a
+// constant: the pointer-to-address conversion above costs a null test and two adds per use
+#define SSQ_LDS_ADDR(ptr) ((unsigned)(size_t)(ptr))
+#define SSQ_LDS_ADD_F64_AT(addr, o, val) asm volatile("ds_add_f64 %0, %1 offset:%2" :: "v"(addr), "v"(val), "n"(o) : "memory")
 // every LDS operation of this wavefront done, then the workgroup's barrier -- without the wait for
 // vector memory that __syncthreads() implies (the loads in flight belong to the next tile)
 #define SSQ_WG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -52,6 +56,35 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
     asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t_) : "v"(a), "v"(b));                  \
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                       \
         : "=v"(d) : "v"(a), "v"(b), "v"(t_)); } while (0)
+// eight taps in one block: A = sum_t w_t.x s_t, D = sum_t w_t.y s_t (s_t = a complex sample, w_t = a pair of real
+// weights), each component the same chain of multiply-adds as SSQ_PK_MUL/FMA_LO/HI build. One asm statement
+// because the compiler pads every pair of dependent packed instructions that sit in separate statements with an
+// s_nop (it cannot see that the instruction between them is one); here each accumulator's instructions alternate
+// with the other's, which is the one wait state the packed forwarding needs.
+#define SSQ_TAPS8(A, D, w, s0, s1, s2, s3, s4, s5, s6, s7)                                                    \
+    asm volatile("v_pk_mul_f32 %0, %2, %10 op_sel_hi:[0,1]\n\t"                                               \
+                 "v_pk_mul_f32 %1, %2, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  \
+                 "v_pk_fma_f32 %0, %3, %11, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %3, %11, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %4, %12, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %4, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %5, %13, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %5, %13, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %6, %14, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %6, %14, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %7, %15, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %7, %15, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %8, %16, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %8, %16, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                          \
+                 "v_pk_fma_f32 %0, %9, %17, %0 op_sel_hi:[0,1,1]\n\t"                                         \
+                 "v_pk_fma_f32 %1, %9, %17, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]"                                \
+                 : "=&v"(A), "=&v"(D)                                                                         \
+                 : "v"((w)[0]), "v"((w)[1]), "v"((w)[2]), "v"((w)[3]), "v"((w)[4]), "v"((w)[5]), "v"((w)[6]),  \
+                   "v"((w)[7]), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7))
+// flip a wave-uniform 0/1 and take the wavefront's issue priority from it (2 or 0): the compiler's form of
+// the same costs two more scalar instructions per use
+#define SSQ_PRIO_TOGGLE(p) asm volatile("s_xor_b32 %0, %0, 1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\t"  \
+                                        "s_setprio 2\n\ts_branch 2f\n1:\n\ts_setprio 0\n2:" : "+s"(p) :: "scc")
 #define SSQ_LDS_WAIT() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define SSQ_LDS_WAITN(n) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(n) : "memory")
 #endif

@@ -940,8 +940,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     double2* T = reinterpret_cast<double2*>(lds_raw);          // (na + 1) x COLS cells, the last row: scratch
     for (int k = threadIdx.x; k < (na + 1) * COLS; k += 64 * NW) T[k] = make_double2(0.0, 0.0);
     __syncthreads();
-    const int scratch16 = (na * COLS + c) * 16;
-    const int c16 = c * 16;
+    // (LDS byte addresses of the lane's column in row 0 and in the scratch row)
+    const int c16 = c * 16 + (int)SSQ_LDS_ADDR(lds_raw);
+    const int scratch16 = na * COLS * 16 + c16;
 
     const int ntx = (int)((N + COLS - 1) / COLS);
     const int G = (int)gridDim.x;
@@ -958,9 +959,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     int prio = (wv >> 2) & 1;
     auto rotate_priority = [&]() {
 #if !(SSQ_TILE_EXP & 8)
-        prio ^= 1;
-        if (prio) __builtin_amdgcn_s_setprio(2);               // (two levels, swapped with every item)
-        else __builtin_amdgcn_s_setprio(0);
+        SSQ_PRIO_TOGGLE(prio);                                 // (two levels, swapped with every item)
 #endif
     };
     const float g2 = (float)(A.gamma * A.gamma);
@@ -1133,6 +1132,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     tl = tc;
     if (total <= 0) return;
     int it_c = i0, it_l = i0;
+    bool tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;   // the arithmetic's tile is a signal's last, partial one
     int left = total;                                          // positions not yet finished
     auto step_loads = [&]() { if (++it_l >= i1) { it_l = i0; tl = next_tile(tl); } };
     // the records of the position in hand and of the one whose data go out next: asked for (through
@@ -1142,7 +1142,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     step_loads();
     D[1] = load_data(any0, items[it_l], tl);
     step_loads();
-    D[2] = D[0];
+    // (the third slot: position 0 again -- a load like the loop's, so that the compiler's count of the loads in
+    // flight at the loop's head is the loop's own; a plain copy made the first body wait for one load too many)
+    D[2] = load_data(any0, Rc, tc);
     int8v Rn = items[it_l];
     // the per-row reassignment weights of the position in hand (scalar loads, asked for with its records)
     w_t csn[RPI];
@@ -1163,6 +1165,9 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         rotate_priority();
         if (!(SSQ_TILE_EXP & 32768)) D[k2] = load_data(any0, Rn, tl);         // the data of p + 2
         step_loads();
+#ifdef SSQ_TILE2_STRICT                                        // (A/B builds: every body waits like the loop's first)
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
         T2_STAMP(1);                                           // loads of p + 2 issued
         const Data dc = D[k0];
         const int w0 = Rc[0];
@@ -1171,7 +1176,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         // (every lane's point counts, except in a class's last item -- padded sub-rows -- and in the last
         // tile of a signal when N is not a multiple of the tile: a wave-uniform test keeps the rest free)
         bool livept = true;
-        if (npad != 0 || pc.nabs0 == nabs_last) livept = h < RPI - npad && nabs - A.n1 < (int)N;
+        if ((w0 & 0xE00) != 0 || tc_last) livept = h < RPI - npad && nabs - A.n1 < (int)N;
         int cell16; float tvx, tvy;
         if (kind == 0) {
             const int kk = dc.kq & 0xFFFF;
@@ -1181,7 +1186,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             const int lgR = (w0 >> 13) & 31;
             const int qb3 = pc.nabs0 >> lgR;                   // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
             const int baddr = (((nabs >> lgR) - qb3) << 2) + hb4;
-            ssq_f2 are2, aim2;
+            ssq_f2 A2, D2;
             {
                 int fr[TILE_W], fi[TILE_W];
                 int ur = __float_as_int(dc.u.x), ui = __float_as_int(dc.u.y);
@@ -1204,37 +1209,33 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
 #endif
                 T2_STAMP(3);                                   // taps gathered
 #if SSQ_TILE_EXP & 16384
-                are2.x = __int_as_float(fr[0] ^ fr[7]); are2.y = __int_as_float(fi[0] ^ fi[7]); aim2.x = __int_as_float(fr[1] ^ fr[6]); aim2.y = __int_as_float(fi[2] ^ fi[5] ^ fr[3] ^ fr[4] ^ fi[1]);
-                if (fr[2] == 77 && fr[5] == 78 && fi[3] == 7 && fi[4] == 7 && fi[6] == 1 && fi[7] == 0) are2.x = wta[0].x + wtb[3].y;
+                A2.x = __int_as_float(fr[0] ^ fr[7]); A2.y = __int_as_float(fi[0] ^ fi[7]); D2.x = __int_as_float(fr[1] ^ fr[6]); D2.y = __int_as_float(fi[2] ^ fi[5] ^ fr[3] ^ fr[4] ^ fi[1]);
+                if (fr[2] == 77 && fr[5] == 78 && fi[3] == 7 && fi[4] == 7 && fi[6] == 1 && fi[7] == 0) A2.x = wta[0].x + wtb[3].y;
 #endif
+                // (A2 = (a_re, a_im), D2 = (a'_re, a'_im): the pairs the modulation multiplies)
+                ssq_f2 sv[TILE_W];
+#pragma unroll
+                for (int t = 0; t < TILE_W; ++t) { sv[t].x = __int_as_float(fr[t]); sv[t].y = __int_as_float(fi[t]); }
                 if ((SSQ_TILE_EXP & 16384) == 0 && it_c < isp) {   // (wave-uniform: the wavefront's first or second class)
-#pragma unroll
-                    for (int t = 0; t < TILE_W; ++t) {
-                        ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
-                        if (t == 0) { SSQ_PK_MUL_LO(are2, wta[0], sv); SSQ_PK_MUL_HI(aim2, wta[0], sv); }
-                        else { SSQ_PK_FMA_LO(are2, wta[t], sv); SSQ_PK_FMA_HI(aim2, wta[t], sv); }
-                    }
+                    SSQ_TAPS8(A2, D2, wta, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
                 } else if ((SSQ_TILE_EXP & 16384) == 0) {
-#pragma unroll
-                    for (int t = 0; t < TILE_W; ++t) {
-                        ssq_f2 sv; sv.x = __int_as_float(fr[t]); sv.y = __int_as_float(fi[t]);
-                        if (t == 0) { SSQ_PK_MUL_LO(are2, wtb[0], sv); SSQ_PK_MUL_HI(aim2, wtb[0], sv); }
-                        else { SSQ_PK_FMA_LO(are2, wtb[t], sv); SSQ_PK_FMA_HI(aim2, wtb[t], sv); }
-                    }
+                    SSQ_TAPS8(A2, D2, wtb, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
                 }
             }
-            const float are = are2.x, aim = aim2.x;
-            float dre = are2.y, dim = aim2.y;
             int kcs = Rc[4];                                    // centre bin of the lane's row
 #pragma unroll
             for (int k = 1; k < RPI; ++k) if (h == k) kcs = Rc[4 + k];
             const float theta = (float)kcs * A.theta_scale;
-            dre = __builtin_fmaf(-theta, aim, dre);
-            dim = __builtin_fmaf(theta, are, dim);
+            // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
+            D2.x = __builtin_fmaf(-theta, A2.y, D2.x);
+            D2.y = __builtin_fmaf(theta, A2.x, D2.y);
             const float rev = (float)(__umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask) * A.inv_m;
-            const float2 tw = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-            const float2 Wv = cmulf(tw, make_float2(are, aim));
-            const float2 Dv = cmulf(tw, make_float2(dre, dim));
+            ssq_f2 tw2, W2, V2;
+            tw2.x = __builtin_amdgcn_cosf(rev); tw2.y = __builtin_amdgcn_sinf(rev);
+            SSQ_CMUL_PK(W2, tw2, A2);
+            SSQ_CMUL_PK(V2, tw2, D2);
+            const float2 Wv = make_float2(W2.x, W2.y);
+            const float2 Dv = make_float2(V2.x, V2.y);
             // (lanes past the last column hold another column's weights, padded sub-rows another row's
             // samples: their values go nowhere)
             char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off8 + (unsigned)Rc[2]);
@@ -1271,10 +1272,10 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             }
             const double ax = (double)TM::make(tvx, cs), ay = (double)TM::make(tvy, cs);
 #if SSQ_TILE_EXP & 2048
-            if (ax == 123.0 && cell16 == 7) { SSQ_LDS_ADD_F64(lds_raw, cell16, ax); SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay); }
+            if (ax == 123.0 && cell16 == 7) { SSQ_LDS_ADD_F64_AT(cell16, 0, ax); SSQ_LDS_ADD_F64_AT(cell16, 8, ay); }
 #else
-            SSQ_LDS_ADD_F64(lds_raw, cell16, ax);
-            SSQ_LDS_ADD_F64(lds_raw, cell16 + 8, ay);
+            SSQ_LDS_ADD_F64_AT(cell16, 0, ax);
+            SSQ_LDS_ADD_F64_AT(cell16, 8, ay);
 #endif
         }
         T2_STAMP(5);                                           // terms added
@@ -1287,13 +1288,23 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         if (tile_end) {
             if (!(SSQ_TILE_EXP & 8192) || !more) { finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg); T2_STAMP(6); }
             tc = next_tile(tc);
+            tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;
         }
     };
+#ifdef SSQ_TILE2_PEEL
+    body(K0{});
+    if (more) for (;;) {
+        body(K1{}); if (!more) break;
+        body(K2{}); if (!more) break;
+        body(K0{}); if (!more) break;
+    }
+#else
     for (;;) {
         body(K0{}); if (!more) break;
         body(K1{}); if (!more) break;
         body(K2{}); if (!more) break;
     }
+#endif
     };
     // (a block spans at most two classes: its first item and the first of its second class tell)
     const bool has0 = !((items[i0][0] >> 12) & 1) || (isp < i1 && !((items[isp][0] >> 12) & 1));
@@ -1386,6 +1397,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
         cols2 = tile2_lds_bytes(na, 32) <= 160 * 1024 ? 32 : 16;
+        if (const char* e = getenv("SSQ_TILE2_COLS")) if (atoi(e) == 16) cols2 = 16;     // (tuning aid)
         SSQ_REQUIRE(tile2_lds_bytes(na, cols2) <= 160 * 1024, "na = %lld: the Tx tile exceeds the LDS", (long long)na);
         const int rpi = 64 / cols2;
         SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
@@ -1782,6 +1794,8 @@ template <int GRID, bool STORE_D>
 static int launch_tile2(const TilePlan& P, Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
     static const int nw = [] { const char* e = getenv("SSQ_TILE_NW"); int v = e ? atoi(e) : 16; return v == 12 ? 12 : 16; }();
     // wave_first2 holds the blocks for 12 and for 16 wavefronts one after the other
+    // (measured, round 4: 16-column tiles with 16 wavefronts 245 us, with 8 wavefronts and two workgroups per CU
+    // 260-275 us, against 220 us for the 32-column tile -- profiles/r4_ab_history.txt)
     A.waves = reinterpret_cast<const int4*>(P.wave_first2) + (nw == 12 ? 0 : 12);
     if (P.cols2 == 32) {
         if (nw == 12) return launch_tile2_k<GRID, STORE_D, 12, 32>(P, A, sp, stream);

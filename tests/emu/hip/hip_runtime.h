@@ -34,6 +34,13 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 #define SSQ_PK_MUL_HI(d, w, s) do { (d).x = (w).x * (s).y; (d).y = (w).y * (s).y; } while (0)
 #define SSQ_PK_FMA_LO(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).x, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).x, (acc).y); } while (0)
 #define SSQ_PK_FMA_HI(acc, w, s) do { (acc).x = __builtin_fmaf((w).x, (s).y, (acc).x); (acc).y = __builtin_fmaf((w).y, (s).y, (acc).y); } while (0)
+#define SSQ_TAPS8(A, D, w, s0, s1, s2, s3, s4, s5, s6, s7) do {                                               \
+    const ssq_f2 s_[8] = {s0, s1, s2, s3, s4, s5, s6, s7};                                                     \
+    (A).x = (w)[0].x * s_[0].x; (A).y = (w)[0].x * s_[0].y; (D).x = (w)[0].y * s_[0].x; (D).y = (w)[0].y * s_[0].y; \
+    for (int t_ = 1; t_ < 8; ++t_) {                                                                          \
+        (A).x = __builtin_fmaf((w)[t_].x, s_[t_].x, (A).x); (A).y = __builtin_fmaf((w)[t_].x, s_[t_].y, (A).y); \
+        (D).x = __builtin_fmaf((w)[t_].y, s_[t_].x, (D).x); (D).y = __builtin_fmaf((w)[t_].y, s_[t_].y, (D).y); \
+    } } while (0)
 #define SSQ_BPERMUTE_OFF(d, addr, v, off) ((d) = emu_ds_bpermute((addr) + (off), (v)))
 #define SSQ_CMUL_PK(d, a, b) do { const float tx_ = (a).x * (b).x, ty_ = (a).x * (b).y;                      \
     (d).x = __builtin_fmaf(-(a).y, (b).y, tx_); (d).y = __builtin_fmaf((a).y, (b).x, ty_); } while (0)
@@ -41,6 +48,10 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
 #define SSQ_LDS_WAIT() ((void)0)
 // LDS float64 add (ds_add_f64) and the LDS-only workgroup barrier of tile2_kernel
 #define SSQ_LDS_ADD_F64(base, off, val) (*reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(base) + (off)) += (val))
+namespace ssq { extern thread_local unsigned char lds_raw[]; }
+#define SSQ_LDS_ADDR(ptr) ((unsigned)(reinterpret_cast<unsigned char*>(ptr) - ssq::lds_raw))
+#define SSQ_LDS_ADD_F64_AT(addr, o, val) (*reinterpret_cast<double*>(ssq::lds_raw + (addr) + (o)) += (val))
+#define SSQ_PRIO_TOGGLE(p) ((p) ^= 1)
 #define SSQ_WG_BARRIER() __syncthreads()
 #define SSQ_CONST_PTR(T, p) reinterpret_cast<const T*>(p)
 #define SSQ_LDS_WAITN(n) ((void)0)

@@ -3,7 +3,7 @@
 cd /root/repo; O=gpurun_out/r4v; mkdir -p $O
 run() { local label=$1; shift
   echo -n "$label "; timeout 200 python bench.py --no-cpu --steps 8 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), {k: round(v,1) for k,v in d['stages_us_per_transform'].items()})"; }
-timeout 900 python -m pytest tests/test_gpu_edge_cases.py tests/test_gpu_00_configs.py -x -q -m gpu -k "tile or config2_ssq" 2>&1 | tail -2 | cut -c1-200
+
 for v in "$@"; do
   if [ "$v" != default ]; then export SSQ_HIP_LIB=/root/repo/ssqueezepy_amd/libssq_hip_$v.so; else unset SSQ_HIP_LIB; fi
   run "lib=$v"
