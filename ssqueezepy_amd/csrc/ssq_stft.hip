@@ -57,11 +57,20 @@ struct StftFusedArgs {
     int64_t padlen, n_hops, rows;
     int hop, s20, s21, modulated;
     int xcd;                            // grid.x padded to a multiple of 8, remapped per XCD
+    // REASSIGN instantiation: Tx of the workgroup's frames is summed in LDS (float64, unordered adds -- see
+    // accumulate_f64_kernel) and written here; neither the bin map nor a second pass over Sx is needed
+    float2* Tx; const void* cst; int cst_uniform;
 };
 
-template <int L, int G, int R1, int R2, int R3>
+template <int L, int G, int R1, int R2, int R3, bool REASSIGN, bool CST64>
 __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
+    // the frames' Tx: a real and an imaginary plane of (L/2 + 1) x G float64 cells
+    constexpr int CELLS = REASSIGN ? (L / 2 + 1) * G : 1;
+    __shared__ double txt[2 * CELLS];
+    if constexpr (REASSIGN) {
+        for (int i = threadIdx.x; i < 2 * CELLS; i += NT) txt[i] = 0.0;     // (barriers follow before its first use)
+    }
     constexpr int RL = (R3 > 1) ? R3 : R2;
     // workgroups are dealt to the 8 XCDs round-robin: give each XCD one contiguous range of
     // frames, so that the G*8-byte pieces of an output line meet in one L2 before they leave
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
     const int tid = threadIdx.x, c0 = bx * G;
     if (c0 >= A.n_hops) return;
     const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
-    const bool deriv = A.dSx != nullptr || A.kidx != nullptr;
+    const bool deriv = A.dSx != nullptr || A.kidx != nullptr || REASSIGN;
     c32 z[PPT];
     {
         constexpr int NB = PPT / R1, STR = L / R1;
@@ -116,27 +125,54 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
         if (!deriv) continue;
         const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
         if (A.dSx) A.dSx[q] = make_float2(dr, di);
-        if (A.kidx) {            // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
+        if (A.kidx || REASSIGN) {   // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
             const int64_t omax = A.rows - 1;
             unsigned short kk = 0xFFFFu;
             if (mag_gt(sr, si, A.gamma)) {
                 const int64_t kb = bin_of_point(dr, di, sr, si, true, A.Sfs[f], sp, omax);
                 kk = (unsigned short)(sp.flipud ? omax - kb : kb);
             }
-            A.kidx[q] = kk;
+            if constexpr (REASSIGN) {
+                if (kk != 0xFFFFu) {
+                    // the term in the CPU path's arithmetic (float32 product; float64 with a float64 weight
+                    // vector), the sum in float64
+                    using w_t = typename std::conditional<CST64, double, float>::type;
+                    const w_t wv = ((const w_t*)A.cst)[A.cst_uniform ? 0 : f];
+                    const double tr = (double)((w_t)sr * wv), ti = (double)((w_t)si * wv);
+                    const unsigned off = ((unsigned)kk * G + (unsigned)g) * 8u;
+                    SSQ_LDS_ADD_F64(txt, off, tr);
+                    SSQ_LDS_ADD_F64(txt, off + (unsigned)CELLS * 8u, ti);
+                }
+            } else {
+                A.kidx[q] = kk;
+            }
+        }
+    }
+    if constexpr (REASSIGN) {
+        __syncthreads();
+        for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
+            const int f = i / G, g = i % G, c = c0 + g;
+            if (c >= A.n_hops) continue;
+            A.Tx[base + (int64_t)f * A.n_hops + c] = make_float2((float)txt[i], (float)txt[CELLS + i]);
         }
     }
 }
 
 template <int L, int G, int R1, int R2, int R3>
 static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_t batch, hipStream_t stream) {
+    SSQ_REQUIRE(!A.Tx || A.rows == L / 2 + 1, "fused reassignment: %lld rows, transform of %d", (long long)A.rows, L);
     static const bool remap = [] { const char* e = getenv("SSQ_STFT_XCD"); return !e || atoi(e) != 0; }();
     StftFusedArgs B = A;
     unsigned nb = (unsigned)((A.n_hops + G - 1) / G);
     B.xcd = remap && nb >= 64;
     if (B.xcd) nb = (nb + 7u) & ~7u;
     dim3 grid(nb, (unsigned)batch);
-    hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3>), grid, dim3(NT), 0, stream, B, sp);
+    if (!A.Tx)
+        hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3, false, false>), grid, dim3(NT), 0, stream, B, sp);
+    else if (sp.cst_f64)
+        hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3, true, true>), grid, dim3(NT), 0, stream, B, sp);
+    else
+        hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3, true, false>), grid, dim3(NT), 0, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
@@ -312,12 +348,19 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     T* dS = dSx ? (T*)dSx : (T*)pl->dSx_ws;
     // fused ssq_stft form: Tx wanted, neither dSx nor w -> the kernel emits 2-byte bins
     // instead of the 8-byte derivative (the reassignment then reads 10 instead of 16 B/pt)
-    bool use_kidx = false;
+    // ... and, unless the ordered sums are asked for (SSQ_TILE_ORDER=ordered), sums Tx itself
+    bool use_kidx = false, fused_tx = false;
     if constexpr (sizeof(T) == 4) {
         if (pl->fused && Tx && !w && !dSx && rows < 65535) {
-            if (!pl->kidx)
-                SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
             use_kidx = true;
+            // (measured, C3: one signal 68 us against 72 with the separate pass; 512 signals 2.75 ms against
+            // 2.35 -- a workgroup's Tx goes out as G * 8-byte pieces and the tile halves the occupancy, so
+            // the fused sums serve the calls that do not fill the GPU; SSQ_STFT_FUSED_TX=0/1 forces)
+            static const int force = getenv("SSQ_STFT_FUSED_TX") ? atoi(getenv("SSQ_STFT_FUSED_TX")) : -1;
+            fused_tx = !reassign_ordered() && rows == n_fft / 2 + 1 &&
+                       (force >= 0 ? force != 0 : batch * n_hops <= 4096);
+            if (!fused_tx && !pl->kidx)
+                SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
         }
     }
     if constexpr (sizeof(T) == 4) {
@@ -326,7 +369,8 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.xp = (const float*)pl->xp; A.window = (const float*)pl->window;
             A.diff_window = (const float*)pl->diff_window; A.ftw = (const c32*)pl->ftw;
             A.Sx = (float2*)Sx; A.dSx = (deriv && !use_kidx) ? (float2*)dS : nullptr;
-            A.kidx = use_kidx ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
+            A.kidx = (use_kidx && !fused_tx) ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
+            A.Tx = fused_tx ? (float2*)Tx : nullptr; A.cst = pl->cst; A.cst_uniform = pl->sp.cst_uniform;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated;
             switch (n_fft) {
@@ -360,7 +404,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
         rc = ssq_phase_stft(d.dtype, Sx, dS, pl->Sfs, w, batch, rows, n_hops, pl->sp.gamma, stream);
         if (rc) return rc;
     }
-    if (Tx) {
+    if (Tx && !fused_tx) {
         if (w)
             rc = launch_accumulate(d.dtype, BIN_FROM_W, Sx, w, nullptr, Tx, pl->cst, pl->sp, batch,
                                    rows, n_hops, nullptr, stream);

@@ -118,6 +118,31 @@ def test_stft_paths_vs_reference(S, orc):
     test_ssq_stft_vs_reference(S, orc, 'float32')
 
 
+def test_fused_stft_reassignment_emulated(S, monkeypatch):
+    """ssq_stft without dSx: the fused STFT kernel sums Tx of its frames in LDS (float64, unordered) --
+    against the ordered two-kernel path on the same input (which the GPU suite checks against the
+    oracle), every FFT configuration that is cheap under the emulator, odd hops, flipud, batched;
+    SSQ_TILE_ORDER=ordered gives the ordered sums bit for bit."""
+    from conftest import two_chirps, assert_tx_vs_oracle
+    from ssqueezepy_amd import _stft
+    for n_fft, hop, N, fl in ((128, 32, 1500, False), (1024, 256, 6000, False), (256, 37, 3000, True)):
+        x = two_chirps(N, seed=n_fft)
+        _stft._PLAN_CACHE.clear()
+        Tx, Sx, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', get_dWx=True, flipud=fl,
+                                astensor=False)
+        T2, S2, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', flipud=fl, astensor=False)
+        assert np.array_equal(S2, Sx)
+        assert_tx_vs_oracle(T2, Tx, what=n_fft)
+        Tb, _, *_ = S.ssq_stft(np.stack([x, x[::-1].copy()]), n_fft=n_fft, hop_len=hop, dtype='float32',
+                               flipud=fl, astensor=False)
+        assert_tx_vs_oracle(Tb[0], Tx, what=n_fft)
+        monkeypatch.setenv('SSQ_TILE_ORDER', 'ordered')
+        T3, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', flipud=fl, astensor=False)
+        monkeypatch.delenv('SSQ_TILE_ORDER')
+        assert np.array_equal(T3, Tx)
+    _stft._PLAN_CACHE.clear()
+
+
 def test_inverses_vs_reference(S, orc):
     """icwt / issq_cwt / istft / issq_stft / trigdiff (tests/test_gpu_inverse.py) under the
     emulator."""
