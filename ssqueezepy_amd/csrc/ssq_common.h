@@ -14,6 +14,10 @@
 #ifndef SSQ_OPAQUE_V
 #define SSQ_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
+// ... and as a wave-uniform value the compiler may not fold or hoist (it stays in a scalar register)
+#ifndef SSQ_OPAQUE_S
+#define SSQ_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#endif
 
 #ifndef SSQ_LDS_ADD_F64
 // LDS float64 add without a return value at byte offset `off` of the workgroup's LDS

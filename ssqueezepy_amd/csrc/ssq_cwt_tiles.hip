@@ -943,6 +943,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // (LDS byte addresses of the lane's column in row 0 and in the scratch row)
     const int c16 = c * 16 + (int)SSQ_LDS_ADDR(lds_raw);
     const int scratch16 = na * COLS * 16 + c16;
+    const int full_rounds = na / (NW * RPI);                   // write-out rounds (NW * RPI rows each) that are complete
 
     const int ntx = (int)((N + COLS - 1) / COLS);
     const int G = (int)gridDim.x;
@@ -1000,18 +1001,48 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
                 }
             }
         } else {
-            const unsigned col = (unsigned)(tx * COLS + c);
-            const bool ok = col < nN;
-            constexpr int ROUNDS = (NA_CAP + NW * RPI - 1) / (NW * RPI);
+            constexpr int ROUNDS = (NA_CAP + NW * RPI - 1) / (NW * RPI), RR = NW * RPI;    // RR rows per round
+            const int k0 = wv * RPI + h;                       // the lane's row in round 0
+            if ((tx + 1) * COLS <= (int)nN) {
+                // every column of the tile exists (all but a signal's last tile when COLS does not divide N):
+                // the rounds below the last need no masks -- scalar base per round + a per-lane constant
+                char* tb = reinterpret_cast<char*>(Tx) + (size_t)tx * (COLS * 8);
+                const unsigned voff = ((unsigned)k0 * nN + (unsigned)c) * 8u;
+                // (the round count and the rounds' distance are re-read as scalars at every use: hoisted out
+                // of the item loop, the compiler keeps ten lane masks and ten 64-bit offsets in spilled registers)
+                int fr = full_rounds;
+                size_t step = (size_t)RR * (size_t)N * 8;
 #pragma unroll
-            for (int m = 0; m < ROUNDS; ++m) {
-                if (m * NW * RPI < na) {
-                    const int k = (wv + m * NW) * RPI + h;
+                for (int m = 0; m < ROUNDS - 1; ++m) {
+                    SSQ_OPAQUE_S(fr); SSQ_OPAQUE_S(step);
+                    if (m < fr) {                              // (wave-uniform)
+                        const int k = k0 + m * RR;
+                        const double2 v = T[k * COLS + c];
+                        T[k * COLS + c] = make_double2(0.0, 0.0);
+                        if (!(SSQ_TILE_EXP & 4096) || v.x == 123.0)
+                            *reinterpret_cast<float2*>(tb + (size_t)voff) = make_float2((float)v.x, (float)v.y);
+                        tb += step;
+                        asm volatile("" ::: "memory");         // (keeps the rounds from being batched into registers)
+                    }
+                }
+                {   // the last round: the rows left, and the scratch row cleared by the lanes past them
+                    const int k = k0 + fr * RR;
                     const int kc_ = k < na ? k : na;
                     const double2 v = T[kc_ * COLS + c];
                     T[kc_ * COLS + c] = make_double2(0.0, 0.0);
-                    if (ok && k < na && (!(SSQ_TILE_EXP & 4096) || v.x == 123.0)) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
-                    asm volatile("" ::: "memory");
+                    if (k < na && (!(SSQ_TILE_EXP & 4096) || v.x == 123.0))
+                        *reinterpret_cast<float2*>(tb + (size_t)voff) = make_float2((float)v.x, (float)v.y);
+                }
+            } else {
+                const unsigned col = (unsigned)(tx * COLS + c);
+                const bool ok = col < nN;
+#pragma unroll 1
+                for (int m = 0; m * RR < na + 1; ++m) {
+                    const int k = k0 + m * RR;
+                    const int kc_ = k < na ? k : na;
+                    const double2 v = T[kc_ * COLS + c];
+                    T[kc_ * COLS + c] = make_double2(0.0, 0.0);
+                    if (ok && k < na) Tx[(unsigned)k * nN + col] = make_float2((float)v.x, (float)v.y);
                 }
             }
         }

@@ -19,3 +19,7 @@ python tools/pmc_traffic.py $O/pmc $(( (3+3+3) * 16 )) $O/pmc_traffic.json > $O/
 rm -rf $O/pmc/*/
 timeout 200 python bench.py --no-cpu --steps 4 --warmup 3 --batch 64 > $O/bench_b64.json 2> $O/bench_b64.err; python -c "import json; d=json.load(open('$O/bench_b64.json')); print('B=64', round(d['value']), d['ms_per_step'])"
 timeout 400 python tools/run_configs.py c1 c3 c5 > $O/configs.jsonl 2> $O/configs.err; cut -c1-220 $O/configs.jsonl
+# what a small transform's time is made of (C1: N = 10 000): kernel time against the wall time run_configs reports
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof1 -o c1 -- python tools/run_configs.py c1 > $O/prof1.log 2>&1
+DB=$(find $O/prof1 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/prof_summary.py $DB $O/kernel_stats_c1.txt | head -12 | cut -c1-160
+rm -rf $O/prof1
