@@ -143,12 +143,17 @@ struct BlockArgs {
     int sig;                           // first signal of the launch (blockIdx.y adds to it)
 };
 
+// The body of one workgroup (item `item_idx` of the class's list; blockIdx.y = signal of the launch). Its LDS
+// arrays come from the caller: blockzoom_kernel sizes them for its class, blockzoom_multi_kernel -- every class
+// in ONE launch, for transforms too small to fill the GPU per class -- shares one set between the classes.
 template <int L, int G, int R1, int R2, int R3, bool LEAN>
-__global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp) {
-    __shared__ c32 buf[D_POINTS];
+__device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqParams& sp, int item_idx,
+                                               c32* __restrict__ buf, c32* __restrict__ spow,
+                                               c32* __restrict__ wrapf, c32* __restrict__ bandW,
+                                               c32* __restrict__ bandD) {
     constexpr int RL = (R3 > 1) ? R3 : R2;         // last radix
     const int tid = threadIdx.x;
-    const int4 item = A.items[blockIdx.x];
+    const int4 item = A.items[item_idx];
     const int row = item.x, blk = item.y, c0 = item.z;
     const BlockRowDev r = A.rows[row];
     const BlockClassDev cl = A.classes[item.w];
@@ -167,13 +172,11 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
     // e^{-2 pi i L c / P}), and those powers -- R1 x G values per workgroup -- are staged
     // in LDS once. 8x fewer scattered table gathers than one per point (the gathers,
     // not the arithmetic, bounded this stage).
-    __shared__ c32 spow[R1 * G];
-    __shared__ c32 wrapf[G];
+    // (spow: R1 * G entries, wrapf: G)
     // The band itself (psi X / P and its derivative multiple) is the same for all G
     // columns of the workgroup: for the small transforms it is formed once per
-    // workgroup in LDS instead of once per point from global memory.
+    // workgroup in LDS instead of once per point from global memory (bandW, bandD: L entries).
     constexpr bool STAGE = (L <= 512);
-    __shared__ c32 bandW[STAGE ? L : 1], bandD[STAGE ? L : 1];
     const float invP = 1.0f / (float)P;             // exact (P is a power of two)
     {
         constexpr int STR = L / R1;
@@ -279,6 +282,43 @@ __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp
                 }
         }
         if (low) emit_point_exact(er, er.k + j, W, D, sp);
+    }
+}
+
+template <int L, int G, int R1, int R2, int R3, bool LEAN>
+__global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp) {
+    __shared__ c32 buf[D_POINTS];
+    __shared__ c32 spow[R1 * G];
+    __shared__ c32 wrapf[G];
+    __shared__ c32 bandW[(L <= 512) ? L : 1], bandD[(L <= 512) ? L : 1];
+    blockzoom_body<L, G, R1, R2, R3, LEAN>(A, sp, (int)blockIdx.x, buf, spow, wrapf, bandW, bandD);
+}
+
+// every class of a plan in one launch: workgroup b belongs to the class whose item range holds b
+struct BlockMultiArgs {
+    BlockArgs A;                       // (items, n_items, ftw: filled per class inside)
+    const int4* items[5]; const c32* ftw[5];
+    int first[6];                      // first workgroup of class s; first[5] = grid size
+};
+template <bool LEAN>
+__global__ __launch_bounds__(NT) void blockzoom_multi_kernel(BlockMultiArgs M, SsqParams sp) {
+    __shared__ c32 buf[D_POINTS];
+    __shared__ c32 spow[512];          // max R1 * G (16 x 32)
+    __shared__ c32 wrapf[32];
+    __shared__ c32 bandW[512], bandD[512];
+    const int b = (int)blockIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) s += b >= M.first[k];
+    BlockArgs A = M.A;
+    A.items = M.items[s]; A.ftw = M.ftw[s];
+    const int it = b - M.first[s];
+    switch (s) {
+        case 0: blockzoom_body<128, 32, 16, 8, 1, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 1: blockzoom_body<256, 16, 16, 16, 1, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 2: blockzoom_body<512, 8, 8, 8, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 3: blockzoom_body<1024, 4, 16, 8, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        default: blockzoom_body<2048, 2, 16, 16, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
     }
 }
 
@@ -805,6 +845,39 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
     A.inv_dt = 1.0f / (float)dt;
     A.gamma = sp.gamma; A.sig = sig;
     int rc = 0;
+    {   // A transform too small to fill the GPU class by class (C1: five launches of 10-18 us each): one launch.
+        // (SSQ_CWT_BLOCKS_MULTI=0/1 forces; default: when no class has more than two workgroups per CU)
+        const char* fe = getenv("SSQ_CWT_BLOCKS_MULTI");                 // (read per call: tests switch it)
+        const int force = fe ? atoi(fe) : -1;
+        int64_t total = 0, biggest = 0; int used = 0;
+        for (int s = 0; s < 5; ++s) {
+            const int64_t n = limit ? limit[s] : n_items[s];
+            total += n; biggest = std::max(biggest, n * nsig); used += n > 0;
+        }
+        static const int ncu = [] {    // (one device per process)
+            int dev = 0; hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
+            return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+        }();
+        const bool multi = force >= 0 ? force != 0 : (used > 1 && biggest <= 2 * (int64_t)ncu);
+        if (multi && total > 0) {
+            BlockMultiArgs Mx;
+            Mx.A = A; Mx.A.items = nullptr; Mx.A.n_items = total; Mx.A.ftw = nullptr;
+            int acc = 0;
+            for (int s = 0; s < 5; ++s) {
+                Mx.items[s] = (const int4*)items[s]; Mx.ftw[s] = (const c32*)ftw + ftw_off[s];
+                Mx.first[s] = acc; acc += (int)(limit ? limit[s] : n_items[s]);
+            }
+            Mx.first[5] = acc;
+            const dim3 grid((unsigned)total, (unsigned)nsig);
+            if (A.kidx && !A.dWx && !A.w && !A.row_scale)
+                hipLaunchKernelGGL((blockzoom_multi_kernel<true>), grid, dim3(NT), 0, stream, Mx, sp);
+            else
+                hipLaunchKernelGGL((blockzoom_multi_kernel<false>), grid, dim3(NT), 0, stream, Mx, sp);
+            SSQ_LAUNCH_CHECK();
+            return 0;
+        }
+    }
 #define ZOOM(slot, L, G, R1, R2, R3)                                                              \
     A.items = (const int4*)items[slot]; A.n_items = limit ? limit[slot] : n_items[slot];                                 \
     A.ftw = (const c32*)ftw + ftw_off[slot];                                                       \

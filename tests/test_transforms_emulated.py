@@ -118,6 +118,28 @@ def test_stft_paths_vs_reference(S, orc):
     test_ssq_stft_vs_reference(S, orc, 'float32')
 
 
+def test_block_classes_in_one_launch_emulated(S, monkeypatch):
+    """Small transforms run every block class in ONE launch (blockzoom_multi_kernel: the class's body
+    picked per workgroup); the same bodies as the per-class kernels, so the results are identical --
+    `cwt` with derivative and the fused `ssq_cwt` (lean bodies), float32."""
+    from conftest import two_chirps
+    from ssqueezepy_amd import _cwt
+    x = two_chirps(3000, seed=5)
+    wav = S.Wavelet()
+    out = {}
+    for multi in ('0', '1'):
+        monkeypatch.setenv('SSQ_CWT_BLOCKS_MULTI', multi)
+        _cwt.clear_plan_cache()
+        Wx, sc, dWx = S.cwt(x, wav, scales='log', nv=16, derivative=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan.algo.startswith('blockzoom') and plan.block_rows > 0.5 * len(sc)
+        Tx, W2, *_ = S.ssq_cwt(x, wav, scales='log', nv=16, astensor=False)
+        out[multi] = (Wx, dWx, Tx, W2)
+    for a, b in zip(out['0'], out['1']):
+        assert np.array_equal(a, b)
+    _cwt.clear_plan_cache()
+
+
 def test_fused_stft_reassignment_emulated(S, monkeypatch):
     """ssq_stft without dSx: the fused STFT kernel sums Tx of its frames in LDS (float64, unordered) --
     against the ordered two-kernel path on the same input (which the GPU suite checks against the
