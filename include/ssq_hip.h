@@ -45,7 +45,7 @@ extern "C" {
 #define SSQ_PAD_WRAP 4
 
 /* ------------------------------------------------------------------ runtime */
-int         ssq_version(void);          /* 102 (101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
+int         ssq_version(void);          /* 103 (102: without ssq_ridge_*_batch; 101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
 const char* ssq_last_error(void);
 int         ssq_device_count(int* count);
 int         ssq_set_device(int device);
@@ -193,6 +193,18 @@ int ssq_ridge_track(int dtype, int penalty_f32, const void* E, void* pe, const v
  * energy[int(ridge[j] - bw) : int(ridge[j] + bw), j] = 0 with Python's slice rules (:142-150). */
 int ssq_ridge_clear(int dtype, void* energy, const int64_t* ridge, double bw, void* ridge_e,
                     int64_t na, int64_t n, void* stream);
+
+/* The three steps above over `batch` transforms at once (ABI 103): contiguous (batch, na, n) arrays, `ridge`
+ * and `ridge_e` (batch, n); one workgroup per transform in the tracking passes -- a pass is one workgroup's
+ * walk over time, so a batch costs about what one transform does until the CUs run out. No counterpart in the
+ * reference (its extract_ridges takes one transform); results per transform are those of the calls above. */
+int ssq_ridge_neglog_batch(int dtype, const void* energy, void* E, double eps, int64_t na, int64_t n,
+                           int64_t batch, void* stream);
+int ssq_ridge_track_batch(int dtype, int penalty_f32, const void* E, void* pe, const void* sc,
+                          double penalty, double eps, int64_t na, int64_t n, int64_t* ridge,
+                          int64_t batch, void* stream);
+int ssq_ridge_clear_batch(int dtype, void* energy, const int64_t* ridge, double bw, void* ridge_e,
+                          int64_t na, int64_t n, int64_t batch, void* stream);
 
 /* ----------------------------------------------------------------- CWT plan
  * Replaces the body of cwt() (_cwt.py:255-306: pad -> fft -> Psih*xh -> ifft

@@ -101,6 +101,12 @@ _PROTOS = {
                                 c_int64, c_int64, c_void_p, c_void_p]),
     'ssq_ridge_clear': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int64,
                                 c_void_p]),
+    'ssq_ridge_neglog_batch': (c_int, [c_int, c_void_p, c_void_p, c_double, c_int64, c_int64, c_int64,
+                                       c_void_p]),
+    'ssq_ridge_track_batch': (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_double,
+                                      c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    'ssq_ridge_clear_batch': (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int64,
+                                      c_int64, c_void_p]),
     'ssq_cwt_plan_create': (c_int, [POINTER(c_void_p), POINTER(CwtDesc)]),
     'ssq_cwt_plan_destroy': (None, [c_void_p]),
     'ssq_cwt_plan_set_ssq': (c_int, [c_void_p, c_int, POINTER(c_double), c_void_p,
@@ -129,7 +135,7 @@ EXPORTS = tuple(_PROTOS)
 _lib = None
 
 
-ABI_VERSION = 102     # include/ssq_hip.h: ssq_version()
+ABI_VERSION = 103     # include/ssq_hip.h: ssq_version()
 
 
 def load(build_if_missing=True):

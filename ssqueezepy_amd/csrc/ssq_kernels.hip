@@ -870,7 +870,7 @@ using namespace ssq;
 // ======================================================================= C ABI
 extern "C" {
 
-int ssq_version(void) { return 102; }   // 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
+int ssq_version(void) { return 103; }   // 103: ssq_ridge_*_batch; 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
 const char* ssq_last_error(void) { return g_last_error.c_str(); }
 
 int ssq_device_count(int* count) {

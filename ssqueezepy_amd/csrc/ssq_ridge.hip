@@ -88,6 +88,7 @@ __global__ __launch_bounds__(64) void ridge_neglog_kernel(const T* __restrict__ 
                                                           T eps, int64_t na, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= n) return;
+    en += (int64_t)blockIdx.y * na * n; E += (int64_t)blockIdx.y * na * n;      // (blockIdx.y: transform of the batch)
     T mx = en[j];
     for (int64_t i = 1; i < na; ++i) { const T v = en[i * n + j]; mx = v > mx ? v : mx; }
     for (int64_t i = 0; i < na; ++i) E[i * n + j] = neg_log(en[i * n + j] / mx + eps);
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(64) void ridge_argmin_kernel(const T* __restrict__ 
                                                           int64_t na, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= n) return;
+    pe += (int64_t)blockIdx.y * na * n; ridge += (int64_t)blockIdx.y * n;
     T best = pe[j]; int64_t bi = 0;
     for (int64_t i = 1; i < na; ++i) { const T v = pe[i * n + j]; if (v < best) { best = v; bi = i; } }
     // np.unravel_index(argmin, (na, n))[1]: the column coordinate of the flat index
@@ -110,6 +112,8 @@ __global__ __launch_bounds__(64) void ridge_clear_kernel(T* __restrict__ en, con
                                                          int64_t na, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (j >= n) return;
+    en += (int64_t)blockIdx.y * na * n; ridge += (int64_t)blockIdx.y * n;
+    if (ridge_e) ridge_e += (int64_t)blockIdx.y * n;
     const int64_t r = ridge[j];
     if (r < 0 || r >= na) return;          // (the reference raises IndexError)
     if (ridge_e) ridge_e[j] = en[r * n + j];
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(NT) void ridge_fw_kernel(const T* __restrict__ E, T
                                                       const TP* __restrict__ sc, TP pen, int na,
                                                       int64_t n, int nf, int S, int Crt, int TT) {
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
+    E += (int64_t)blockIdx.x * na * n; pe += (int64_t)blockIdx.x * na * n;      // one workgroup per transform of the batch
     const int C = CREG ? CREG : Crt;
     const int SC = S * C, W = TT + 1;
     T* prev0 = reinterpret_cast<T*>(smem);                      // pe[:, t-1], +inf beyond na
@@ -359,6 +364,7 @@ __global__ __launch_bounds__(RIDGE_BW_NT) void ridge_bw_kernel(const T* __restri
                                                        const TP* __restrict__ sc, TP pen, T eps, int na,
                                                        int64_t n, int64_t* __restrict__ ridge, int TT) {
     extern __shared__ __attribute__((aligned(32))) unsigned char smem[];
+    E += (int64_t)blockIdx.x * na * n; pe += (int64_t)blockIdx.x * na * n; ridge += (int64_t)blockIdx.x * n;
     const int W = TT + 3;                                       // TT + 1 columns, odd stride
     T* peT = reinterpret_cast<T*>(smem);
     T* eT = peT + (size_t)na * W;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(RIDGE_BW_NT) void ridge_bw_kernel(const T* __restri
 
 template <typename T, typename TP>
 static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double eps, int64_t na,
-                         int64_t n, int64_t* ridge, hipStream_t stream) {
+                         int64_t n, int64_t* ridge, int64_t batch, hipStream_t stream) {
     const RidgeGeom g = ridge_geometry<T, TP>(na);
     SSQ_REQUIRE(g.lds <= 160 * 1024, "ssq_ridge_track: %lld rows do not fit the workgroup's LDS",
                 (long long)na);
@@ -443,7 +449,7 @@ static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double
         auto fw = ridge_fw_kernel<T, TP, NT, F, CREG>;                                             \
         SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fw),                       \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds)); \
-        hipLaunchKernelGGL(fw, dim3(1), dim3(NT), g.lds, stream, E, pe, sc, (TP)penalty, (int)na, n, \
+        hipLaunchKernelGGL(fw, dim3((unsigned)batch), dim3(NT), g.lds, stream, E, pe, sc, (TP)penalty, (int)na, n, \
                            g.nf, g.S, g.C, g.TT);                                                  \
     } while (0)
     constexpr bool PF = sizeof(TP) == 4, TF = sizeof(T) == 4;   // register variants: see ridge_geometry
@@ -453,7 +459,7 @@ static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double
     else FW_LAUNCH(1024, 4, 0);
 #undef FW_LAUNCH
     SSQ_LAUNCH_CHECK();
-    hipLaunchKernelGGL((ridge_argmin_kernel<T>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((ridge_argmin_kernel<T>), dim3((unsigned)((n + 63) / 64), (unsigned)batch), dim3(64), 0, stream,
                        (const T*)pe, ridge, na, n);
     SSQ_LAUNCH_CHECK();
     int TT = 32;
@@ -468,7 +474,7 @@ static int ridge_track_t(const T* E, T* pe, const TP* sc, double penalty, double
     auto bwk = ridge_bw_kernel<T, TP>;
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwk),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(bwk, dim3(1), dim3(RIDGE_BW_NT), lds, stream, E, (const T*)pe, sc, (TP)penalty, (T)eps,
+    hipLaunchKernelGGL(bwk, dim3((unsigned)batch), dim3(RIDGE_BW_NT), lds, stream, E, (const T*)pe, sc, (TP)penalty, (T)eps,
                        (int)na, n, ridge, TT);
     SSQ_LAUNCH_CHECK();
     return 0;
@@ -499,10 +505,16 @@ int ssq_ridge_energy(int dtype, int is_complex, const void* Tf, void* energy, in
 
 int ssq_ridge_neglog(int dtype, const void* energy, void* E, double eps, int64_t na, int64_t n,
                      void* stream) {
+    return ssq_ridge_neglog_batch(dtype, energy, E, eps, na, n, 1, stream);
+}
+
+int ssq_ridge_neglog_batch(int dtype, const void* energy, void* E, double eps, int64_t na, int64_t n,
+                           int64_t batch, void* stream) {
     SSQ_REQUIRE(energy && E, "ssq_ridge_neglog: null pointer");
     SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "bad dtype %d", dtype);
-    SSQ_REQUIRE(na >= 1 && n >= 1, "ssq_ridge_neglog: bad shape (%lld, %lld)", (long long)na, (long long)n);
-    const dim3 grid((unsigned)((n + 63) / 64));
+    SSQ_REQUIRE(na >= 1 && n >= 1 && batch >= 1 && batch <= 65535, "ssq_ridge_neglog: bad shape (%lld, %lld, %lld)",
+                (long long)batch, (long long)na, (long long)n);
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)batch);
     hipStream_t s = as_stream(stream);
     if (dtype == SSQ_F32)
         hipLaunchKernelGGL((ridge_neglog_kernel<float>), grid, dim3(64), 0, s, (const float*)energy,
@@ -516,27 +528,38 @@ int ssq_ridge_neglog(int dtype, const void* energy, void* E, double eps, int64_t
 
 int ssq_ridge_track(int dtype, int penalty_f32, const void* E, void* pe, const void* sc, double penalty,
                     double eps, int64_t na, int64_t n, int64_t* ridge, void* stream) {
+    return ssq_ridge_track_batch(dtype, penalty_f32, E, pe, sc, penalty, eps, na, n, ridge, 1, stream);
+}
+
+int ssq_ridge_track_batch(int dtype, int penalty_f32, const void* E, void* pe, const void* sc, double penalty,
+                          double eps, int64_t na, int64_t n, int64_t* ridge, int64_t batch, void* stream) {
     SSQ_REQUIRE(E && pe && sc && ridge, "ssq_ridge_track: null pointer");
     SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "bad dtype %d", dtype);
-    SSQ_REQUIRE(na >= 1 && n >= 1 && na <= 16384, "ssq_ridge_track: bad shape (%lld, %lld)",
-                (long long)na, (long long)n);
+    SSQ_REQUIRE(na >= 1 && n >= 1 && na <= 16384 && batch >= 1 && batch <= 65535,
+                "ssq_ridge_track: bad shape (%lld, %lld, %lld)", (long long)batch, (long long)na, (long long)n);
     SSQ_REQUIRE(dtype == SSQ_F64 || penalty_f32, "ssq_ridge_track: float32 data take a float32 penalty");
     hipStream_t s = as_stream(stream);
     if (dtype == SSQ_F32)
         return ridge_track_t<float, float>((const float*)E, (float*)pe, (const float*)sc, penalty, eps, na, n,
-                                           ridge, s);
+                                           ridge, batch, s);
     if (penalty_f32)
         return ridge_track_t<double, float>((const double*)E, (double*)pe, (const float*)sc, penalty, eps,
-                                            na, n, ridge, s);
+                                            na, n, ridge, batch, s);
     return ridge_track_t<double, double>((const double*)E, (double*)pe, (const double*)sc, penalty, eps, na,
-                                         n, ridge, s);
+                                         n, ridge, batch, s);
 }
 
 int ssq_ridge_clear(int dtype, void* energy, const int64_t* ridge, double bw, void* ridge_e, int64_t na,
                     int64_t n, void* stream) {
+    return ssq_ridge_clear_batch(dtype, energy, ridge, bw, ridge_e, na, n, 1, stream);
+}
+
+int ssq_ridge_clear_batch(int dtype, void* energy, const int64_t* ridge, double bw, void* ridge_e, int64_t na,
+                          int64_t n, int64_t batch, void* stream) {
     SSQ_REQUIRE(energy && ridge, "ssq_ridge_clear: null pointer");
     SSQ_REQUIRE(dtype == SSQ_F32 || dtype == SSQ_F64, "bad dtype %d", dtype);
-    const dim3 grid((unsigned)((n + 63) / 64));
+    SSQ_REQUIRE(batch >= 1 && batch <= 65535, "ssq_ridge_clear: bad batch %lld", (long long)batch);
+    const dim3 grid((unsigned)((n + 63) / 64), (unsigned)batch);
     hipStream_t s = as_stream(stream);
     if (dtype == SSQ_F32)
         hipLaunchKernelGGL((ridge_clear_kernel<float>), grid, dim3(64), 0, s, (float*)energy, ridge, bw,

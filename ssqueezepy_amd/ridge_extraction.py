@@ -26,7 +26,10 @@ def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
     tracking (ssqueezepy/ridge_extraction.py:11-141).
 
     # Arguments
-        Tf: (n_scales, n_timeshifts) torch.Tensor / np.ndarray, complex or real.
+        Tf: (n_scales, n_timeshifts) torch.Tensor / np.ndarray, complex or real; or a batch of
+            transforms of one scale vector, (batch, n_scales, n_timeshifts) (an extension: the reference
+            takes one transform) -- every output gains the leading batch axis, and each transform's
+            result is what the 2D call returns for it.
         scales: frequency scales (CWT: scales, log'd inside; STFT: frequencies).
         penalty, n_ridges, bw, transform ('cwt' | 'stft'), get_params: as in the
             reference.
@@ -46,13 +49,20 @@ def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
             Tf = Tf.astype(np.float64)
         elif Tf.dtype == np.float16:
             Tf = Tf.astype(np.float32)
-    if Tf.ndim != 2:
-        raise ValueError("`Tf` must be 2D, (scales, timeshifts) (got shape %s)"
+    if Tf.ndim not in (2, 3):
+        raise ValueError("`Tf` must be 2D, (scales, timeshifts), or a batch of such, 3D (got shape %s)"
                          % (tuple(Tf.shape),))
     Tf = to_device(Tf)
     if Tf.dtype not in (torch.complex64, torch.complex128, torch.float32, torch.float64):
         Tf = Tf.to(torch.float64)
-    na, n = Tf.shape
+    # a batch (3D; not in the reference, whose extract_ridges takes one transform): every step below runs
+    # over all transforms in one launch -- a tracking pass is one workgroup's walk over time, so a batch
+    # costs about what one transform does
+    batched = Tf.ndim == 3
+    if not batched:
+        Tf = Tf[None]
+    Tf = Tf.contiguous()
+    B, na, n = Tf.shape
 
     # ridge_extraction.py:113-121: float64 only for complex128 input
     c128 = Tf.dtype == torch.complex128
@@ -74,23 +84,25 @@ def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
     code = F64 if rdt == torch.float64 else F32
     dev = Tf.device
     sc_d = torch.from_numpy(sc).to(dev)
-    energy = torch.empty((na, n), dtype=rdt, device=dev)
+    energy = torch.empty((B, na, n), dtype=rdt, device=dev)
     E = torch.empty_like(energy)
     pe = torch.empty_like(energy)
-    ridge = torch.empty(n, dtype=torch.int64, device=dev)
-    ridge_idxs = torch.zeros((n, n_ridges), dtype=torch.int64, device=dev)
-    ridge_e = torch.zeros((n, n_ridges), dtype=rdt, device=dev)
+    ridge = torch.empty((B, n), dtype=torch.int64, device=dev)
+    ridge_idxs = torch.zeros((B, n, n_ridges), dtype=torch.int64, device=dev)
+    ridge_e = torch.zeros((B, n, n_ridges), dtype=rdt, device=dev)
+    e_col = torch.empty((B, n), dtype=rdt, device=dev)
     st = stream()
-    check(lib.ssq_ridge_energy(code, int(is_cplx), _ptr(Tf), _ptr(energy), na, n, st))
+    check(lib.ssq_ridge_energy(code, int(is_cplx), _ptr(Tf), _ptr(energy), B * na, n, st))
     for i in range(n_ridges):
-        check(lib.ssq_ridge_neglog(code, _ptr(energy), _ptr(E), float(eps), na, n, st))
-        check(lib.ssq_ridge_track(code, int(not c128), _ptr(E), _ptr(pe), _ptr(sc_d), pen,
-                                  float(eps), na, n, _ptr(ridge), st))
-        e_col = ridge_e[:, i].contiguous()
-        check(lib.ssq_ridge_clear(code, _ptr(energy), _ptr(ridge), float(bw), _ptr(e_col),
-                                  na, n, st))
-        ridge_idxs[:, i] = ridge
-        ridge_e[:, i] = e_col
+        check(lib.ssq_ridge_neglog_batch(code, _ptr(energy), _ptr(E), float(eps), na, n, B, st))
+        check(lib.ssq_ridge_track_batch(code, int(not c128), _ptr(E), _ptr(pe), _ptr(sc_d), pen,
+                                        float(eps), na, n, _ptr(ridge), B, st))
+        check(lib.ssq_ridge_clear_batch(code, _ptr(energy), _ptr(ridge), float(bw), _ptr(e_col),
+                                        na, n, B, st))
+        ridge_idxs[:, :, i] = ridge
+        ridge_e[:, :, i] = e_col
+    if not batched:
+        ridge_idxs, ridge_e = ridge_idxs[0], ridge_e[0]
 
     if get_params:
         so = torch.from_numpy(np.ascontiguousarray(scales_orig.reshape(-1))).to(dev)

@@ -159,6 +159,27 @@ def test_on_device_transforms(S):
         assert (ri[:, 0] != ri[:, 1]).float().mean() > 0.99   # the +-bw band was cleared
 
 
+def test_batch_of_transforms(S):
+    """A 3D input (batch of transforms of one scale vector; not in the reference) == the 2D call per
+    transform: indices, frequencies, energies; tensors and arrays, CWT and STFT forms."""
+    import torch
+    N = 3000
+    xb = np.stack([two_chirps(N, s, noise=0.02) for s in (1, 2, 3)])
+    Tb, _, ssq_freqs, _ = S.ssq_cwt(xb, 'gmw')
+    assert Tb.ndim == 3
+    out = S.extract_ridges(Tb, ssq_freqs, penalty=2.0, n_ridges=2, bw=4, get_params=True)
+    assert tuple(out[0].shape) == (3, N, 2) and all(isinstance(a, torch.Tensor) for a in out)
+    for b in range(3):
+        one = S.extract_ridges(Tb[b], ssq_freqs, penalty=2.0, n_ridges=2, bw=4, get_params=True)
+        for A, a in zip(out, one):
+            assert torch.equal(A[b], a), b
+    Sb = S.ssq_stft(xb, n_fft=128, astensor=False)
+    ri = S.extract_ridges(Sb[0], Sb[2], penalty=20.0, transform='stft')
+    assert isinstance(ri, np.ndarray) and ri.shape == (3, Sb[0].shape[-1], 1)
+    for b in range(3):
+        assert np.array_equal(ri[b], S.extract_ridges(Sb[0][b], Sb[2], penalty=20.0, transform='stft'))
+
+
 def test_argument_checks(S):
     with pytest.raises(ValueError):
         S.extract_ridges(np.zeros((4, 8, 2)), np.arange(1, 5.))

@@ -69,3 +69,37 @@ def test_emulated_kernels_vs_oracle(emu, orc, cdtype, na, n, transform):
             ref[int(ridge[t] - bw):int(ridge[t] + bw), t] = 0
         assert np.array_equal(en2, ref)
         assert np.array_equal(r_e, en[ridge, np.arange(n)])
+
+
+@pytest.mark.parametrize('cdtype,na,n', [('complex64', 130, 37), ('complex128', 40, 70)])
+def test_emulated_batch_entry_points(emu, cdtype, na, n):
+    """ssq_ridge_{neglog,track,clear}_batch over three transforms == the single-transform entry points on each
+    (one workgroup per transform in the tracking passes, blockIdx.y elsewhere)."""
+    B = 3
+    rng = np.random.default_rng(na)
+    mag = rng.random((B, na, n)) + 3 * np.exp(-0.5 * ((np.arange(na)[None, :, None] - na * 0.5
+                                                         - 5 * np.arange(B)[:, None, None]) / 2)**2)
+    Tf = (mag * np.exp(2j * np.pi * rng.random((B, na, n)))).astype(cdtype)
+    f64 = cdtype == 'complex128'
+    rdt, code, pdt = (np.float64, 1, np.float64) if f64 else (np.float32, 0, np.float32)
+    eps = np.finfo(pdt).eps
+    sc = np.ascontiguousarray(np.log(np.exp(np.linspace(-0.3, 6.2, na))).astype(pdt))
+    i64, dbl = ctypes.c_int64, ctypes.c_double
+    en = np.empty((B, na, n), rdt)
+    assert emu.ssq_ridge_energy(code, 1, _p(Tf), _p(en), i64(B * na), i64(n), None) == 0
+    Eb, peb, rb = np.empty_like(en), np.empty_like(en), np.empty((B, n), np.int64)
+    assert emu.ssq_ridge_neglog_batch(code, _p(en), _p(Eb), dbl(float(eps)), i64(na), i64(n), i64(B), None) == 0
+    assert emu.ssq_ridge_track_batch(code, int(not f64), _p(Eb), _p(peb), _p(sc), dbl(2.0), dbl(float(eps)),
+                                     i64(na), i64(n), _p(rb), i64(B), None) == 0
+    enb, reb = en.copy(), np.empty((B, n), rdt)
+    assert emu.ssq_ridge_clear_batch(code, _p(enb), _p(rb), dbl(4), _p(reb), i64(na), i64(n), i64(B), None) == 0
+    for b in range(B):
+        e1 = np.ascontiguousarray(en[b])
+        E1, pe1, r1 = np.empty_like(e1), np.empty_like(e1), np.empty(n, np.int64)
+        assert emu.ssq_ridge_neglog(code, _p(e1), _p(E1), dbl(float(eps)), i64(na), i64(n), None) == 0
+        assert emu.ssq_ridge_track(code, int(not f64), _p(E1), _p(pe1), _p(sc), dbl(2.0), dbl(float(eps)),
+                                   i64(na), i64(n), _p(r1), None) == 0
+        re1 = np.empty(n, rdt)
+        assert emu.ssq_ridge_clear(code, _p(e1), _p(r1), dbl(4), _p(re1), i64(na), i64(n), None) == 0
+        assert np.array_equal(Eb[b], E1) and np.array_equal(peb[b], pe1) and np.array_equal(rb[b], r1)
+        assert np.array_equal(enb[b], e1) and np.array_equal(reb[b], re1)

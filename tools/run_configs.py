@@ -97,6 +97,13 @@ def main():
         ms, r = timeit(lambda: S.extract_ridges(Tx, ssq_freqs, penalty=2.0, n_ridges=1, bw=4), 2)
         print(json.dumps({"config": "extract_ridges ssq_cwt N=%d 300 scales f32, 1 ridge" % N,
                           "ms": ms, "us_per_step": ms * 1e3 / N}))
+        # ... and over a batch of transforms in one call (one workgroup per transform)
+        B = int(os.environ.get('RIDGE_B', 16))
+        Tb = Tx[None].expand(B, -1, -1).contiguous()
+        msb, rb = timeit(lambda: S.extract_ridges(Tb, ssq_freqs, penalty=2.0, n_ridges=1, bw=4), 2)
+        assert torch.equal(rb[0], r) and torch.equal(rb[B - 1], r)
+        print(json.dumps({"config": "extract_ridges batch of %d, N=%d 300 scales f32, 1 ridge" % (B, N),
+                          "ms": msb, "ms_per_transform": msb / B, "speedup_vs_one_by_one": ms * B / msb}))
 
 
 if __name__ == '__main__':
