@@ -338,7 +338,7 @@ struct BlockArgs64 {
 };
 
 template <int L, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(FftGeom<double>::NT) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
+__global__ __launch_bounds__(FftGeom<double>::NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
     constexpr int NT64 = FftGeom<double>::NT;
     __shared__ c64 buf[FftGeom<double>::D];
     __shared__ c64 spow[R1 * G];
