@@ -15,6 +15,10 @@
 #define SSQ_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
 // ... and as a wave-uniform value the compiler may not fold or hoist (it stays in a scalar register)
+// occupancy the compiler must plan a kernel's registers for (wavefronts per SIMD: min, max)
+#ifndef SSQ_WAVES_PER_EU
+#define SSQ_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 #ifndef SSQ_OPAQUE_S
 #define SSQ_OPAQUE_S(x) asm volatile("" : "+s"(x))
 #endif

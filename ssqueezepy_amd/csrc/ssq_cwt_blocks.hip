@@ -337,8 +337,10 @@ struct BlockArgs64 {
     int sig;
 };
 
+// (two wavefronts per SIMD: left alone the compiler takes 276-280 registers -- one wavefront per SIMD -- and config 5's
+// block rows run at 10.5 ms instead of 8.1; at 256 it spills ~90 bytes per lane)
 template <int L, int G, int R1, int R2, int R3>
-__global__ __launch_bounds__(FftGeom<double>::NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
+__global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
     constexpr int NT64 = FftGeom<double>::NT;
     __shared__ c64 buf[FftGeom<double>::D];
     __shared__ c64 spow[R1 * G];
