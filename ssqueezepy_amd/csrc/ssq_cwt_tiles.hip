@@ -1478,9 +1478,22 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         std::vector<double> pre((size_t)n_items2 + 1, 0.0);
         for (int it = 0; it < n_items2; ++it) pre[it + 1] = pre[it] + cost[it];
         std::vector<int32_t> wt_;
+        // (SSQ_TILE2_WAVE_SPEED="a,b,c,d": relative speeds of the wavefront groups 0-3 / 4-7 / 8-11 / 12-15 to size the
+        // blocks by. The -DSSQ_TILE2_PROF stamps show the older wavefronts of a SIMD -- w, w + 4, w + 8, w + 12 share one --
+        // finishing the same work 10-19 % sooner and waiting at the tile's end; sizing the blocks by that changes
+        // nothing (221 +- 3 us for every setting tried): a SIMD's total is what counts, and it is the same.)
+        float speed[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (const char* e = getenv("SSQ_TILE2_WAVE_SPEED")) {
+            float v[4];
+            if (sscanf(e, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0)
+                for (int k = 0; k < 4; ++k) speed[k] = v[k];
+        }
         for (int nw : {12, 16}) {
             int cur = 0;
+            double stot = 0, sacc = 0;
+            for (int w = 0; w < nw; ++w) stot += speed[std::min(w / 4, 3)];
             for (int w = 0; w < nw; ++w) {
+                sacc += speed[std::min(w / 4, 3)];
                 if (cur >= n_items2) { wt_.insert(wt_.end(), {n_items2, n_items2, n_items2, 0}); continue; }
                 int r0 = 0;
                 while (run_start[r0 + 1] <= cur) ++r0;
@@ -1490,7 +1503,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                 int mine = rem == 0 ? n_items2 : run_start[std::min(rmin, nruns)];
                 mine = std::max(mine, cur + 1);
                 int e = cur;
-                const double want = pre[n_items2] * (w + 1) / nw;
+                const double want = pre[n_items2] * sacc / stot;
                 while (e < n_items2 && pre[e + 1] <= want + 1e-9) ++e;
                 e = std::min(std::max(e, mine), maxe);
                 if (rem == 0) { e = n_items2; if (e > maxe) tile2_ok = false; }
