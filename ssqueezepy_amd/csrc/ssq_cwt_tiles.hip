@@ -900,6 +900,7 @@ struct Tile2Args {
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
     int64_t N, na;
     int n_items, n1, mmask, lgM, sig0, nsig, group;
+    int carry;                                       // the walk b, b + G, ... runs through the signals' boundaries
     float inv_m, theta_scale, cst0;
     unsigned long long* counters;
     double gamma;
@@ -947,8 +948,12 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
 
     const int ntx = (int)((N + COLS - 1) / COLS);
     const int G = (int)gridDim.x;
+    // Workgroup b walks tiles b, b + G, ... -- of each signal (then a signal's last round is short for the
+    // workgroups past ntx mod G, launch after launch: 304 against 320 tiles at config 2), or, A.carry, of the
+    // signals laid end to end (the launcher allows it when the lanes' weights survive the boundary).
     const int per_sig = (int)blockIdx.x < ntx ? (ntx - (int)blockIdx.x + G - 1) / G : 0;
-    const int ntl = per_sig * A.nsig;                          // tiles of this workgroup
+    const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - (int)blockIdx.x + G - 1) / G)
+                            : per_sig * A.nsig;                // tiles of this workgroup
     const auto* waves = SSQ_CONST_PTR(int4, A.waves);
     const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
     // The wavefronts of a SIMD compete for its issue slots and the oldest wins: left alone, the four
@@ -1056,7 +1061,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
         for (int j = 0; j < ntl; ++j) {
             finish_tile(tx, sg);
             tx += G;
-            if (tx >= ntx) { tx = (int)blockIdx.x; ++sg; }
+            if (tx >= ntx) { tx = A.carry ? tx - ntx : (int)blockIdx.x; ++sg; }
         }
         return;
     }
@@ -1072,13 +1077,16 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     struct Pos { int nabs0, sg; int64_t off8; };
     const int nabs_step = G * COLS, nabs_first = A.n1 + (int)blockIdx.x * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
     const int64_t off8_step = (int64_t)G * COLS * 8;
-    const int64_t off8_wrap = ((int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS) * 8;
+    // (a signal's end: back to the workgroup's first tile, or -- carry -- on by the same stride into the next signal)
+    const int64_t off8_wrap = A.carry ? ((int64_t)na * N + (int64_t)(G - ntx) * COLS) * 8
+                                      : ((int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS) * 8;
+    const int nabs_back = ntx * COLS;
     auto next_tile = [&](Pos q) {
         Pos r = q;
         r.nabs0 += nabs_step;
         const bool wrap = r.nabs0 > nabs_last;
         r.off8 += wrap ? off8_wrap : off8_step;
-        if (wrap) { r.nabs0 = nabs_first; ++r.sg; }
+        if (wrap) { r.nabs0 = A.carry ? r.nabs0 - nabs_back : nabs_first; ++r.sg; }
         return (wrap && r.sg >= A.nsig) ? q : r;               // (the tile after the last: the last)
     };
     const int total = ntl * ni;                                // positions of this wavefront
@@ -1823,7 +1831,13 @@ static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams
     const int64_t cap = (int64_t)P.ncu * per_cu;
     const int64_t q = std::max<int64_t>(1, ((int64_t)1 << P.lgr_max2) / COLS);
     const int64_t G = ntx <= cap ? ntx : std::max<int64_t>(q, cap / q * q);
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, A, sp);
+    // ... and through the signals' boundaries when a signal's tile count keeps that phase too
+    // (SSQ_TILE2_CARRY=0: every signal's walk starts at the workgroup's own tile)
+    const char* ce = getenv("SSQ_TILE2_CARRY");              // (read per launch: tests switch it)
+    const bool carry_on = !(ce && atoi(ce) == 0);
+    Tile2Args B = A;
+    B.carry = (carry_on && ntx > G && ntx % q == 0) ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
@@ -1865,7 +1879,7 @@ int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const uns
         B.lgM = 0; while (((int64_t)1 << B.lgM) < M) ++B.lgM;
         B.sig0 = sig; B.nsig = nsig; B.group = group; B.inv_m = 1.0f / (float)M;
         B.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); B.cst0 = cst0;
-        B.counters = counters; B.gamma = sp.gamma;
+        B.counters = counters; B.gamma = sp.gamma; B.carry = 0;
 #define TILE2_LAUNCH(G)                                                                     \
         return dWx ? launch_tile2<G, true>(*this, B, sp, stream) : launch_tile2<G, false>(*this, B, sp, stream);
         auto launch2 = [&]() -> int {

@@ -140,6 +140,27 @@ def test_block_classes_in_one_launch_emulated(S, monkeypatch):
     _cwt.clear_plan_cache()
 
 
+def test_tile_walk_through_signal_boundaries_emulated(S, monkeypatch):
+    """tile2_kernel's workgroups walk tiles b, b + G, ... of the signals laid end to end (no short last round per
+    signal) when the lanes' resident weights survive the boundary: same results as the walk that restarts at every
+    signal (SSQ_TILE2_CARRY=0); 6 and 4 workgroups over 80 / 126 tiles x 3 signals, so that the boundary shifts."""
+    from conftest import two_chirps
+    from ssqueezepy_amd import _cwt
+    for grid, N in (('6', 2560), ('4', 4003)):
+        monkeypatch.setenv('SSQ_TILE_GRID', grid)
+        xb = np.stack([two_chirps(N, seed=s) for s in range(3)])
+        out = {}
+        for carry in ('0', '1'):
+            monkeypatch.setenv('SSQ_TILE2_CARRY', carry)
+            _cwt.clear_plan_cache()
+            Tx, Wx, *_ = S.ssq_cwt(xb, S.Wavelet(), scales='log', nv=16, astensor=False)
+            plan = next(iter(_cwt._PLAN_CACHE.values()))
+            assert plan.tile_rows > 0 and plan.tiles_done() == 3 * plan.tiles_per_signal(N)
+            out[carry] = (Tx, Wx)
+        assert np.array_equal(out['0'][1], out['1'][1]) and np.array_equal(out['0'][0], out['1'][0])
+    _cwt.clear_plan_cache()
+
+
 def test_fused_stft_reassignment_emulated(S, monkeypatch):
     """ssq_stft without dSx: the fused STFT kernel sums Tx of its frames in LDS (float64, unordered) --
     against the ordered two-kernel path on the same input (which the GPU suite checks against the
