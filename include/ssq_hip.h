@@ -45,7 +45,12 @@ extern "C" {
 #define SSQ_PAD_WRAP 4
 
 /* ------------------------------------------------------------------ runtime */
-int         ssq_version(void);          /* 103 (102: without ssq_ridge_*_batch; 101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
+int         ssq_version(void);          /* 104 (103: without ssq_build_sha / ssq_cwt_plan_set_bin_dump; 102: without ssq_ridge_*_batch; 101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
+/* The git commit of the device code this library was built from: the last commit that touched
+ * ssqueezepy_amd/csrc or include/ ("<sha>-dirty" when the build tree had uncommitted changes there,
+ * "unknown" when built outside a git checkout). Measurement records carry it (bench.py, profiles/):
+ * evidence and library can be matched without trusting a file name. */
+const char* ssq_build_sha(void);
 const char* ssq_last_error(void);
 int         ssq_device_count(int* count);
 int         ssq_set_device(int device);
@@ -338,6 +343,19 @@ int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
  * environment (float32 tile, terms added in the reference's row order; na <= 318). 0 without
  * tile tables. */
 int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
+
+/* Diagnostic (tests; not needed by a caller of the transforms): from now on every fused execute
+ * (Tx requested, bins from dWx) also writes the bin index of every point AS THE REASSIGNMENT CONSUMED
+ * IT -- 0 .. na-1, 0xFFFF for a point below gamma -- to `kmap`, a caller-owned device array
+ * (batch, na, n) of uint16; NULL switches it off. On the column-tile path the default tile kernel
+ * (a separate diagnostic build of it: uniform reassignment weights, i.e. 'log' scales, 16 wavefronts)
+ * stores the bins it computes for the rows it interpolates and the ones it reads back for the others;
+ * on the block path + separate reassignment the plan's own bin map is copied. With
+ * SSQ_TILE_ORDER=ordered on the tile path the execute fails (that kernel's Tx is the CPU loop's bit
+ * for bit, which pins its bins). Replaces the reference's `ssqueeze_fast(..., get_k)`-style
+ * introspection: /root/reference has none (algos.py:859-984 computes k inline), the oracle's
+ * `get_k` is the other side of the comparison. */
+int  ssq_cwt_plan_set_bin_dump(ssq_cwt_plan* plan, unsigned short* kmap);
 
 /* Rows per step the tile kernel of this build walks (4; the host tables of
  * ssq_cwt_plan_set_tiles must be built for the same number: `rows` holds that many records per

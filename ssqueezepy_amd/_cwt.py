@@ -221,6 +221,16 @@ class CwtPlan():
         """columns per tile of the tile kernel the next execute launches (0: no tile path)"""
         return int(self.lib.ssq_cwt_plan_tile_cols(self._h))
 
+    def set_bin_dump(self, kmap):
+        """Diagnostic (`ssq_cwt_plan_set_bin_dump`): `kmap` -- a GPU int16 / uint16 tensor of at least
+        ``max_batch * na * N`` elements, kept alive by the plan -- receives the bin index of every point
+        of every following fused execute (0xFFFF: below gamma); ``None`` switches it off."""
+        if kmap is not None and (kmap.element_size() != 2 or kmap.numel() < self.max_batch * self.na * self.N
+                                 or not kmap.is_contiguous()):
+            raise ValueError("bin dump: a contiguous 2-byte tensor of max_batch * na * N elements is needed")
+        check(self.lib.ssq_cwt_plan_set_bin_dump(self._h, kmap.data_ptr() if kmap is not None else None))
+        self._kdump = kmap
+
     def tiles_per_signal(self, N):
         return -(-int(N) // self.tile_cols) if self.tile_cols else 0
 

@@ -121,6 +121,8 @@ _PROTOS = {
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
     'ssq_cwt_plan_tile_cols': (c_int, [c_void_p]),
+    'ssq_cwt_plan_set_bin_dump': (c_int, [c_void_p, c_void_p]),
+    'ssq_build_sha': (c_char_p, []),
     'ssq_cwt_tile_rows_per_step': (c_int, []),
     'ssq_stft_plan_create': (c_int, [POINTER(c_void_p), POINTER(StftDesc)]),
     'ssq_stft_plan_destroy': (None, [c_void_p]),
@@ -135,7 +137,7 @@ EXPORTS = tuple(_PROTOS)
 _lib = None
 
 
-ABI_VERSION = 103     # include/ssq_hip.h: ssq_version()
+ABI_VERSION = 104     # include/ssq_hip.h: ssq_version()
 
 
 def load(build_if_missing=True):

@@ -34,6 +34,43 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
           '-I' + os.path.join(ROCM, 'include'), '-Wno-unused-result']
 
 
+def device_code_sha():
+    """The last commit that touched the device code (csrc/, include/), "-dirty" appended when the
+    working tree differs from it there; None outside a git checkout (the GPU box: the library built
+    here travels with its stamp)."""
+    root = os.path.join(HERE, '..')
+    paths = ['ssqueezepy_amd/csrc', 'include']
+    try:
+        sha = subprocess.run(['git', 'log', '-1', '--format=%H', '--'] + paths, cwd=root, capture_output=True,
+                             text=True, timeout=20)
+        if sha.returncode or not sha.stdout.strip():
+            return None
+        dirty = subprocess.run(['git', 'status', '--porcelain', '--'] + paths, cwd=root, capture_output=True,
+                               text=True, timeout=20)
+        return sha.stdout.strip() + ('-dirty' if dirty.stdout.strip() else '')
+    except Exception:
+        return None
+
+
+def _stamp(objdir, verbose):
+    """_obj/build_info.o: the strong definition of `ssq_build_sha_value` (ssq_kernels.hip holds a weak
+    "unknown"). Returns (object or None, changed)."""
+    src, obj = os.path.join(objdir, 'build_info.c'), os.path.join(objdir, 'build_info.o')
+    sha = device_code_sha()
+    if sha is None:                       # no git here: keep whatever stamp the objects came with
+        return (obj if os.path.isfile(obj) else None), False
+    text = 'const char ssq_build_sha_value[] = "%s";\n' % sha
+    if os.path.isfile(src) and os.path.isfile(obj) and open(src).read() == text:
+        return obj, False
+    with open(src, 'w') as fh:
+        fh.write(text)
+    cmd = ['gcc', '-fPIC', '-c', src, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj, True
+
+
 def _newer(src, dst):
     return (not os.path.isfile(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -59,7 +96,10 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
             rebuilt = True
         objs.append(opath)
-    if rebuilt or not os.path.isfile(LIB):
+    stamp, restamped = _stamp(objdir, verbose)
+    if stamp:
+        objs.append(stamp)
+    if rebuilt or restamped or not os.path.isfile(LIB):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + [
             '-L' + os.path.join(ROCM, 'lib'), '-lrocfft',
             '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]

@@ -162,6 +162,7 @@ struct ssq_cwt_plan {
     BlockPlan* blk = nullptr;
     TilePlan* tile = nullptr;             // column-tile path of the fused ssq form (ssq_cwt_tiles.hip)
     bool executed = false;
+    unsigned short* kdump = nullptr;      // diagnostic (ssq_cwt_plan_set_bin_dump): caller-owned (batch, na, n) bin map
     // optional per-stage HIP-event timing (bench.py reads it): 0 = pad + forward FFT +
     // block spectra, 1 = block rows, 2 = exact / generic rows, 3 = reassignment
     bool timing = false;
@@ -355,6 +356,13 @@ int ssq_cwt_plan_timing(ssq_cwt_plan* pl, int enable, double* stage_ms, int64_t*
     return 0;
 }
 
+int ssq_cwt_plan_set_bin_dump(ssq_cwt_plan* pl, unsigned short* kmap) {
+    SSQ_REQUIRE(pl, "ssq_cwt_plan_set_bin_dump: null plan");
+    std::lock_guard<std::mutex> lock(pl->order.mu);
+    pl->kdump = kmap;
+    return 0;
+}
+
 int ssq_cwt_plan_group(const ssq_cwt_plan* pl) { return pl ? pl->group : 0; }
 int ssq_cwt_tile_rows_per_step(void) { return ssq::tile_rows_per_step(); }
 int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* pl, void* stream) {
@@ -415,7 +423,9 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     const int64_t n_gen = use_blocks ? pl->n_gen : na;
     // fused ssq form on the column-tile path: block / exact kernels only for the rows the
     // tile kernel reads back, no separate reassignment launch
-    const bool use_tiles = use_blocks && pl->tile && Tx && !w && sizeof(T) == 4;
+    // (a tile plan the selected kernel cannot run -- more rows than the ordered kernel's tile holds -- is decided
+    // HERE, before any row is routed: those calls take the block kernels + the separate reassignment)
+    const bool use_tiles = use_blocks && pl->tile && pl->tile->usable() && Tx && !w && sizeof(T) == 4;
     if (use_blocks) {
         int rc = pl->blk->spectra(pl->xp, pl->xh, batch, stream, use_tiles ? pl->tile->class_need.data() : nullptr);
         if (rc) return rc;
@@ -508,9 +518,14 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         mark(2 + 4 * slot + 2);
         if (use_tiles) {
             if (fork) SSQ_CHECK_HIP(hipStreamWaitEvent(stream, pl->tile->ev_join, 0));
-            int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->cst0, pl->sp, stream);
+            int rc2 = pl->tile->run((int)b0, ng, (float*)Wx, (float*)dWx, (float*)Tx, pl->kidx, pl->cst, pl->cst0, pl->sp, stream,
+                                    pl->kdump);
             if (rc2) return rc2;
         } else if (Tx) {
+            // (diagnostic: the map the separate reassignment is about to consume)
+            if (pl->kdump && !w)
+                SSQ_CHECK_HIP(hipMemcpyAsync(pl->kdump + (size_t)b0 * na * N, pl->kidx, (size_t)ng * na * N * 2,
+                                             hipMemcpyDeviceToDevice, stream));
             T* Wx_g = (T*)Wx + (size_t)b0 * na * out_cols * 2;
             T* w_g = w ? (T*)w + (size_t)b0 * na * out_cols : nullptr;
             T* Tx_g = (T*)Tx + (size_t)b0 * na * out_cols * 2;

@@ -898,6 +898,7 @@ struct Tile2Args {
     const float4* wtab; const float2* U;
     const void* cst;
     float2* Wx; float2* dWx; float2* Tx; const unsigned short* kidx;
+    unsigned short* kdump;   // STORE_K builds: the bin of every point as it is consumed, (signal, row, column); else null
     int64_t N, na;
     int n_items, n1, mmask, lgM, sig0, nsig, group;
     int carry;                                       // the walk b, b + G, ... runs through the signals' boundaries
@@ -928,7 +929,9 @@ struct Tile2Args {
 //     rows spans at most two decimation classes (the host cuts the blocks that way), and a lane's
 //     weights depend on its column only through n mod R, the same for every tile of a workgroup
 //     whose tile stride is a multiple of R (the launcher picks the grid that way).
-template <int GRID, bool STORE_D, int NW, int CSTK, int COLS>
+// STORE_K (diagnostic builds, ssq_cwt_plan_set_bin_dump): every point's bin index goes to A.kdump as the
+// reassignment consumes it -- what pins the kernel's index work as integers against the oracle's map.
+template <int GRID, bool STORE_D, int NW, int CSTK, int COLS, bool STORE_K = false>
 __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams sp) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int RPI = Tile2Geo<COLS>::RPI, LGC = Tile2Geo<COLS>::LGC;
@@ -1221,6 +1224,10 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
             const int kk = dc.kq & 0xFFFF;
             cell16 = (livept && kk != TILE_NOBIN) ? kk * (COLS * 16) + c16 : scratch16;
             tvx = dc.u.x; tvy = dc.u.y;
+            if constexpr (STORE_K) {
+                char* kd8 = reinterpret_cast<char*>(A.kdump) + (((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]) >> 2);
+                if (livept) *reinterpret_cast<unsigned short*>(kd8 + (size_t)(lane_row8 >> 2)) = (unsigned short)kk;
+            }
         } else {
             const int lgR = (w0 >> 13) & 31;
             const int qb3 = pc.nabs0 >> lgR;                   // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
@@ -1300,6 +1307,10 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
 #endif
             cell16 = kout >= 0 ? kout * (COLS * 16) + c16 : scratch16;
             tvx = Wv.x; tvy = Wv.y;
+            if constexpr (STORE_K) {
+                char* kd8 = reinterpret_cast<char*>(A.kdump) + (((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]) >> 2);
+                if (livept) *reinterpret_cast<unsigned short*>(kd8 + (size_t)(lane_row8 >> 2)) = (unsigned short)(kout >= 0 ? kout : TILE_NOBIN);
+            }
             T2_STAMP(4);                                       // arithmetic, store, bin
         }
         {
@@ -1812,9 +1823,9 @@ static int launch_tile(const TilePlan& P, const TileArgs& A, const SsqParams& sp
 }
 
 // ---- tile2_kernel launch
-template <int GRID, bool STORE_D, int NW, int CSTK, int COLS>
+template <int GRID, bool STORE_D, int NW, int CSTK, int COLS, bool STORE_K = false>
 static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
-    auto kern = tile2_kernel<GRID, STORE_D, NW, CSTK, COLS>;
+    auto kern = tile2_kernel<GRID, STORE_D, NW, CSTK, COLS, STORE_K>;
     const size_t lds = tile2_lds_bytes(P.na, COLS);
     static bool attr_set = false;            // per instantiation
     if (!attr_set) {
@@ -1844,6 +1855,16 @@ static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams
 template <int GRID, bool STORE_D, int NW, int COLS>
 static int launch_tile2_k(const TilePlan& P, const Tile2Args& A, const SsqParams& sp, hipStream_t stream) {
     const int cstk = sp.cst_f64 ? 2 : (sp.cst_uniform ? 0 : 1);
+    if (A.kdump) {
+        // the diagnostic builds exist for the default wavefront count and one weight per transform (the bins do
+        // not depend on the weights: 'log' scales, what the full-size index test runs)
+        if constexpr (NW == 16) {
+            SSQ_REQUIRE(cstk == 0, "bin dump: built for uniform reassignment weights ('log' scales)");
+            return launch_tile2_c<GRID, STORE_D, NW, 0, COLS, true>(P, A, sp, stream);
+        } else {
+            SSQ_REQUIRE(false, "bin dump: built for 16 wavefronts per workgroup (unset SSQ_TILE_NW)");
+        }
+    }
     if (cstk == 0) return launch_tile2_c<GRID, STORE_D, NW, 0, COLS>(P, A, sp, stream);
     if (cstk == 1) return launch_tile2_c<GRID, STORE_D, NW, 1, COLS>(P, A, sp, stream);
     return launch_tile2_c<GRID, STORE_D, NW, 2, COLS>(P, A, sp, stream);
@@ -1866,12 +1887,18 @@ static int launch_tile2(const TilePlan& P, Tile2Args& A, const SsqParams& sp, hi
 // SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
 // 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
 bool tile_ordered() { return reassign_ordered(); }
-int TilePlan::tile_cols() const { return (tile_ordered() || !tile2_ok) ? TILE_COLS : cols2; }
+bool TilePlan::usable() const {
+    if (!tile_ordered() && tile2_ok) return true;
+    return tile_lds_bytes(na) <= 160 * 1024;
+}
+int TilePlan::tile_cols() const { return !usable() ? 0 : (tile_ordered() || !tile2_ok) ? TILE_COLS : cols2; }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
-                  const void* cst, float cst0, const SsqParams& sp, hipStream_t stream) {
+                  const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump) {
+    SSQ_REQUIRE(!kdump || (!tile_ordered() && tile2_ok), "bin dump: the default tile kernel only (unset SSQ_TILE_ORDER)");
     if (!tile_ordered() && tile2_ok) {
         Tile2Args B;
+        B.kdump = kdump;
         B.items = reinterpret_cast<const int*>(items2); B.waves = nullptr;
         B.wtab = (const float4*)wtab; B.U = (const float2*)U; B.cst = cst;
         B.Wx = (float2*)Wx; B.dWx = (float2*)dWx; B.Tx = (float2*)Tx; B.kidx = kidx;

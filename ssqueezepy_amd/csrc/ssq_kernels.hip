@@ -868,9 +868,14 @@ static inline unsigned stream_grid(int64_t total, int block = 256) {
 using namespace ssq;
 
 // ======================================================================= C ABI
+// the build's stamp: ssqueezepy_amd/build.py links a strong definition (the last commit that touched
+// csrc/ or include/) over this one
+extern "C" __attribute__((weak)) const char ssq_build_sha_value[] = "unknown";
+
 extern "C" {
 
-int ssq_version(void) { return 103; }   // 103: ssq_ridge_*_batch; 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
+const char* ssq_build_sha(void) { return ssq_build_sha_value; }
+int ssq_version(void) { return 104; }   // 104: ssq_build_sha, ssq_cwt_plan_set_bin_dump; 103: ssq_ridge_*_batch; 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
 const char* ssq_last_error(void) { return g_last_error.c_str(); }
 
 int ssq_device_count(int* count) {

@@ -67,7 +67,12 @@ struct TilePlan {
     int n_items2 = 0, cols2 = 32;
     int lgr_max2 = 0;                       // largest decimation (log2) among the interpolated classes
     bool tile2_ok = false;                  // the items could be cut into blocks of at most two classes
-    int tile_cols() const;                  // columns per tile of the kernel that `run` launches
+    int tile_cols() const;                  // columns per tile of the kernel that `run` launches (0: none can run)
+    // Can `run` launch a tile kernel for this plan in the mode selected right now? The default kernel needs the
+    // items cut into blocks of at most two classes (tile2_ok), the ordered one (SSQ_TILE_ORDER=ordered, also the
+    // stand-in when !tile2_ok) a 64-column float32 tile inside the LDS (na <= 318). Asked by the executor BEFORE it
+    // routes any row: a plan that is not usable takes the block kernels + the separate reassignment for every row.
+    bool usable() const;
     // A, B > 0: a long class transformed by the four-step kernels of ssq_cwt_tiles.hip (L = A B);
     // A = 0, B = 1: a short class (64 .. 4096 entries) transformed by the one-pass kernel;
     // A = B = 0: rocFFT. first: its rows in `irows` (sorted by class, the classes of our own
@@ -91,8 +96,9 @@ struct TilePlan {
     // intermediates of signals sig .. sig+nsig-1 (nsig <= group) from the spectra of the batch
     int spectra(int sig, int nsig, const void* xh_all, hipStream_t stream);
     // Wx of the interpolated rows, Tx of all rows (the other rows' Wx and bin map must be in place)
+    // (kdump: diagnostic -- the bin of every point as the kernel consumed it, (batch signal, row, column), or null)
     int run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
-            const void* cst, float cst0, const SsqParams& sp, hipStream_t stream);
+            const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump = nullptr);
     // tiles finished by the tile kernel so far (synchronises `stream`): what actually ran
     int64_t tiles_done(hipStream_t stream);
 };

@@ -350,11 +350,15 @@ def test_tile_kernel_every_instantiation(S, orc, case, tile_mode):
     assert_tx_repeat(T2, Tx, tiles=True, what=case)
 
 
-def test_more_rows_than_the_32_column_tile_holds(S, orc):
+def test_more_rows_than_the_32_column_tile_holds(S, orc, tile_mode):
     """456 rows -- `process_scales('log', N, nv=32)` without the `[:300]` of the benchmark --
     exceed the 318 rows a 32-column float64 tile (and the ticketed kernel's 64-column float32 tile)
     can keep in a CU's LDS: the default tile kernel then runs 16-column tiles, four rows per
-    wavefront instruction. What executed is asserted on, and the result against the oracle."""
+    wavefront instruction. The ordered kernel has no such form: with `SSQ_TILE_ORDER=ordered` the plan
+    reports no usable tile kernel (`tile_cols == 0`) and the call takes the block kernels + the ordered
+    reassignment for every row -- decided before any row is routed (round-4 advisor: it used to fail
+    inside `TilePlan::run`, after the block work had been launched). What executed is asserted on,
+    and the result against the oracle, in both modes."""
     from ssqueezepy_amd import _cwt
     from pipeline import oracle_ssq_cwt, GRIDNAME
     N = 20000 if os.environ.get('SSQ_EMULATE') == '1' else 160000
@@ -365,8 +369,11 @@ def test_more_rows_than_the_32_column_tile_holds(S, orc):
     Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales=scales, get_dWx=True, astensor=False)
     plan = next(iter(_cwt._PLAN_CACHE.values()))
     assert plan.na == len(scales) > 318
-    assert plan.tile_cols == 16 and plan.tile_rows > 0.5 * plan.na
-    assert plan.tiles_done() == plan.tiles_per_signal(N), (plan.tiles_done(), plan.algo)
+    if tile_mode == 'ordered':
+        assert plan.tile_cols == 0 and plan.tiles_done() == 0, (plan.tile_cols, plan.tiles_done(), plan.algo)
+    else:
+        assert plan.tile_cols == 16 and plan.tile_rows > 0.5 * plan.na
+        assert plan.tiles_done() == plan.tiles_per_signal(N), (plan.tiles_done(), plan.algo)
     r = oracle_ssq_cwt(orc, x, 'float32', scales=scales)
     assert np.abs(Wx - r['Wx']).max() <= 1e-5 * np.abs(r['Wx']).max()
     assert np.abs(dWx - r['dWx']).max() <= 1e-5 * np.abs(r['dWx']).max()

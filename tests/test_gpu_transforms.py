@@ -279,10 +279,14 @@ def test_full_size_properties(S):
 
 
 def test_full_size_bin_map_exact(S, orc):
-    """BASELINE config 2 at full size, index work bit-exact: the fused kernels'
-    float32-screened bin map (48M points) must reproduce the exact double-precision
-    map of the CPU path. The oracle reassigns this engine's own (Wx, dWx): equal Tx,
-    cell for cell, means every one of the 48M indices and the summation order agree."""
+    """BASELINE config 2 at full size: the oracle reassigns this engine's own (Wx, dWx) and `Tx`
+    is compared with the result. With `SSQ_TILE_ORDER=ordered` (the ticketed kernel; the `tile_mode`
+    fixture and test_gpu_00_configs run it) equal `Tx`, cell for cell, means every one of the 48 M
+    indices and the summation order agree. In the DEFAULT mode (float64 tile, unordered adds) the
+    comparison is to 1e-6 of the largest cell: it pins the sums and every bin whose point weighs more
+    than that -- not the indices of points below it. Those are pinned as integers by
+    test_gpu_00_configs.py::test_config2_bin_indices_are_the_oracles_integers (a bin dump of the same
+    kernel against the oracle's map, `array_equal`); this test keeps the lean / full build comparison."""
     N, na = 160000, 300
     wav = S.Wavelet()
     scales = S.process_scales('log', N, wav, nv=32)[:na]
