@@ -278,6 +278,10 @@ def main():
                 tj = json.load(fh)
             traffic = tj.get('bytes_per_transform')
             traffic_sha = tj.get('git_sha')
+        # the device code this run executed (stamped into the library at build time: the last commit that
+        # touched csrc/ or include/) against the one the PMC traffic figure was collected on
+        from ssqueezepy_amd import _lib
+        build_sha = _lib.load(build_if_missing=False).ssq_build_sha().decode()
         line = {
             "metric": "ssq_cwt transforms/sec (N=160k, 300 scales, f32)",
             "value": value, "unit": "transforms/s", "n_gpus": world, "ranks": (dist.get_world_size() if world > 1 else 1),
@@ -292,12 +296,13 @@ def main():
                        "signals_per_gpu_per_step": B,
                        "sharding": "independent signals per rank, no data-path "
                                    "collective; one all_gather of checksums",
-                       "algo": plan.algo,
+                       "algo": plan.algo, "build_sha": build_sha,
                        "tile_kernel": ("ordered (ticketed float32 tile)" if os.environ.get('SSQ_TILE_ORDER') == 'ordered'
                                        else "float64 tile, unordered ds_add_f64") if 'tiles' in plan.algo else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_at": traffic_sha,
+                         "traffic_stale": (traffic is not None and traffic_sha != build_sha),
                          "scope": "whole transform (all kernels), HIP-event timed",
                          "bytes_alg_per_transform": bytes_alg,
                          "us_per_transform": t_transform * 1e6},

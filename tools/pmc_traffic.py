@@ -41,7 +41,17 @@ def main(d, n_transforms, out=None):
               % (acc[0][0][:40], acc[0][1] / 2 / known_rd, acc[0][2] / known_wr))
     print("total per transform: %.1f MB" % (total / 1e6))
     if out:
-        json.dump({"bytes_per_transform": total,
+        # the device code measured: the library's own stamp (ssq_build_sha: the last commit that touched csrc/ or
+        # include/), which bench.py compares with the library it runs (`roofline.traffic_stale`)
+        import ctypes
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            lib = ctypes.CDLL(os.environ.get('SSQ_HIP_LIB') or os.path.join(root, 'ssqueezepy_amd', 'libssq_hip.so'))
+            lib.ssq_build_sha.restype = ctypes.c_char_p
+            sha = lib.ssq_build_sha().decode()
+        except Exception as e:
+            sha = 'unknown (%r)' % (e,)
+        json.dump({"git_sha": sha, "bytes_per_transform": total,
                    "per_kernel": {k[:120]: {"read": rd, "write": wr} for k, rd, wr in rows[:20]},
                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; "
                              "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, summed over "
