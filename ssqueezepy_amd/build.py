@@ -25,6 +25,9 @@ SOURCES = [
     ('ssq_cwt.hip', ['-ffp-contract=off']),
     ('ssq_cwt_blocks.hip', ['-ffp-contract=off']),
     ('ssq_cwt_tiles.hip', ['-ffp-contract=off']),
+    ('ssq_tile_fft.hip', ['-ffp-contract=off']),
+    ('ssq_tile_f64.hip', ['-ffp-contract=off']),
+    ('ssq_tile_ordered.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
     ('ssq_inverse.hip', ['-ffp-contract=off']),
     ('ssq_ridge.hip', ['-ffp-contract=off']),
@@ -81,7 +84,7 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC)
                if f.endswith(('.h', '.inl'))]
     headers.append(os.path.join(HERE, '..', 'include', 'ssq_hip.h'))
-    objs, rebuilt = [], False
+    objs, rebuilt, jobs = [], False, []
     for src, extra in SOURCES:
         spath = os.path.join(CSRC, src)
         if not os.path.isfile(spath):
@@ -93,9 +96,14 @@ def build(force=False, verbose=True):
             cmd = [HIPCC] + COMMON + extra + ['-c', spath, '-o', opath]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
             rebuilt = True
         objs.append(opath)
+    if jobs:
+        # the translation units are independent: compile the stale ones side by side
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(subprocess.check_call, jobs))
     stamp, restamped = _stamp(objdir, verbose)
     if stamp:
         objs.append(stamp)

@@ -47,7 +47,20 @@ struct AnalyticFft {
     int run(const void* xh_all, void* xa, int64_t batch, hipStream_t stream);
 };
 
-int tile_rows_per_step();               // TILE_G of ssq_cwt_tiles.hip
+// ---- geometry both tile kernels and the plan agree on
+constexpr int TILE_COLS = 64;           // ordered kernel: columns per tile (one per lane)
+#ifndef SSQ_TILE_G
+#define SSQ_TILE_G 4
+#endif
+constexpr int TILE_G = SSQ_TILE_G;      // rows per step of the host's tables (_tiles.py: RSUB)
+constexpr int TILE2_NW = 16;            // default kernel: wavefronts per workgroup (one workgroup per CU)
+// LDS of a workgroup: the ordered kernel's (na + 1) x 64 float32 pairs + ticket words; the default kernel's
+// (na + 1) x cols float64 pairs
+__host__ __device__ inline size_t tile_lds_bytes(int64_t na) { return (size_t)(na + 1) * TILE_COLS * 8 + 16; }
+__host__ __device__ inline size_t tile2_lds_bytes(int64_t na, int cols) { return (size_t)(na + 1) * cols * 16; }
+bool tile_ordered();                    // SSQ_TILE_ORDER=ordered in the environment (read at every call)
+
+int tile_rows_per_step();               // TILE_G
 
 struct TilePlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0;
@@ -62,7 +75,7 @@ struct TilePlan {
     void* U = nullptr;                      // group x u_total complex64
     unsigned long long* counters = nullptr; // [0]: tiles the kernel has finished since plan creation
     // tile2_kernel (float64 tile, unordered adds): packed item records, [steps * 4] int4; the
-    // wavefronts' blocks of items for 12 and 16 wavefronts ([12 + 16][4]); columns per tile
+    // wavefronts' blocks of items ([TILE2_NW][4]); columns per tile
     void* items2 = nullptr; int32_t* wave_first2 = nullptr;
     int n_items2 = 0, cols2 = 32;
     int lgr_max2 = 0;                       // largest decimation (log2) among the interpolated classes
@@ -99,6 +112,11 @@ struct TilePlan {
     // (kdump: diagnostic -- the bin of every point as the kernel consumed it, (batch signal, row, column), or null)
     int run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
             const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump = nullptr);
+    // ... by the default kernel (ssq_tile_f64.hip) / by the ordered one (ssq_tile_ordered.hip)
+    int run_f64(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
+                const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump);
+    int run_ordered(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
+                    const void* cst, float cst0, const SsqParams& sp, hipStream_t stream);
     // tiles finished by the tile kernel so far (synchronises `stream`): what actually ran
     int64_t tiles_done(hipStream_t stream);
 };

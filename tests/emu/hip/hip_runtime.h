@@ -341,7 +341,7 @@ inline float atomicAdd(float* p, float v) { float old = *p; *p = old + v; return
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 // memory fences: the work-items of a workgroup are fibers of one OS thread
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(order, scope, ...) ((void)0)
 // v_sin_f32 / v_cos_f32: argument in revolutions
 inline float emu_sinf_rev(float x) { return (float)sin(6.283185307179586 * (double)x); }
 inline float emu_cosf_rev(float x) { return (float)cos(6.283185307179586 * (double)x); }
