@@ -31,6 +31,7 @@ struct BlockPlan {
     int64_t M = 0, N = 0, n1 = 0, na = 0, max_batch = 1;
     int dtype = SSQ_F32;             // tables, spectra and kernels in this precision
     int group = 1;                   // signals per launch (kernels take them as a grid dimension)
+    int ncu = 256;                   // CUs of the plan's device (BlockPlan::create asks the runtime)
     int nc = 0;
     std::vector<BlockClassDev> hcls;
     BlockClassDev* classes = nullptr;

@@ -756,6 +756,11 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
         }
     }
     n_generic = d.n_generic;
+    {   // the CU count of the device the plan lives on (the multi-class launch asks how full a launch is)
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ncu = pr.multiProcessorCount;
+    }
     return 0;
 }
 
@@ -856,11 +861,6 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
             const int64_t n = limit ? limit[s] : n_items[s];
             total += n; biggest = std::max(biggest, n * nsig); used += n > 0;
         }
-        static const int ncu = [] {    // (one device per process)
-            int dev = 0; hipDeviceProp_t pr;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 256;
-            return pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-        }();
         const bool multi = force >= 0 ? force != 0 : (used > 1 && biggest <= 2 * (int64_t)ncu);
         if (multi && total > 0) {
             BlockMultiArgs Mx;

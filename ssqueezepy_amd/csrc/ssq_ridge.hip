@@ -115,7 +115,10 @@ __global__ __launch_bounds__(64) void ridge_clear_kernel(T* __restrict__ en, con
     en += (int64_t)blockIdx.y * na * n; ridge += (int64_t)blockIdx.y * n;
     if (ridge_e) ridge_e += (int64_t)blockIdx.y * n;
     const int64_t r = ridge[j];
-    if (r < 0 || r >= na) return;          // (the reference raises IndexError)
+    if (r < 0 || r >= na) {                // (the reference raises IndexError; the tracking passes never produce it)
+        if (ridge_e) ridge_e[j] = (T)0;    // ... but the caller's buffer is reused across ridges: never leave it stale
+        return;
+    }
     if (ridge_e) ridge_e[j] = en[r * n + j];
     // energy[int(r - bw):int(r + bw), j] = 0 with Python's slice rules
     int64_t lo = (int64_t)trunc((double)r - bw), hi = (int64_t)trunc((double)r + bw);

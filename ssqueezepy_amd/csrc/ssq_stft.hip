@@ -68,6 +68,10 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
     // the frames' Tx: a real and an imaginary plane of (L/2 + 1) x G float64 cells
     constexpr int CELLS = REASSIGN ? (L / 2 + 1) * G : 1;
     __shared__ double txt[2 * CELLS];
+    // (the REASSIGN builds hold the FFT buffer and the frames' float64 Tx planes side by side: a gfx950 workgroup may
+    // use 160 KB of LDS, two of these workgroups share a CU)
+    static_assert(sizeof(c32) * D_POINTS + sizeof(double) * 2 * CELLS <= 80 * 1024,
+                  "stft_fused_kernel: static LDS beyond half of a gfx950 CU's 160 KB");
     if constexpr (REASSIGN) {
         for (int i = threadIdx.x; i < 2 * CELLS; i += NT) txt[i] = 0.0;     // (barriers follow before its first use)
     }
@@ -356,7 +360,8 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             // (measured, C3: one signal 68 us against 72 with the separate pass; 512 signals 2.75 ms against
             // 2.35 -- a workgroup's Tx goes out as G * 8-byte pieces and the tile halves the occupancy, so
             // the fused sums serve the calls that do not fill the GPU; SSQ_STFT_FUSED_TX=0/1 forces)
-            static const int force = getenv("SSQ_STFT_FUSED_TX") ? atoi(getenv("SSQ_STFT_FUSED_TX")) : -1;
+            const char* fe = getenv("SSQ_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
+            const int force = fe ? atoi(fe) : -1;
             fused_tx = !reassign_ordered() && rows == n_fft / 2 + 1 &&
                        (force >= 0 ? force != 0 : batch * n_hops <= 4096);
             if (!fused_tx && !pl->kidx)

@@ -19,6 +19,10 @@ from .configs import EPS32, EPS64
 
 __all__ = ['extract_ridges']
 
+# transforms per launch: the batch entry points put the transform index on a grid dimension (blockIdx.y / x),
+# which holds at most 65535 workgroups; longer batches are walked in chunks of this size
+MAX_BATCH_PER_LAUNCH = 32768
+
 
 def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
                    get_params=False, parallel=True):
@@ -59,6 +63,12 @@ def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
     # over all transforms in one launch -- a tracking pass is one workgroup's walk over time, so a batch
     # costs about what one transform does
     batched = Tf.ndim == 3
+    if batched and Tf.shape[0] > MAX_BATCH_PER_LAUNCH:
+        parts = [extract_ridges(Tf[b0:b0 + MAX_BATCH_PER_LAUNCH], scales, penalty, n_ridges, bw, transform,
+                                get_params, parallel)
+                 for b0 in range(0, Tf.shape[0], MAX_BATCH_PER_LAUNCH)]
+        join = (lambda xs: torch.cat(list(xs))) if as_tensor else (lambda xs: np.concatenate(list(xs)))
+        return tuple(join(p[k] for p in parts) for k in range(3)) if get_params else join(parts)
     if not batched:
         Tf = Tf[None]
     Tf = Tf.contiguous()
