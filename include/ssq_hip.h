@@ -393,6 +393,12 @@ int  ssq_stft_plan_set_ssq(ssq_stft_plan* plan, const void* Sfs, int grid,
                            int flipud, double gamma);
 /* rows = n_fft/2 + 1, n_hops = (n - 1) / hop_len + 1 -> query */
 int  ssq_stft_plan_shape(const ssq_stft_plan* plan, int64_t* rows, int64_t* n_hops);
+/* name of the route the plan takes for the framing + window + FFT stage: "fused" (float32, n_fft a power of
+ * two in [128, 2048]: one launch, LDS transform), "fused-mixed-radix" (float32, any other n_fft whose prime
+ * factors are <= 31 and that fits the LDS: one launch, mixed-radix LDS transform -- the reference's benchmark
+ * shape n_fft = 598, examples/benchmarks.py:78-79), "rocfft" (everything else, float64: framing kernel + batched
+ * rocFFT with strided output). Tests assert on it. */
+const char* ssq_stft_plan_algo(const ssq_stft_plan* plan);
 /* x: (batch, n). Sx, dSx, Tx: (batch, rows, n_hops) complex; w: real. */
 int  ssq_stft_execute(ssq_stft_plan* plan, const void* x, int64_t batch, void* Sx,
                       void* dSx, void* Tx, void* w, void* stream);

@@ -129,6 +129,7 @@ _PROTOS = {
     'ssq_stft_plan_set_ssq': (c_int, [c_void_p, c_void_p, c_int, POINTER(c_double),
                                       c_void_p, c_int, c_int, c_double]),
     'ssq_stft_plan_shape': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64)]),
+    'ssq_stft_plan_algo': (c_char_p, [c_void_p]),
     'ssq_stft_execute': (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
 }

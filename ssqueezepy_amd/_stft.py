@@ -180,6 +180,11 @@ class StftPlan():
                 pass
             self._h = None
 
+    @property
+    def algo(self):
+        """route of the framing + window + FFT stage: 'fused', 'fused-mixed-radix' or 'rocfft'"""
+        return self.lib.ssq_stft_plan_algo(self._h).decode()
+
     def set_ssq(self, Sfs, grid, params, const, flipud, gamma):
         Sfs = np.ascontiguousarray(np.asarray(Sfs, dtype=self.dtype))
         const = np.asarray(const)

@@ -29,6 +29,7 @@ SOURCES = [
     ('ssq_tile_f64.hip', ['-ffp-contract=off']),
     ('ssq_tile_ordered.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
+    ('ssq_stft_generic.hip', ['-ffp-contract=off']),
     ('ssq_inverse.hip', ['-ffp-contract=off']),
     ('ssq_ridge.hip', ['-ffp-contract=off']),
     ('ssq_fft.hip', []),

@@ -1,0 +1,33 @@
+// ssq_stft.h -- what the STFT translation units share: the fused kernels' argument block and the entry points of
+// the mixed-radix kernel (ssq_stft_generic.hip) the plan (ssq_stft.hip) calls.
+#pragma once
+#include "ssq_common.h"
+#include "ssq_ldsfft.h"
+
+namespace ssq {
+
+struct StftFusedArgs {
+    const float* xp; const float* window; const float* diff_window; const c32* ftw;
+    float2* Sx; float2* dSx;            // dSx null: derivative not stored
+    // fused ssq_stft: the bin of every point (2 bytes) instead of dSx (8 bytes)
+    unsigned short* kidx; const float* Sfs; double gamma;
+    int64_t padlen, n_hops, rows;
+    int hop, s20, s21, modulated;
+    int xcd;                            // grid.x padded to a multiple of 8, remapped per XCD
+    // REASSIGN instantiation: Tx of the workgroup's frames is summed in LDS (float64, unordered adds -- see
+    // accumulate_f64_kernel) and written here; neither the bin map nor a second pass over Sx is needed
+    float2* Tx; const void* cst; int cst_uniform;
+};
+
+// ---- mixed-radix fused kernel (any n_fft with prime factors <= 31, float32)
+constexpr int GEN_NT = 256;
+constexpr int GEN_MAX_PASSES = 10;
+constexpr int GEN_MAX_PPT = 40;                     // complex points a work-item holds in a pass (n_fft * G / 256 <= 39)
+constexpr int GEN_LDS_BYTES = 78 * 1024;            // n_fft * G * 8 bytes at most: two workgroups per CU
+// factors of n (16s, 8s, 4s, a 2, then the odd primes up to 31) and the frames per workgroup; false when n has a
+// larger prime factor, too many factors, or does not fit the LDS
+bool stft_generic_plan(int64_t n, int* radix, int* npass, int* G);
+int launch_stft_generic(const StftFusedArgs& A, const SsqParams& sp, const c32* tw, int n, const int* radix,
+                        int npass, int G, int64_t batch, hipStream_t stream);
+
+}  // namespace ssq

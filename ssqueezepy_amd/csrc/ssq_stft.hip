@@ -16,6 +16,7 @@
 #include "ssq_common.h"
 #include "ssq_fft.h"
 #include "ssq_ldsfft.h"
+#include "ssq_stft.h"
 #include <vector>
 #include <cmath>
 #include <algorithm>
@@ -49,18 +50,6 @@ __global__ __launch_bounds__(256) void frame_window_kernel(
 // taken as conj(IFFT(conj(.))) with the inverse LDS FFT of ssq_ldsfft.h: input
 // a - ib, output Z' with FFT(a + ib) = conj(Z'). With A = FFT(a), B = FFT(b) Hermitian,
 //   A[f] = (Z[f] + conj(Z[L-f])) / 2,   B[f] = (Z[f] - conj(Z[L-f])) / (2i),  f <= L/2.
-struct StftFusedArgs {
-    const float* xp; const float* window; const float* diff_window; const c32* ftw;
-    float2* Sx; float2* dSx;            // dSx null: derivative not stored
-    // fused ssq_stft: the bin of every point (2 bytes) instead of dSx (8 bytes)
-    unsigned short* kidx; const float* Sfs; double gamma;
-    int64_t padlen, n_hops, rows;
-    int hop, s20, s21, modulated;
-    int xcd;                            // grid.x padded to a multiple of 8, remapped per XCD
-    // REASSIGN instantiation: Tx of the workgroup's frames is summed in LDS (float64, unordered adds -- see
-    // accumulate_f64_kernel) and written here; neither the bin map nor a second pass over Sx is needed
-    float2* Tx; const void* cst; int cst_uniform;
-};
 
 template <int L, int G, int R1, int R2, int R3, bool REASSIGN, bool CST64>
 __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
@@ -181,6 +170,7 @@ static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_
     return 0;
 }
 
+
 // R2C with transposed (strided) output: transform c writes bin f at out[f*n_hops + c]
 struct StridedR2C {
     rocfft_plan plan = nullptr; rocfft_execution_info info = nullptr;
@@ -234,6 +224,8 @@ struct ssq_stft_plan {
     void* xp = nullptr; void* frames = nullptr; void* dframes = nullptr; void* dSx_ws = nullptr;
     StridedR2C fft;
     bool fused = false; void* ftw = nullptr;      // fused float32 path (power-of-two n_fft)
+    // fused float32 path for the other sizes (prime factors <= 31): mixed-radix LDS transform
+    bool generic_fused = false; int gen_radix[GEN_MAX_PASSES] = {0}; int gen_npass = 0, gen_G = 0;
     unsigned short* kidx = nullptr;               // bin map of the fused ssq_stft form
     bool have_ssq = false; SsqParams sp{}; void* cst = nullptr; void* Sfs = nullptr;   // current entries of
     WeightVersions weights, freqs;                                                      // these
@@ -288,6 +280,16 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
         if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
         SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         pl->fused = true;
+    } else if (d.dtype == SSQ_F32 && !getenv("SSQ_STFT_GENERIC")
+               && stft_generic_plan(d.n_fft, pl->gen_radix, &pl->gen_npass, &pl->gen_G)) {
+        std::vector<float> tw((size_t)2 * d.n_fft);
+        for (int64_t q = 0; q < d.n_fft; ++q) {
+            double ang = 2.0 * 3.14159265358979323846 * (double)q / (double)d.n_fft;
+            tw[2 * q] = (float)cos(ang); tw[2 * q + 1] = (float)sin(ang);
+        }
+        if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
+        SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        pl->generic_fused = true;
     }
     pl->d.window = nullptr; pl->d.diff_window = nullptr;
     *out = pl;
@@ -330,6 +332,10 @@ int ssq_stft_plan_set_ssq(ssq_stft_plan* pl, const void* Sfs, int grid, const do
     return 0;
 }
 
+const char* ssq_stft_plan_algo(const ssq_stft_plan* pl) {
+    return !pl ? "" : pl->fused ? "fused" : pl->generic_fused ? "fused-mixed-radix" : "rocfft";
+}
+
 int ssq_stft_plan_shape(const ssq_stft_plan* pl, int64_t* rows, int64_t* n_hops) {
     SSQ_REQUIRE(pl, "ssq_stft_plan_shape: null plan");
     if (rows) *rows = pl->rows;
@@ -355,14 +361,14 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     // ... and, unless the ordered sums are asked for (SSQ_TILE_ORDER=ordered), sums Tx itself
     bool use_kidx = false, fused_tx = false;
     if constexpr (sizeof(T) == 4) {
-        if (pl->fused && Tx && !w && !dSx && rows < 65535) {
+        if ((pl->fused || pl->generic_fused) && Tx && !w && !dSx && rows < 65535) {
             use_kidx = true;
             // (measured, C3: one signal 68 us against 72 with the separate pass; 512 signals 2.75 ms against
             // 2.35 -- a workgroup's Tx goes out as G * 8-byte pieces and the tile halves the occupancy, so
             // the fused sums serve the calls that do not fill the GPU; SSQ_STFT_FUSED_TX=0/1 forces)
             const char* fe = getenv("SSQ_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
             const int force = fe ? atoi(fe) : -1;
-            fused_tx = !reassign_ordered() && rows == n_fft / 2 + 1 &&
+            fused_tx = pl->fused && !reassign_ordered() && rows == n_fft / 2 + 1 &&
                        (force >= 0 ? force != 0 : batch * n_hops <= 4096);
             if (!fused_tx && !pl->kidx)
                 SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
@@ -388,7 +394,22 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             if (rc) return rc;
         }
     }
-    for (int64_t b = 0; b < (pl->fused ? 0 : batch); ++b) {
+    if constexpr (sizeof(T) == 4) {
+        if (pl->generic_fused) {
+            StftFusedArgs A;
+            A.xp = (const float*)pl->xp; A.window = (const float*)pl->window;
+            A.diff_window = (const float*)pl->diff_window; A.ftw = nullptr;
+            A.Sx = (float2*)Sx; A.dSx = (deriv && !use_kidx) ? (float2*)dS : nullptr;
+            A.kidx = use_kidx ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
+            A.Tx = nullptr; A.cst = nullptr; A.cst_uniform = 0;
+            A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
+            A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated; A.xcd = 0;
+            rc = launch_stft_generic(A, pl->sp, (const c32*)pl->ftw, (int)n_fft, pl->gen_radix, pl->gen_npass, pl->gen_G,
+                                     batch, stream);
+            if (rc) return rc;
+        }
+    }
+    for (int64_t b = 0; b < ((pl->fused || pl->generic_fused) ? 0 : batch); ++b) {
         const T* xp = (const T*)pl->xp + (size_t)b * pl->padlen;
         int64_t total = n_fft * n_hops;
         unsigned g = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);

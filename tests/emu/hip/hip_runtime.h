@@ -351,6 +351,7 @@ inline float emu_cosf_rev(float x) { return (float)cos(6.283185307179586 * (doub
 inline float __log2f(float x) { return log2f(x); }          // v_log_f32 (1 ulp)
 inline int __ffs(int x) { return __builtin_ffs(x); }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 inline int __double2loint(double d) { long long q; memcpy(&q, &d, 8); return (int)(q & 0xffffffffll); }

@@ -105,21 +105,25 @@ def test_stft_odd_sizes_and_windows(S, orc, dtype):
     assert np.array_equal(Tf[2], Tn[2][::-1])
 
 
-@pytest.mark.parametrize('n_fft', [128, 256, 512, 1024, 2048])
+@pytest.mark.parametrize('n_fft', [128, 256, 512, 1024, 2048, 598, 1001, 899, 323, 210, 1600, 24, 729])
 def test_fused_stft_every_size(S, orc, n_fft):
-    """The fused framing + window + packed-pair FFT kernel (float32, power-of-two n_fft)
-    for each of its five FFT configurations: against the oracle (reference tolerance 1e-5),
-    against this engine's rocFFT path (env switch), modulated and not, batched, hops that
-    leave a partial last workgroup; Tx exact against the oracle reassignment of the
-    device's own Sx, dSx."""
+    """The fused framing + window + packed-pair FFT kernels (float32): the power-of-two one for each of its five
+    FFT configurations, and the mixed-radix one (round 5) for window lengths that cover every radix it has --
+    598 = 2 x 13 x 23 (the reference's published benchmark shape, examples/benchmarks.py:78-79), 1001 = 7 x 11 x 13
+    (odd), 899 = 29 x 31, 323 = 17 x 19, 210 = 2 x 3 x 5 x 7, 1600 = 16 x 4 x 5 x 5, 24 = 8 x 3, 729 = 3^6 (six passes). Against the oracle (reference tolerance 1e-5), against this engine's rocFFT
+    path (env switch), modulated and not, batched, hops that leave a partial last workgroup; Tx exact against the
+    oracle reassignment of the device's own Sx, dSx."""
     import os, subprocess, sys, json
     from ssqueezepy_amd import _stft
     N = 6000 + n_fft
+    pow2 = n_fft & (n_fft - 1) == 0
     for hop, mod in ((n_fft // 4, True), (37, False)):
         x = two_chirps(N, seed=n_fft + hop)
         _stft._PLAN_CACHE.clear()
         Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, modulated=mod,
                                           dtype='float32', get_dWx=True, astensor=False)
+        plan = next(iter(_stft._PLAN_CACHE.values()))
+        assert plan.algo == ('fused' if pow2 else 'fused-mixed-radix'), plan.algo       # what was planned to run
         ro = oracle_ssq_stft(orc, x, 'float32', n_fft=n_fft, hop_len=hop, modulated=mod)
         assert Sx.shape == ro['Sx'].shape
         assert relmax(Sx, ro['Sx']) <= 1e-5 and relmax(dSx, ro['dSx']) <= 1e-5, (hop, mod)
