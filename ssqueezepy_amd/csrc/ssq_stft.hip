@@ -271,7 +271,9 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
     rc = pl->fft.create(d.dtype, (size_t)d.n_fft, (size_t)pl->n_hops);
     if (rc) { ssq_stft_plan_destroy(pl); return rc; }
     const bool pow2 = (d.n_fft & (d.n_fft - 1)) == 0;
-    if (d.dtype == SSQ_F32 && pow2 && d.n_fft >= 128 && d.n_fft <= 2048 && !getenv("SSQ_STFT_GENERIC")) {
+    // (SSQ_STFT_MIXED=1: the mixed-radix kernel for the powers of two as well -- A/B aid)
+    const bool prefer_mixed = getenv("SSQ_STFT_MIXED") && atoi(getenv("SSQ_STFT_MIXED")) != 0;
+    if (d.dtype == SSQ_F32 && pow2 && d.n_fft >= 128 && d.n_fft <= 2048 && !getenv("SSQ_STFT_GENERIC") && !prefer_mixed) {
         std::vector<float> tw((size_t)2 * d.n_fft);
         for (int64_t q = 0; q < d.n_fft; ++q) {
             double ang = 2.0 * 3.14159265358979323846 * (double)q / (double)d.n_fft;

@@ -12,6 +12,22 @@ import ssqueezepy_amd as S
 from conftest import two_chirps
 
 
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def roofline(bytes_alg, ms, what):
+    """the block bench.py prints for config 2, for another BASELINE configuration: algorithmic bytes (SURVEY 8d:
+    inputs read once + returned outputs written once) over the HIP-event time of the whole call"""
+    gbs = bytes_alg / ms / 1e6
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "traffic": None, "bytes_alg": int(bytes_alg), "scope": what}
+
+
+def build_sha():
+    from ssqueezepy_amd import _lib
+    return _lib.load(build_if_missing=False).ssq_build_sha().decode()
+
+
 def timeit(fn, n):
     for _ in range(2):
         out = fn()
@@ -34,7 +50,8 @@ def main():
         x = torch.as_tensor(two_chirps(N, 0), dtype=torch.float32, device=dev)
         ms, out = timeit(lambda: S.cwt(x, wav, scales=scales), 50)
         print(json.dumps({"config": "C1 cwt N=10k 300 scales f32", "ms": ms,
-                          "transforms_per_s": 1e3 / ms}))
+                          "transforms_per_s": 1e3 / ms, "build_sha": build_sha(),
+                          "roofline": roofline(N * 4 + na * N * 8, ms, "cwt: x in, Wx out; one call, launch-bound")}))
     if 'c3' in which:
         N = 160000
         for B in (1, 64, 512):
@@ -46,7 +63,8 @@ def main():
             bytes_alg = B * (N * 4 + 2 * Sx.shape[-2] * Sx.shape[-1] * 8)
             print(json.dumps({"config": "C3 ssq_stft N=160k n_fft=1024 hop=256 f32", "batch": B,
                               "ms": ms, "transforms_per_s": B * 1e3 / ms,
-                              "shape": list(Sx.shape), "GBps_alg": bytes_alg / ms / 1e6}))
+                              "shape": list(Sx.shape), "GBps_alg": bytes_alg / ms / 1e6, "build_sha": build_sha(),
+                              "roofline": roofline(bytes_alg, ms, "ssq_stft: x in, Tx + Sx out; %d signals per call" % B)}))
     if 'c5' in which:
         N, na = 1048576, 512
         wav = S.Wavelet(('gmw', {'dtype': 'float64'}))
@@ -62,7 +80,8 @@ def main():
         bytes_alg = N * 8 + 2 * na * N * 16
         print(json.dumps({"config": "C5 ssq_cwt N=1048576 512 scales f64", "ms": ms,
                           "transforms_per_s": 1e3 / ms, "colsum_rel_err": err,
-                          "GBps_alg": bytes_alg / ms / 1e6,
+                          "GBps_alg": bytes_alg / ms / 1e6, "build_sha": build_sha(),
+                          "roofline": roofline(bytes_alg, ms, "ssq_cwt float64: x in, Tx + Wx out; one signal per call"),
                           "setup_s": time.time() - t0}))
         assert err < 1e-11, err
 
