@@ -107,7 +107,11 @@ def cpu_baseline(N, na, seconds_budget=25.0):
                       "float32; scipy.fft workers=%d + OpenMP loop nests on %d cores; wavelet "
                       "bank cached as in examples/benchmarks.py). kind 'port': the oracle's "
                       "restatement of the reference's CPU algorithm -- ssqueezepy itself "
-                      "(numba, SSQ_PARALLEL=1) is not installable on the GPU box"
+                      "(numba, SSQ_PARALLEL=1) is not installable on the GPU box. Calibration "
+                      "against the reference itself (build container, 8 cores, same input: "
+                      "tools/r5/cpu_calibrate.py, profiles/r5_cpu_calibration.json): ssqueezepy's "
+                      "own ssq_cwt with its loop nests bound to the OpenMP restatement 0.63 "
+                      "transforms/s, this port 0.48 -- the port runs at 0.76 of the reference"
                       % (runs, N, na, fft_workers, cores)}
 
 
