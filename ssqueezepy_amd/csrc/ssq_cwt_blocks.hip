@@ -861,7 +861,11 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
             const int64_t n = limit ? limit[s] : n_items[s];
             total += n; biggest = std::max(biggest, n * nsig); used += n > 0;
         }
-        const bool multi = force >= 0 ? force != 0 : (used > 1 && biggest <= 2 * (int64_t)ncu);
+        // (... or when the whole call is only a few rounds of workgroups -- three of them share a CU: a single signal
+        // at config 2 is 1512 + 1344 workgroups, two rounds per class launched one after the other, 3.7 rounds
+        // together: block stage 107 -> 89 us, round 5)
+        const bool multi = force >= 0 ? force != 0
+                                      : (used > 1 && (biggest <= 2 * (int64_t)ncu || total * nsig <= 18 * (int64_t)ncu));
         if (multi && total > 0) {
             BlockMultiArgs Mx;
             Mx.A = A; Mx.A.items = nullptr; Mx.A.n_items = total; Mx.A.ftw = nullptr;
