@@ -66,7 +66,9 @@ def main(n_cases=30, seed=0):
                   'eW=%.1e eD=%.1e' % (eW, eD), 'OK' if ok else 'MISMATCH')
         else:
             N = int(rng.integers(300, 20000))
-            n_fft = int(rng.choice([64, 100, 128, 256, 512, 1000, 1024]))
+            # (powers of two: the fused kernel; any other length: the mixed-radix fused kernel when its prime factors
+            # are <= 31, else framing + rocFFT)
+            n_fft = int(rng.choice([64, 100, 128, 256, 512, 1000, 1024])) if rng.random() < 0.4 else int(rng.integers(16, 1500))
             n_fft = min(n_fft, N // 2)
             hop = int(rng.integers(1, max(2, n_fft // 2)))
             mod = bool(rng.random() < 0.7)
