@@ -63,6 +63,7 @@ struct Tile2Args {
     int64_t N, na;
     int n_items, n1, mmask, lgM, sig0, nsig, group;
     int carry;                                       // the walk b, b + G, ... runs through the signals' boundaries
+    int xcd;                                         // first tiles permuted per XCD (see the kernel)
     float inv_m, theta_scale, cst0;
     unsigned long long* counters;
     double gamma;
@@ -105,8 +106,14 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // Workgroup b walks tiles b, b + G, ... -- of each signal (then a signal's last round is short for the
     // workgroups past ntx mod G, launch after launch: 304 against 320 tiles at config 2), or, A.carry, of the
     // signals laid end to end (the launcher allows it when the lanes' weights survive the boundary).
-    const int per_sig = (int)blockIdx.x < ntx ? (ntx - (int)blockIdx.x + G - 1) / G : 0;
-    const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - (int)blockIdx.x + G - 1) / G)
+    // Workgroup b runs on XCD b mod 8 (each XCD has its own L2). The workgroup's FIRST tile is permuted so that the 32
+    // workgroups of an XCD walk 32 ADJACENT tiles at a time: neighbouring tiles read overlapping windows of the decimated
+    // samples (8 taps of halo; for R >= 64 the very same samples), which then meet in one L2 instead of being fetched
+    // from HBM once per tile. The stride between a workgroup's tiles stays G, so the lanes' weight phase is kept.
+    // (SSQ_TILE2_XCD=0 in the launcher's environment: the identity.)
+    const int bid = (A.xcd && (G & 7) == 0) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int per_sig = bid < ntx ? (ntx - bid + G - 1) / G : 0;
+    const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - bid + G - 1) / G)
                             : per_sig * A.nsig;                // tiles of this workgroup
     const auto* waves = SSQ_CONST_PTR(int4, A.waves);
     const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
@@ -185,11 +192,11 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     };
 
     if (ni <= 0) {                                             // more wavefronts than items: write-outs only
-        int tx = (int)blockIdx.x, sg = 0;
+        int tx = bid, sg = 0;
         for (int j = 0; j < ntl; ++j) {
             finish_tile(tx, sg);
             tx += G;
-            if (tx >= ntx) { tx = A.carry ? tx - ntx : (int)blockIdx.x; ++sg; }
+            if (tx >= ntx) { tx = A.carry ? tx - ntx : bid; ++sg; }
         }
         return;
     }
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // position records copied around per item). Past the last tile the loads' cursor stays on it (all
     // loads unconditional, see the note in tile_kernel: what they fetch there is valid and unused).
     struct Pos { int nabs0, sg; int64_t off8; };
-    const int nabs_step = G * COLS, nabs_first = A.n1 + (int)blockIdx.x * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
+    const int nabs_step = G * COLS, nabs_first = A.n1 + bid * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
     const int64_t off8_step = (int64_t)G * COLS * 8;
     // (a signal's end: back to the workgroup's first tile, or -- carry -- on by the same stride into the next signal)
     const int64_t off8_wrap = A.carry ? ((int64_t)na * N + (int64_t)(G - ntx) * COLS) * 8
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     ssq_f2 wta[TILE_W], wtb[TILE_W];
     auto load_wt = [&](ssq_f2 (&wt)[TILE_W], int it, int woff) {
         const int lgR = (items[it][0] >> 13) & 31;
-        const int nabs = A.n1 + (int)blockIdx.x * COLS + c;    // (every tile of this workgroup: the same n mod R)
+        const int nabs = A.n1 + bid * COLS + c;                // (every tile of this workgroup: the same n mod R)
         const int R = 1 << lgR;
         const float4* wp = A.wtab + (int64_t)woff * 4 + (nabs & (R - 1));
 #pragma unroll
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     constexpr bool ANY0 = decltype(any0)::value;
     Data D[3];
     Pos tc, tl;                                                // the tile of the arithmetic's cursor, of the loads'
-    tc.nabs0 = nabs_first; tc.sg = 0; tc.off8 = (int64_t)blockIdx.x * COLS * 8;
+    tc.nabs0 = nabs_first; tc.sg = 0; tc.off8 = (int64_t)bid * COLS * 8;
     tl = tc;
     if (total <= 0) return;
     int it_c = i0, it_l = i0;
@@ -474,6 +481,8 @@ static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams
     const bool carry_on = !(ce && atoi(ce) == 0);
     Tile2Args B = A;
     B.carry = (carry_on && ntx > G && ntx % q == 0) ? 1 : 0;
+    const char* xe = getenv("SSQ_TILE2_XCD");                 // (read per launch)
+    B.xcd = !(xe && atoi(xe) == 0) && G >= 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;

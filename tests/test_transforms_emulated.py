@@ -143,21 +143,26 @@ def test_block_classes_in_one_launch_emulated(S, monkeypatch):
 def test_tile_walk_through_signal_boundaries_emulated(S, monkeypatch):
     """tile2_kernel's workgroups walk tiles b, b + G, ... of the signals laid end to end (no short last round per
     signal) when the lanes' resident weights survive the boundary: same results as the walk that restarts at every
-    signal (SSQ_TILE2_CARRY=0); 6 and 4 workgroups over 80 / 126 tiles x 3 signals, so that the boundary shifts."""
+    signal (SSQ_TILE2_CARRY=0); 6 and 4 workgroups over 80 / 126 tiles x 3 signals, so that the boundary shifts.
+    (Round 5: with 16 workgroups and more the workgroups' first tiles are permuted per XCD -- workgroup b starts at tile
+    (b mod 8) G / 8 + b / 8 -- so that the workgroups of one XCD walk adjacent tiles; SSQ_TILE2_XCD=0 is the identity:
+    same results, both walks.)"""
     from conftest import two_chirps
     from ssqueezepy_amd import _cwt
-    for grid, N in (('6', 2560), ('4', 4003)):
+    for grid, N in (('6', 2560), ('4', 4003), ('16', 2560), ('24', 4003)):
         monkeypatch.setenv('SSQ_TILE_GRID', grid)
         xb = np.stack([two_chirps(N, seed=s) for s in range(3)])
         out = {}
-        for carry in ('0', '1'):
+        for carry, xcd in (('0', '1'), ('1', '1'), ('0', '0'), ('1', '0')):
             monkeypatch.setenv('SSQ_TILE2_CARRY', carry)
+            monkeypatch.setenv('SSQ_TILE2_XCD', xcd)
             _cwt.clear_plan_cache()
             Tx, Wx, *_ = S.ssq_cwt(xb, S.Wavelet(), scales='log', nv=16, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
             assert plan.tile_rows > 0 and plan.tiles_done() == 3 * plan.tiles_per_signal(N)
-            out[carry] = (Tx, Wx)
-        assert np.array_equal(out['0'][1], out['1'][1]) and np.array_equal(out['0'][0], out['1'][0])
+            out[carry + xcd] = (Tx, Wx)
+        for k in ('11', '00', '10'):
+            assert np.array_equal(out['01'][1], out[k][1]) and np.array_equal(out['01'][0], out[k][0]), (grid, k)
     _cwt.clear_plan_cache()
 
 
