@@ -190,7 +190,11 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     // one extra ticket per tile, during which the finished tile is written out.
     const int ntx = (int)((N + TILE_COLS - 1) / TILE_COLS);
     const int ntot = ntx * A.nsig;
-    const int ntl = ntot > (int)blockIdx.x ? (ntot - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    // (first tiles permuted per XCD -- workgroup b runs on XCD b mod 8 -- so that the workgroups of one XCD walk adjacent
+    // tiles and their sample windows meet in one L2, as in tile2_kernel: ssq_tile_f64.hip)
+    const int G_ = (int)gridDim.x;
+    const int bid = ((G_ & 7) == 0 && G_ >= 16) ? ((int)blockIdx.x & 7) * (G_ >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    const int ntl = ntot > bid ? (ntot - bid + G_ - 1) / G_ : 0;
     const int nst = A.nsteps;
     const int total = nst * ntl;
     struct Pos { int S, itl, st, tx, sg; };                   // a step: sequence number, tile, step in tile, tile position
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(64 * NW) void tile_kernel(TileArgs A, SsqParams sp)
     };
 
     Pos pc; pc.S = 0; pc.itl = 0; pc.st = 0;
-    pc.sg = (int)blockIdx.x / ntx; pc.tx = (int)blockIdx.x - pc.sg * ntx;
+    pc.sg = bid / ntx; pc.tx = bid - pc.sg * ntx;
     int w_itl = 0, w_tx = pc.tx, w_sg = pc.sg;                // next tile to write out
     advance(pc, wv);                          // the step computed
     auto write_outs_before = [&](int itl) {   // every finished tile before tile `itl`, in order
