@@ -53,6 +53,7 @@ struct BlockPlan {
     FftPlan inv_m;                   // rocFFT route (float64, or M outside the four-step kernels' range)
     AnalyticFft* ana = nullptr;      // four-step kernels of ssq_cwt_tiles.hip (float32)
     int n_analytic = 0;
+    bool own4096 = false;            // float32: the P = 4096 classes' spectra by block_spectra4096_kernel (one launch)
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take
     bool exact_ok = false;

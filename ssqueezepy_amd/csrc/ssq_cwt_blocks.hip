@@ -675,6 +675,66 @@ __global__ __launch_bounds__(256) void analytic_spectrum_kernel(const C* __restr
     }
 }
 
+
+// ---- block spectra of the P = 4096 classes in ONE launch (float32, round 5) ----------------------------------
+// Rounds 1-4: gather kernel per kind -> batched rocFFT (real-to-complex for the blocks of x: two kernels; complex for
+// the blocks of the analytic signal) per block length: at config 2 -- where every class has P = 4096 -- five launches
+// of 6-30 us per launch group (5 us of 327 per transform at 16 signals, 32 of 430 for a single one). Here a workgroup
+// takes TWO consecutive real blocks a, b of a signal as one complex sequence a + ib (or one analytic block), gathers
+// them from the periodic padded signal, runs the 4096-point LDS transform of ssq_ldsfft.h (radices 16 x 16 x 16;
+// twiddles: the class' own e^{2 pi i q / P} table) and writes the spectra the block kernels read:
+//   Z' = sum_p z[p] e^{+2 pi i k p / P} = Z[P - k]  (the transform at hand is the inverse one, unnormalised), so
+//   X_a[k] = (Z'[P-k] + conj Z'[k]) / 2,   X_b[k] = (Z'[P-k] - conj Z'[k]) / 2i,   k <= P / 2;   analytic: X[k] = Z'[P-k].
+struct BlockSpecArgs {
+    const float* xp; const c32* xa; c32* xb;
+    const BlockClassDev* classes; const c32* ctw;
+    int64_t M, n1;
+    int cls[8]; int first[9];          // classes served, first workgroup of each (first[n]: the grid's x size)
+    int ncls;
+};
+__global__ __launch_bounds__(NT) void block_spectra4096_kernel(BlockSpecArgs A) {
+    constexpr int P = 4096;
+    __shared__ c32 buf[P];
+    const int tid = threadIdx.x;
+    int b = (int)blockIdx.x, c = 0;
+    while (c + 1 < A.ncls && b >= A.first[c + 1]) ++c;
+    b -= A.first[c];
+    const BlockClassDev k = A.classes[A.cls[c]];
+    const int64_t sig = blockIdx.y, M = A.M;
+    const int64_t lead = A.n1 - k.m;
+    c32 z[PPT];
+    const bool ana = k.analytic != 0;
+    const int b0 = ana ? b : 2 * b, b1 = b0 + 1;                 // blocks of this workgroup
+    const bool two = !ana && b1 < (int)k.nb;
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) {
+        const int p = tid + t * NT;
+        int64_t s0 = (lead + (int64_t)b0 * k.V + p) % M; if (s0 < 0) s0 += M;
+        if (ana) z[t] = A.xa[sig * M + s0];
+        else {
+            int64_t s1 = (lead + (int64_t)b1 * k.V + p) % M; if (s1 < 0) s1 += M;
+            z[t] = {A.xp[sig * M + s0], two ? A.xp[sig * M + s1] : 0.f};
+        }
+    }
+    lds_ifft<P, 1, 16, 16, 16>(z, buf, A.ctw + k.ctw_off, tid);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PPT; ++t) buf[tid + t * NT] = z[t];    // natural order: Z'[tid + 256 t]
+    __syncthreads();
+    c32* out0 = A.xb + k.xb_off + (sig * k.nb + b0) * k.xb_stride;
+    if (ana) {
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) { const int f = tid + t * NT; out0[f] = buf[(P - f) & (P - 1)]; }
+    } else {
+        c32* out1 = out0 + k.xb_stride;
+        for (int f = tid; f <= P / 2; f += NT) {
+            const c32 Pk = buf[f], Qk = buf[(P - f) & (P - 1)];
+            out0[f] = {0.5f * (Qk.x + Pk.x), 0.5f * (Qk.y - Pk.y)};
+            if (two) out1[f] = {0.5f * (Qk.y + Pk.y), 0.5f * (Pk.x - Qk.x)};
+        }
+    }
+}
+
 template <int L, int G, int R1, int R2, int R3>
 static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
@@ -756,6 +816,8 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
         }
     }
     n_generic = d.n_generic;
+    // (SSQ_BLOCK_SPECTRA=rocfft: every class through gather + rocFFT, as in rounds 1-4)
+    own4096 = dtype == SSQ_F32 && M > 4096 && !(getenv("SSQ_BLOCK_SPECTRA") && !strcmp(getenv("SSQ_BLOCK_SPECTRA"), "rocfft"));
     {   // the CU count of the device the plan lives on (the multi-class launch asks how full a launch is)
         int dev = 0; hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
@@ -778,18 +840,58 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
     (void)batch;                                   // planned batch: stale rows are ignored later
     // classes are gathered and transformed in runs of equal block length and kind; with `need`,
     // only the runs that hold a needed class (class indices are contiguous per run). The real
-    // classes come first, the analytic ones last: one gather launch per kind.
+    // classes come first, the analytic ones last: one gather launch per kind. The P = 4096 classes of a
+    // float32 plan -- the first ones of each kind -- take block_spectra4096_kernel instead (own4096).
     std::vector<char> run_on(ffts.size(), 1);
-    int lo[2] = {nc, nc}, hi[2] = {-1, -1};        // needed class range per kind
+    int lo[2] = {nc, nc}, hi[2] = {-1, -1};        // needed class range per kind (rocFFT route)
+    bool any_analytic = false;
+    BlockSpecArgs S;
+    S.ncls = 0; S.first[0] = 0;
     for (size_t f = 0; f < ffts.size(); ++f) {
         const int a = fft_first[f], b = f + 1 < ffts.size() ? fft_first[f + 1] : nc;
         bool on = !need;
         for (int c = a; c < b && !on; ++c) on = need[c] != 0;
-        run_on[f] = on;
         const int kind = (int)hcls[a].analytic;
+        any_analytic = any_analytic || (on && kind);
+        if (on && own4096 && hcls[a].P == 4096) {
+            for (int c = a; c < b; ++c) {
+                if (need && !need[c]) continue;
+                SSQ_REQUIRE(S.ncls < 8, "more than 8 block classes of 4096 points");
+                S.cls[S.ncls] = c;
+                const int64_t wgs = kind ? hcls[c].nb : (hcls[c].nb + 1) / 2;
+                S.first[S.ncls + 1] = S.first[S.ncls] + (int)wgs;
+                ++S.ncls;
+            }
+            on = false;                            // (not through gather + rocFFT)
+        }
+        run_on[f] = on;
         if (on) { lo[kind] = std::min(lo[kind], a); hi[kind] = std::max(hi[kind], b - 1); }
     }
     const size_t rs = dtype == SSQ_F32 ? 4 : 8;
+    if (any_analytic) {
+        // the analytic signal of every padded signal first
+        SSQ_REQUIRE(xh && xa, "analytic block classes need the half spectrum");
+        if (ana) {
+            int rc = ana->run(xh, xa, max_batch, stream);
+            if (rc) return rc;
+        } else {
+            dim3 ga((unsigned)std::min<int64_t>((max_batch * M + 255) / 256, 4096));
+            if (dtype == SSQ_F32)
+                hipLaunchKernelGGL(analytic_spectrum_kernel<c32>, ga, dim3(256), 0, stream, (const c32*)xh, (c32*)xa, M, max_batch);
+            else
+                hipLaunchKernelGGL(analytic_spectrum_kernel<c64>, ga, dim3(256), 0, stream, (const c64*)xh, (c64*)xa, M, max_batch);
+            SSQ_LAUNCH_CHECK();
+            int rc = inv_m.execute(xa, nullptr, stream);
+            if (rc) return rc;
+        }
+    }
+    if (S.ncls) {
+        S.xp = (const float*)xp; S.xa = (const c32*)xa; S.xb = (c32*)xb;
+        S.classes = classes; S.ctw = (const c32*)ctw; S.M = M; S.n1 = n1;
+        hipLaunchKernelGGL(block_spectra4096_kernel, dim3((unsigned)S.first[S.ncls], (unsigned)max_batch), dim3(NT), 0,
+                           stream, S);
+        SSQ_LAUNCH_CHECK();
+    }
     for (int kind = 0; kind < 2; ++kind) {
         if (hi[kind] < lo[kind]) continue;
         int64_t most = 0;
@@ -804,21 +906,6 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
                                    (double*)blocks, classes + lo[0], M, n1, max_batch);
             SSQ_LAUNCH_CHECK();
         } else {
-            // the analytic signal of every padded signal first
-            SSQ_REQUIRE(xh && xa, "analytic block classes need the half spectrum");
-            if (ana) {
-                int rc = ana->run(xh, xa, max_batch, stream);
-                if (rc) return rc;
-            } else {
-                dim3 ga((unsigned)std::min<int64_t>((max_batch * M + 255) / 256, 4096));
-                if (dtype == SSQ_F32)
-                    hipLaunchKernelGGL(analytic_spectrum_kernel<c32>, ga, dim3(256), 0, stream, (const c32*)xh, (c32*)xa, M, max_batch);
-                else
-                    hipLaunchKernelGGL(analytic_spectrum_kernel<c64>, ga, dim3(256), 0, stream, (const c64*)xh, (c64*)xa, M, max_batch);
-                SSQ_LAUNCH_CHECK();
-                int rc = inv_m.execute(xa, nullptr, stream);
-                if (rc) return rc;
-            }
             if (dtype == SSQ_F32)
                 hipLaunchKernelGGL((gather_blocks_kernel<c32, true>), grid, dim3(256), 0, stream, (const c32*)xa,
                                    (c32*)xb, classes + lo[1], M, n1, max_batch);
