@@ -264,12 +264,7 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
         SSQ_CHECK_HIP(hipMemcpy(pl->diff_window, d.diff_window, (size_t)d.n_fft * rs, hipMemcpyHostToDevice));
     }
     TRYA(pl->xp, (size_t)pl->d.max_batch * pl->padlen * rs);
-    TRYA(pl->frames, (size_t)d.n_fft * pl->n_hops * rs);
-    TRYA(pl->dframes, (size_t)d.n_fft * pl->n_hops * rs);
-    TRYA(pl->dSx_ws, (size_t)pl->d.max_batch * pl->rows * pl->n_hops * rs * 2);
 #undef TRYA
-    rc = pl->fft.create(d.dtype, (size_t)d.n_fft, (size_t)pl->n_hops);
-    if (rc) { ssq_stft_plan_destroy(pl); return rc; }
     const bool pow2 = (d.n_fft & (d.n_fft - 1)) == 0;
     // (SSQ_STFT_MIXED=1: the mixed-radix kernel for the powers of two as well -- A/B aid)
     const bool prefer_mixed = getenv("SSQ_STFT_MIXED") && atoi(getenv("SSQ_STFT_MIXED")) != 0;
@@ -292,6 +287,17 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
         if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
         SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         pl->generic_fused = true;
+    }
+    // The framing workspace (two n_fft x n_hops arrays) and the rocFFT plan belong to the unfused route only: a fused
+    // plan does without them (at the reference's hop-1 benchmark shape they would be 2 x 383 MB). The derivative's
+    // workspace (dSx not returned, and no bin map in its place) is allocated at the first execute that needs it.
+    if (!pl->fused && !pl->generic_fused) {
+        const size_t fb = (size_t)d.n_fft * pl->n_hops * rs;
+        if (hipMalloc(&pl->frames, fb) != hipSuccess || hipMalloc(&pl->dframes, fb) != hipSuccess) {
+            set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2;
+        }
+        rc = pl->fft.create(d.dtype, (size_t)d.n_fft, (size_t)pl->n_hops);
+        if (rc) { ssq_stft_plan_destroy(pl); return rc; }
     }
     pl->d.window = nullptr; pl->d.diff_window = nullptr;
     *out = pl;
@@ -357,7 +363,14 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     int rc = ssq_pad_signal(d.dtype, x, pl->xp, batch, d.n, pl->n1, pl->n2, d.padtype, stream);
     if (rc) return rc;
     const int64_t s20 = (n_fft + 1) / 2, s21 = (n_fft % 2 == 1) ? s20 - 1 : s20;
-    T* dS = dSx ? (T*)dSx : (T*)pl->dSx_ws;
+    // (decided below: whether the derivative is stored at all; its workspace exists from the first call that needs one)
+    auto dsx_workspace = [&]() -> void* {
+        if (!pl->dSx_ws) {
+            if (hipMalloc(&pl->dSx_ws, (size_t)pl->d.max_batch * rows * n_hops * sizeof(T) * 2) != hipSuccess) return nullptr;
+        }
+        return pl->dSx_ws;
+    };
+    T* dS = (T*)dSx;
     // fused ssq_stft form: Tx wanted, neither dSx nor w -> the kernel emits 2-byte bins
     // instead of the 8-byte derivative (the reassignment then reads 10 instead of 16 B/pt)
     // ... and, unless the ordered sums are asked for (SSQ_TILE_ORDER=ordered), sums Tx itself
@@ -375,6 +388,10 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             if (!fused_tx && !pl->kidx)
                 SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
         }
+    }
+    if (deriv && !dSx && !use_kidx) {              // the derivative is needed (phase transform / bins) but not returned
+        dS = (T*)dsx_workspace();
+        SSQ_REQUIRE(dS, "hipMalloc failed (stft derivative workspace)");
     }
     if constexpr (sizeof(T) == 4) {
         if (pl->fused) {
