@@ -142,6 +142,7 @@ struct ssq_cwt_plan {
     // workspace
     void* xp = nullptr; void* xh = nullptr; void* prod = nullptr; unsigned short* kidx = nullptr;
     int64_t rows_chunk = 0;
+    size_t prod_bytes = 0;                // size of `prod` once it is allocated
     int64_t bytes = 0;
     // signals per launch group: the fast-path kernels and the reassignment take `group`
     // signals as a grid dimension (fewer, longer launches; the bin map holds `group` maps)
@@ -227,7 +228,9 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
     const size_t per_row = (size_t)2 * d.m * cs;
     const size_t budget = (size_t)2 << 30;
     pl->rows_chunk = std::max<int64_t>(1, std::min<int64_t>(d.na, (int64_t)(budget / per_row)));
-    TRY(dev_alloc(&pl->prod, (size_t)pl->rows_chunk * per_row, pl->bytes));
+    // (allocated by the first execute that sends rows through the generic route: a plan whose rows all run on the
+    // block / tile kernels -- the usual case -- never needs these up to 2 GiB)
+    pl->prod_bytes = (size_t)pl->rows_chunk * per_row;
     {
         // default: up to 16 signals per launch (measured at config 2: 16 -> +1 % over 8), bin maps
         // bounded to ~2 GiB
@@ -485,6 +488,10 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         T* Wx_b = Wx ? (T*)Wx + (size_t)b * na * out_cols * 2 : nullptr;
         T* dWx_b = dWx ? (T*)dWx + (size_t)b * na * out_cols * 2 : nullptr;
         T* w_b = w ? (T*)w + (size_t)b * na * out_cols : nullptr;
+        if (n_gen > 0 && !pl->prod) {
+            SSQ_CHECK_HIP(hipMalloc(&pl->prod, pl->prod_bytes ? pl->prod_bytes : 1));
+            pl->bytes += (int64_t)pl->prod_bytes;
+        }
         for (int64_t row0 = 0; row0 < n_gen; row0 += pl->rows_chunk) {
             const int64_t rows = std::min(pl->rows_chunk, n_gen - row0);
             unsigned gx = (unsigned)std::min<int64_t>((M + 255) / 256, 4096);
