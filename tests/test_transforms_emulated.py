@@ -166,6 +166,32 @@ def test_tile_walk_through_signal_boundaries_emulated(S, monkeypatch):
     _cwt.clear_plan_cache()
 
 
+def test_mixed_radix_stft_emulated(S, orc):
+    """Round 5: window lengths that are not powers of two run the mixed-radix fused kernel (csrc/ssq_stft_generic.hip)
+    when their prime factors are <= 31 and the transform fits the LDS -- the reference's published benchmark length 598 =
+    2 x 13 x 23 among them -- and framing + rocFFT otherwise; what each plan chose is asserted on, the results against
+    the oracle (reference tolerance), the block spectra of the CWT through the own 4096-point kernel and through rocFFT
+    against each other."""
+    from conftest import two_chirps
+    from pipeline import oracle_ssq_stft
+    from ssqueezepy_amd import _stft, _lib
+    relmax = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    for n_fft, want in ((598, 'fused-mixed-radix'), (1001, 'fused-mixed-radix'), (97, 'rocfft'), (2 * 37, 'rocfft'),
+                        (256, 'fused'), (5000, 'rocfft')):
+        N = 3 * n_fft + 700
+        x = two_chirps(N, seed=n_fft)
+        _stft._PLAN_CACHE.clear()
+        Tx, Sx, sf, Sfs, dSx = S.ssq_stft(x, n_fft=n_fft, hop_len=max(1, n_fft // 5), dtype='float32', get_dWx=True,
+                                          astensor=False)
+        plan = next(iter(_stft._PLAN_CACHE.values()))
+        assert plan.algo == want, (n_fft, plan.algo)
+        ro = oracle_ssq_stft(orc, x, 'float32', n_fft=n_fft, hop_len=max(1, n_fft // 5))
+        assert relmax(Sx, ro['Sx']) <= 1e-5 and relmax(dSx, ro['dSx']) <= 1e-5, n_fft
+    _stft._PLAN_CACHE.clear()
+    sha = _lib.load().ssq_build_sha().decode()
+    assert sha == 'unknown' or len(sha.split('-')[0]) == 40, sha
+
+
 def test_fused_stft_reassignment_emulated(S, monkeypatch):
     """ssq_stft without dSx: the fused STFT kernel sums Tx of its frames in LDS (float64, unordered) --
     against the ordered two-kernel path on the same input (which the GPU suite checks against the
