@@ -178,7 +178,42 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
     // workgroup in LDS instead of once per point from global memory (bandW, bandD: L entries).
     constexpr bool STAGE = (L <= 512);
     const float invP = 1.0f / (float)P;             // exact (P is a power of two)
-    {
+    // Round 5, the large classes (no band staging): every global load of the prologue -- the staged twiddles, the
+    // work-item's first column twiddle and the band's three loads per point -- is issued up front, into registers,
+    // and only then are the staged values written to LDS and the barrier taken: the band's latency runs under the
+    // staging instead of starting behind its barrier. Block rows 69.4 -> 64.0 us (an ablation without the band's
+    // loads runs at 51.8: profiles/r5_ab_history.txt). -DSSQ_BLOCK_EARLY=0: loads where they are used, as before.
+#ifndef SSQ_BLOCK_EARLY
+#define SSQ_BLOCK_EARLY 1
+#endif
+    constexpr bool EARLY = !STAGE && SSQ_BLOCK_EARLY && (R1 * G <= NT);
+    float e_p[EARLY ? PPT : 1], e_m[EARLY ? PPT : 1];
+    c32 e_X[EARLY ? PPT : 1], e_cw[EARLY ? PPT / R1 : 1];
+    if constexpr (EARLY) {
+        constexpr int NBe = PPT / R1, STR = L / R1;
+        c32 st_v = {0.f, 0.f}, st_w = {0.f, 0.f};
+        if (tid < R1 * G) {
+            const unsigned t = (unsigned)(tid / G), col = (unsigned)(c0 + tid % G);
+            st_v = ctw[(t * (unsigned)STR * col) & (unsigned)(P - 1)];
+        }
+        if (tid < G) st_w = ctw[(0u - (unsigned)L * (unsigned)(c0 + tid)) & (unsigned)(P - 1)];
+#pragma unroll
+        for (int it = 0; it < NBe; ++it) {
+            const int idx = tid + it * NT, g = idx % G, u = idx / G;
+            const int off0 = (u - r.klo) & (L - 1);
+            e_cw[it] = ctw[((unsigned)(r.klo + off0) * (unsigned)(c0 + g)) & (unsigned)(P - 1)];
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int off = (off0 + k * STR) & (L - 1);
+                const bool in = off < r.KP;              // slots past the band: zeros
+                e_p[it * R1 + k] = in ? psi[off] : 0.f;
+                e_X[it * R1 + k] = in ? xb[r.klo + off] : c32{0.f, 0.f};
+                e_m[it * R1 + k] = in ? pxi[off] : 0.f;
+            }
+        }
+        if (tid < R1 * G) spow[tid] = st_v;
+        if (tid < G) wrapf[tid] = st_w;
+    } else {
         constexpr int STR = L / R1;
         for (int i = tid; i < R1 * G; i += NT) {
             const unsigned t = (unsigned)(i / G), col = (unsigned)(c0 + i % G);
@@ -211,7 +246,7 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
             const int idx = tid + it * NT, g = idx % G, u = idx / G;
             const unsigned col = (unsigned)(c0 + g);
             const int off0 = (u - r.klo) & (L - 1);
-            const c32 cw0 = ctw[((unsigned)(r.klo + off0) * col) & (unsigned)(P - 1)];
+            const c32 cw0 = EARLY ? e_cw[EARLY ? it : 0] : ctw[((unsigned)(r.klo + off0) * col) & (unsigned)(P - 1)];
             const c32 wf = wrapf[g];
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
@@ -224,14 +259,14 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
                     if (offu >= L) cw = cmul_v(cw, wf);
                     z = cmul_v(bandW[off], cw);
                     dz = cmul_v(bandD[off], cw);
-                } else if (off < r.KP) {
-                    const float p = psi[off] * invP;
-                    const c32 X = xb[r.klo + off];
+                } else if (EARLY || off < r.KP) {            // (EARLY: slots past the band were loaded as zeros)
+                    const float p = (EARLY ? e_p[EARLY ? it * R1 + k : 0] : psi[off]) * invP;
+                    const c32 X = EARLY ? e_X[EARLY ? it * R1 + k : 0] : xb[r.klo + off];
                     c32 cw = (k == 0) ? cw0 : cmul_v(cw0, spow[k * G + g]);
                     if (offu >= L) cw = cmul_v(cw, wf);
                     const c32 bz = {p * X.x, p * X.y};
                     z = cmul_v(bz, cw);
-                    const float mm = pxi[off] * A.inv_dt;
+                    const float mm = (EARLY ? e_m[EARLY ? it * R1 + k : 0] : pxi[off]) * A.inv_dt;
                     dz = {-(z.y * mm), z.x * mm};
                 }
                 zw[it * R1 + k] = z; zd[it * R1 + k] = dz;
