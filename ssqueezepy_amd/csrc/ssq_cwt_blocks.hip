@@ -986,8 +986,11 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
         // (... or when the whole call is only a few rounds of workgroups -- three of them share a CU: a single signal
         // at config 2 is 1512 + 1344 workgroups, two rounds per class launched one after the other, 3.7 rounds
         // together: block stage 107 -> 89 us, round 5)
+        // (... and the fused form's lean kernels always: at config 2, 16 signals per launch, the two large classes in
+        // one launch take 58.5 us per transform against 64.0 one after the other -- one tail instead of two -- round 5)
+        const bool lean = A.kidx && !A.dWx && !A.w && !A.row_scale;
         const bool multi = force >= 0 ? force != 0
-                                      : (used > 1 && (biggest <= 2 * (int64_t)ncu || total * nsig <= 18 * (int64_t)ncu));
+                                      : (used > 1 && (lean || biggest <= 2 * (int64_t)ncu || total * nsig <= 18 * (int64_t)ncu));
         if (multi && total > 0) {
             BlockMultiArgs Mx;
             Mx.A = A; Mx.A.items = nullptr; Mx.A.n_items = total; Mx.A.ftw = nullptr;
@@ -998,7 +1001,7 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
             }
             Mx.first[5] = acc;
             const dim3 grid((unsigned)total, (unsigned)nsig);
-            if (A.kidx && !A.dWx && !A.w && !A.row_scale)
+            if (lean)
                 hipLaunchKernelGGL((blockzoom_multi_kernel<true>), grid, dim3(NT), 0, stream, Mx, sp);
             else
                 hipLaunchKernelGGL((blockzoom_multi_kernel<false>), grid, dim3(NT), 0, stream, Mx, sp);
