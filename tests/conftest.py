@@ -105,6 +105,13 @@ def tile_order():
     return 'ordered' if os.environ.get('SSQ_TILE_ORDER') == 'ordered' else 'f64'
 
 
+def needs_tile_path():
+    """Tests of the column-tile path itself: skipped when a run switches it off (SSQ_CWT_TILES=0,
+    the whole suite on the block kernels + the two-step reassignment)."""
+    if os.environ.get('SSQ_CWT_TILES', '') == '0':
+        pytest.skip('the column-tile path is switched off (SSQ_CWT_TILES=0)')
+
+
 @pytest.fixture(params=['f64', 'ordered'])
 def tile_mode(request, monkeypatch):
     monkeypatch.setenv('SSQ_TILE_ORDER', request.param)

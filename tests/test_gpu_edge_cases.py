@@ -5,7 +5,7 @@ time vectors, odd n_fft, short windows, single-scale banks, plan-cache reuse."""
 import os
 import numpy as np
 import pytest
-from conftest import two_chirps, assert_tx_vs_oracle, assert_tx_repeat, tile_mode  # noqa: F401
+from conftest import two_chirps, assert_tx_vs_oracle, assert_tx_repeat, tile_mode, needs_tile_path  # noqa: F401
 from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
 
 pytestmark = pytest.mark.gpu
@@ -231,6 +231,7 @@ def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
     """The long classes of the tile path's intermediates on the four-step kernels (default) against
     the same transform with every class on rocFFT (SSQ_TILE_FFT=rocfft): N = 100 000 covers
     L = 2^14 .. 2^16, N = 2^20 (padded to 2^21) the factors up to 512 x 1024; batched == single."""
+    needs_tile_path()
     from ssqueezepy_amd import _cwt
     if os.environ.get('SSQ_EMULATE') == '1' and N > 200000:
         pytest.skip("2^20 points under the CPU emulation of the kernels take minutes")
@@ -286,6 +287,7 @@ def test_tile_kernel_every_instantiation(S, orc, case, tile_mode):
     default 'log-piecewise' scales and its 'linear' scales, ssqueezing.py:126-128 ->
     algos.py:66-79), with and without `dWx` stored. What is asserted on is what EXECUTED
     (`plan.tiles_done()` counts the tiles the kernel finished), not the plan's label."""
+    needs_tile_path()
     import os
     from ssqueezepy_amd import _cwt, _ssq_cwt
     emulated = os.environ.get('SSQ_EMULATE') == '1'
@@ -363,6 +365,7 @@ def test_more_rows_than_the_32_column_tile_holds(S, orc, tile_mode):
     reassignment for every row -- decided before any row is routed (round-4 advisor: it used to fail
     inside `TilePlan::run`, after the block work had been launched). What executed is asserted on,
     and the result against the oracle, in both modes."""
+    needs_tile_path()
     from ssqueezepy_amd import _cwt
     from pipeline import oracle_ssq_cwt, GRIDNAME
     N = 20000 if os.environ.get('SSQ_EMULATE') == '1' else 160000

@@ -38,3 +38,9 @@ rm -rf $O/prof1
 # 5. the other BASELINE configurations, each line with its own roofline block; the STFT at the reference's published shape
 timeout 500 python tools/run_configs.py c1 c3 c5 > $O/configs.jsonl 2> $O/configs.err; cut -c1-260 $O/configs.jsonl
 timeout 300 python tools/stft_hop1_probe.py 1024 598 2>/dev/null | tee $O/stft_hop1.txt
+# 6. the GPU suite in the other two modes, and the randomised sweep (MODES=0 skips)
+if [ "${MODES:-1}" != 0 ]; then
+  SSQ_TILE_ORDER=ordered timeout 1200 python -m pytest tests -q -m gpu > $O/gpu_suite_ordered_mode.txt 2>&1; tail -1 $O/gpu_suite_ordered_mode.txt
+  SSQ_CWT_TILES=0 timeout 1200 python -m pytest tests -q -m gpu > $O/gpu_suite_no_tiles.txt 2>&1; tail -1 $O/gpu_suite_no_tiles.txt
+  timeout 600 python tools/fuzz_parity.py 150 2025 > $O/fuzz_gpu.txt 2>&1; tail -1 $O/fuzz_gpu.txt
+fi
