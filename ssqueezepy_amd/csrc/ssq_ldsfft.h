@@ -104,13 +104,18 @@ constexpr int NT = FftGeom<float>::NT;          //                  256 threads
 // `v` holds the pass-1 inputs on entry (butterfly u = idx / G, column g = idx % G,
 // idx = tid + it*NT, input t at q = u + t*L/R1) and the final-pass outputs on exit
 // (n_hi = u + t*L/RL with RL the last radix, same idx -> (u, g) mapping).
-template <int L, int G, int R1, int R2, int R3, typename R>
+// EARLY_TW (float32): the twiddles of passes 2 and 3 are requested before the barrier in front of the pass instead of
+// after its LDS reads -- the table reads' latency runs under the barrier (block rows 58.9 -> 56.7 us at config 2; no
+// change for the intermediates' kernels, which wait on HBM). FRESH: `buf` holds nothing a wavefront may still be
+// reading (a kernel's first transform): no barrier before pass 1.
+template <int L, int G, int R1, int R2, int R3, bool EARLY_TW = false, bool FRESH = false, typename R>
 __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ buf,
                                          const cx<R>* __restrict__ ftw, int tid) {
     constexpr int NT = FftGeom<R>::NT;
     static_assert(L * G == FftGeom<R>::D, "L * G must fill the workgroup");
     constexpr bool three = (R3 > 1);
-    __syncthreads();                               // LDS free (previous transform's reads done)
+    constexpr bool ETW = EARLY_TW && sizeof(R) == 4;
+    if constexpr (!FRESH) __syncthreads();         // LDS free (previous transform's reads done)
     // ---- pass 1 (Ns = 1): inputs already in registers
     {
         constexpr int NB = PPT / R1;
@@ -123,6 +128,16 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             int idx = tid + it * NT, g = idx % G, u = idx / G;
 #pragma unroll
             for (int k = 0; k < R1; ++k) buf[(u * R1 + k) * G + g] = t[k];
+        }
+    }
+    cx<R> tw2[ETW ? PPT / R2 : 1][ETW ? R2 : 1];
+    if constexpr (ETW) {
+        constexpr int NB = PPT / R2, Ns = R1, TW = L / (Ns * R2);
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int kk = ((tid + it * NT) / G) % Ns;
+#pragma unroll
+            for (int k = 1; k < R2; ++k) tw2[it][k] = ftw[kk * k * TW];
         }
     }
     __syncthreads();
@@ -143,7 +158,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             int kk = u % Ns;
             constexpr int TW = L / (Ns * R2);
 #pragma unroll
-            for (int k = 1; k < R2; ++k) t[it][k] = cmul_v(t[it][k], ftw[kk * k * TW]);
+            for (int k = 1; k < R2; ++k) t[it][k] = cmul_v(t[it][k], ETW ? tw2[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k * TW]);
             Dft<R2>::run(t[it]);
             if (three) {
                 int j0 = (u / Ns) * Ns * R2 + kk;
@@ -156,6 +171,15 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
         }
     }
     if constexpr (three) {
+        cx<R> tw3[ETW ? PPT / R3 : 1][ETW ? R3 : 1];
+        if constexpr (ETW) {
+#pragma unroll
+            for (int it = 0; it < PPT / R3; ++it) {
+                const int kk = ((tid + it * NT) / G) % (R1 * R2);
+#pragma unroll
+                for (int k = 1; k < R3; ++k) tw3[it][k] = ftw[kk * k];
+            }
+        }
         __syncthreads();
         constexpr int NB = PPT / R3, Ns = R1 * R2, STR = L / R3;
 #pragma unroll
@@ -166,7 +190,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             for (int k = 0; k < R3; ++k) t[k] = buf[(u + k * STR) * G + g];
             int kk = u % Ns;                       // == u (Ns*R3 == L)
 #pragma unroll
-            for (int k = 1; k < R3; ++k) t[k] = cmul_v(t[k], ftw[kk * k]);
+            for (int k = 1; k < R3; ++k) t[k] = cmul_v(t[k], ETW ? tw3[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k]);
             Dft<R3>::run(t);
 #pragma unroll
             for (int k = 0; k < R3; ++k) v[it * R3 + k] = t[k];
