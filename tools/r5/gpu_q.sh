@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the block kernels' undecided points through a queue + fix-up kernel (default) against evaluated in place
-# (SSQ_BLOCK_QUEUE=0), same library, same box; then the full-size parity checks
+# (SSQ_BLOCK_QUEUE=0), same library, same box; then the full-size parity checks. Measured and not kept
+# (profiles/r5_ab_history.txt, block "r5zz"): the queue, its fix-up kernel and the switch are not in the tree any more.
 cd /root/repo; O=gpurun_out/${OUT:-r5q}; mkdir -p $O
 run() { local label=$1; shift
   echo -n "$label "; timeout 200 python bench.py --no-cpu --steps ${STEPS:-8} "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), {k: round(v,1) for k,v in d['stages_us_per_transform'].items()})"; }
