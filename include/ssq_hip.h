@@ -45,7 +45,7 @@ extern "C" {
 #define SSQ_PAD_WRAP 4
 
 /* ------------------------------------------------------------------ runtime */
-int         ssq_version(void);          /* 104 (103: without ssq_build_sha / ssq_cwt_plan_set_bin_dump; 102: without ssq_ridge_*_batch; 101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
+int         ssq_version(void);          /* 105 (104: without ssq_cwt_plan_tile_kernel; 103: without ssq_build_sha / ssq_cwt_plan_set_bin_dump; 102: without ssq_ridge_*_batch; 101: without ssq_cwt_plan_tile_cols; 100: block classes without the `analytic` column) */
 /* The git commit of the device code this library was built from: the last commit that touched
  * ssqueezepy_amd/csrc or include/ ("<sha>-dirty" when the build tree had uncommitted changes there,
  * "unknown" when built outside a git checkout). Measurement records carry it (bench.py, profiles/):
@@ -343,6 +343,11 @@ int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
  * environment (float32 tile, terms added in the reference's row order; na <= 318). 0 without
  * tile tables. */
 int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
+/* Which column-tile kernel the next execute launches (ABI 105): 0 none, 1 the ordered float32 tile
+ * (SSQ_TILE_ORDER=ordered), 2 the float64 tile with one column per lane (tile2_kernel), 3 the float64 tile with a
+ * column pair per lane (tile3_kernel: the default whenever the signal's length and its left padding are even and
+ * the tile holds 32 columns; SSQ_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
+int  ssq_cwt_plan_tile_kernel(const ssq_cwt_plan* plan);
 
 /* Diagnostic (tests; not needed by a caller of the transforms): from now on every fused execute
  * (Tx requested, bins from dWx) also writes the bin index of every point AS THE REASSIGNMENT CONSUMED

@@ -221,6 +221,12 @@ class CwtPlan():
         """columns per tile of the tile kernel the next execute launches (0: no tile path)"""
         return int(self.lib.ssq_cwt_plan_tile_cols(self._h))
 
+    @property
+    def tile_kernel(self):
+        """which column-tile kernel the next execute launches: 0 none, 1 ordered (float32 tile), 2 float64 tile
+        with a column per lane, 3 float64 tile with a column pair per lane (`ssq_cwt_plan_tile_kernel`)"""
+        return int(self.lib.ssq_cwt_plan_tile_kernel(self._h))
+
     def set_bin_dump(self, kmap):
         """Diagnostic (`ssq_cwt_plan_set_bin_dump`): `kmap` -- a GPU int16 / uint16 tensor of at least
         ``max_batch * na * N`` elements, kept alive by the plan -- receives the bin index of every point

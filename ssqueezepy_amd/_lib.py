@@ -121,6 +121,7 @@ _PROTOS = {
     'ssq_cwt_plan_algo': (c_char_p, [c_void_p]),
     'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
     'ssq_cwt_plan_tile_cols': (c_int, [c_void_p]),
+    'ssq_cwt_plan_tile_kernel': (c_int, [c_void_p]),
     'ssq_cwt_plan_set_bin_dump': (c_int, [c_void_p, c_void_p]),
     'ssq_build_sha': (c_char_p, []),
     'ssq_cwt_tile_rows_per_step': (c_int, []),
@@ -138,7 +139,7 @@ EXPORTS = tuple(_PROTOS)
 _lib = None
 
 
-ABI_VERSION = 104     # include/ssq_hip.h: ssq_version()
+ABI_VERSION = 105     # include/ssq_hip.h: ssq_version()
 
 
 def load(build_if_missing=True):

@@ -27,6 +27,7 @@ SOURCES = [
     ('ssq_cwt_tiles.hip', ['-ffp-contract=off']),
     ('ssq_tile_fft.hip', ['-ffp-contract=off']),
     ('ssq_tile_f64.hip', ['-ffp-contract=off']),
+    ('ssq_tile_pair.hip', ['-ffp-contract=off']),
     ('ssq_tile_ordered.hip', ['-ffp-contract=off']),
     ('ssq_stft.hip', ['-ffp-contract=off']),
     ('ssq_stft_generic.hip', ['-ffp-contract=off']),

@@ -89,6 +89,26 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
                  : "=&v"(A), "=&v"(D)                                                                         \
                  : "v"((w)[0]), "v"((w)[1]), "v"((w)[2]), "v"((w)[3]), "v"((w)[4]), "v"((w)[5]), "v"((w)[6]),  \
                    "v"((w)[7]), "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7))
+// The same for TWO points that share their samples (neighbouring columns of one row, tile3_kernel): weights wa / wb,
+// four accumulators taken in turn -- every instruction's operands are three instructions old.
+#define SSQ_TAPS_T_(t, ta, tb, ts)                                                                            \
+                 "v_pk_fma_f32 %0, %" #ta ", %" #ts ", %0 op_sel_hi:[0,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %1, %" #ta ", %" #ts ", %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"                \
+                 "v_pk_fma_f32 %2, %" #tb ", %" #ts ", %2 op_sel_hi:[0,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %3, %" #tb ", %" #ts ", %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define SSQ_TAPS8X2(A0, D0, A1, D1, wa, wb, s0, s1, s2, s3, s4, s5, s6, s7)                                    \
+    asm volatile("v_pk_mul_f32 %0, %4, %20 op_sel_hi:[0,1]\n\t"                                               \
+                 "v_pk_mul_f32 %1, %4, %20 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                  \
+                 "v_pk_mul_f32 %2, %12, %20 op_sel_hi:[0,1]\n\t"                                              \
+                 "v_pk_mul_f32 %3, %12, %20 op_sel:[1,0] op_sel_hi:[1,1]\n\t"                                 \
+                 SSQ_TAPS_T_(1, 5, 13, 21) SSQ_TAPS_T_(2, 6, 14, 22) SSQ_TAPS_T_(3, 7, 15, 23)                 \
+                 SSQ_TAPS_T_(4, 8, 16, 24) SSQ_TAPS_T_(5, 9, 17, 25) SSQ_TAPS_T_(6, 10, 18, 26)                \
+                 SSQ_TAPS_T_(7, 11, 19, 27)                                                                   \
+                 : "=&v"(A0), "=&v"(D0), "=&v"(A1), "=&v"(D1)                                                 \
+                 : "v"((wa)[0]), "v"((wa)[1]), "v"((wa)[2]), "v"((wa)[3]), "v"((wa)[4]), "v"((wa)[5]),        \
+                   "v"((wa)[6]), "v"((wa)[7]), "v"((wb)[0]), "v"((wb)[1]), "v"((wb)[2]), "v"((wb)[3]),        \
+                   "v"((wb)[4]), "v"((wb)[5]), "v"((wb)[6]), "v"((wb)[7]),                                    \
+                   "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7))
 // flip a wave-uniform 0/1 and take the wavefront's issue priority from it (2 or 0): the compiler's form of
 // the same costs two more scalar instructions per use
 #define SSQ_PRIO_TOGGLE(p) asm volatile("s_xor_b32 %0, %0, 1\n\ts_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 1f\n\t"  \

@@ -82,93 +82,107 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
         if ((rc = up((void**)&rows, hp.data(), hp.size() * 4))) return rc;
     }
-    {   // tile2_kernel's items: 64 / COLS consecutive rows of a step, one record of 8 words per item:
-        // row0 | padded sub-rows << 9 | kind << 12 | lgR << 13, samples of sub-row 0 (class offset + row
-        // in class * L), row0 * N * 8, entries between two signals' rows of the class, centre bins
+    {   // the default kernels' items: `rpi` consecutive rows of a step, one record of 8 words per item:
+        // row0 | padded sub-rows << 9 | kind << 12 | lgR << 13 (| the weights' table offset << 18: tile3_kernel),
+        // samples of sub-row 0 (class offset + row in class * L), row0 * N * 8, entries between two signals' rows of
+        // the class, centre bins -- and the wavefronts' blocks of items, [nw][4] = first item, end, first item of the
+        // second class, the weights' table offsets of the two classes (16 bits each).
+        // tile2_kernel (ssq_tile_f64.hip): rpi = 64 / columns per tile; tile3_kernel (ssq_tile_pair.hip): 4 rows x 32
+        // columns, two columns per lane.
         const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
         cols2 = tile2_lds_bytes(na, 32) <= 160 * 1024 ? 32 : 16;
         if (const char* e = getenv("SSQ_TILE2_COLS")) if (atoi(e) == 16) cols2 = 16;     // (tuning aid)
         SSQ_REQUIRE(tile2_lds_bytes(na, cols2) <= 160 * 1024, "na = %lld: the Tx tile exceeds the LDS", (long long)na);
-        const int rpi = 64 / cols2;
-        SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
-        n_items2 = nsteps * TILE_G / rpi;
-        std::vector<int32_t> hi8((size_t)n_items2 * 8, 0);
-        std::vector<float> cost((size_t)n_items2, 0.f);
-        std::vector<int32_t> icls((size_t)n_items2, 0), woff((size_t)n_items2, 0);
+        lgr_max2 = 0;
+        for (int i = 0; i < nsegs; ++i) if (sg[i].kind) lgr_max2 = std::max(lgr_max2, (int)sg[i].lgR);
         // (what a row read back costs next to an interpolated one when the rows are dealt to the wavefronts; measured
         // 0.5 .. 1.2: 221 / 223 / 222 / 228 / 225 us, round 4)
-        const float rb_cost = 0.7f;
-        tile2_ok = true;
-        lgr_max2 = 0;
-        for (int i = 0; i < nsegs; ++i) {
-            const int64_t L = (int64_t)M >> sg[i].lgR;
-            if (sg[i].kind && (sg[i].wtab_off >= 65536 || sg[i].sig_stride % L)) tile2_ok = false;
-            if (sg[i].kind) lgr_max2 = std::max(lgr_max2, (int)sg[i].lgR);
-            for (int t = 0; t < sg[i].nsteps * TILE_G / rpi; ++t) {
-                const size_t it = (size_t)sg[i].first * TILE_G / rpi + t;
-                const TileRow* r = rw + it * rpi;
-                int npad = 0;
-                for (int k = 0; k < rpi; ++k) {
-                    if (r[k].row < 0) ++npad;
-                    else if (npad) tile2_ok = false;                  // padding trails
-                    // the sub-rows are consecutive rows of the class (the padding repeats the last one)
-                    if (r[k].row >= 0 && ((r[k].row & 0xFFFF) != (r[0].row & 0xFFFF) + k
-                                          || (sg[i].kind && r[k].ubase != r[0].ubase + k * L))) tile2_ok = false;
-                    hi8[8 * it + 4 + k] = r[k].kc;
+        auto build = [&](int rpi, int nw, bool woff_in_record, float rb_cost, void** items_dev, int32_t** waves_dev,
+                         int& n_items, bool& ok) -> int {
+            SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
+            n_items = nsteps * TILE_G / rpi;
+            std::vector<int32_t> hi8((size_t)n_items * 8, 0);
+            std::vector<float> cost((size_t)n_items, 0.f);
+            std::vector<int32_t> icls((size_t)n_items, 0), woff((size_t)n_items, 0);
+            ok = true;
+            for (int i = 0; i < nsegs; ++i) {
+                const int64_t L = (int64_t)M >> sg[i].lgR;
+                if (sg[i].kind && (sg[i].wtab_off >= (woff_in_record ? 16384 : 65536) || sg[i].sig_stride % L)) ok = false;
+                for (int t = 0; t < sg[i].nsteps * TILE_G / rpi; ++t) {
+                    const size_t it = (size_t)sg[i].first * TILE_G / rpi + t;
+                    const TileRow* r = rw + it * rpi;
+                    int npad = 0;
+                    for (int k = 0; k < rpi; ++k) {
+                        if (r[k].row < 0) ++npad;
+                        else if (npad) ok = false;                        // padding trails
+                        // the sub-rows are consecutive rows of the class (the padding repeats the last one)
+                        if (r[k].row >= 0 && ((r[k].row & 0xFFFF) != (r[0].row & 0xFFFF) + k
+                                              || (sg[i].kind && r[k].ubase != r[0].ubase + k * L))) ok = false;
+                        hi8[8 * it + 4 + k] = r[k].kc;
+                    }
+                    const int32_t row0 = r[0].row & 0xFFFF;
+                    hi8[8 * it] = row0 | (npad << 9) | (sg[i].kind << 12) | (sg[i].lgR << 13)
+                                  | (woff_in_record && sg[i].kind ? (int32_t)((uint32_t)sg[i].wtab_off << 18) : 0);
+                    hi8[8 * it + 1] = sg[i].kind ? sg[i].cls_base + r[0].ubase : 0;
+                    hi8[8 * it + 2] = (int32_t)(uint32_t)((int64_t)row0 * N * 8);
+                    hi8[8 * it + 3] = sg[i].kind ? sg[i].sig_stride : 0;
+                    cost[it] = sg[i].kind ? 1.0f : rb_cost;           // what rows read back cost next to interpolated ones
+                    icls[it] = sg[i].kind ? 1 + sg[i].lgR : 0;
+                    woff[it] = sg[i].kind ? sg[i].wtab_off : 0;
                 }
-                const int32_t row0 = r[0].row & 0xFFFF;
-                hi8[8 * it] = row0 | (npad << 9) | (sg[i].kind << 12) | (sg[i].lgR << 13);
-                hi8[8 * it + 1] = sg[i].kind ? sg[i].cls_base + r[0].ubase : 0;
-                hi8[8 * it + 2] = (int32_t)(uint32_t)((int64_t)row0 * N * 8);
-                hi8[8 * it + 3] = sg[i].kind ? sg[i].sig_stride : 0;
-                cost[it] = sg[i].kind ? 1.0f : rb_cost;               // what rows read back cost next to interpolated ones
-                icls[it] = sg[i].kind ? 1 + sg[i].lgR : 0;
-                woff[it] = sg[i].kind ? sg[i].wtab_off : 0;
             }
-        }
-        if ((rc = up((void**)&items2, hi8.data(), hi8.size() * 4))) return rc;
-        // Contiguous, cost-balanced blocks of items per wavefront, each spanning at most TWO classes
-        // (kind / decimation): the kernel keeps the weights of two classes in registers. [TILE2_NW][4] =
-        // first item, end, first item of the second class, the weights' table offsets of the two classes
-        // (16 bits each).
-        std::vector<int> run_start;                        // maximal runs of one class
-        for (int it = 0; it < n_items2; ++it)
-            if (it == 0 || icls[it] != icls[it - 1]) run_start.push_back(it);
-        const int nruns = (int)run_start.size();
-        run_start.push_back(n_items2);
-        std::vector<double> pre((size_t)n_items2 + 1, 0.0);
-        for (int it = 0; it < n_items2; ++it) pre[it + 1] = pre[it] + cost[it];
-        std::vector<int32_t> wt_;
-        // (round 4 also sized the blocks by the wavefronts' measured speeds -- the older wavefronts of a SIMD finish the
-        // same work 10-19 % sooner -- to no effect: 221 +- 3 us for every weighting; a SIMD's total is what counts)
-        {
-            const int nw = TILE2_NW;
-            int cur = 0;
-            const double stot = nw;
-            double sacc = 0;
-            for (int w = 0; w < nw; ++w) {
-                sacc += 1.0;
-                if (cur >= n_items2) { wt_.insert(wt_.end(), {n_items2, n_items2, n_items2, 0}); continue; }
-                int r0 = 0;
-                while (run_start[r0 + 1] <= cur) ++r0;
-                const int maxe = run_start[std::min(r0 + 2, nruns)];          // at most the rest of this run and the next
-                const int rem = nw - w - 1;
-                const int rmin = std::max(r0, nruns - 2 * rem);               // the rest must fit the remaining wavefronts
-                int mine = rem == 0 ? n_items2 : run_start[std::min(rmin, nruns)];
-                mine = std::max(mine, cur + 1);
-                int e = cur;
-                const double want = pre[n_items2] * sacc / stot;
-                while (e < n_items2 && pre[e + 1] <= want + 1e-9) ++e;
-                e = std::min(std::max(e, mine), maxe);
-                if (rem == 0) { e = n_items2; if (e > maxe) tile2_ok = false; }
-                const int isp = run_start[r0 + 1] < e ? run_start[r0 + 1] : e;
-                wt_.insert(wt_.end(), {cur, e, isp, woff[cur] | (woff[std::min(isp, n_items2 - 1)] << 16)});
-                cur = e;
+            int rcb;
+            if ((rcb = up(items_dev, hi8.data(), hi8.size() * 4))) return rcb;
+            // Contiguous, cost-balanced blocks of items per wavefront, each spanning at most TWO classes
+            // (kind / decimation): the kernels keep the weights of (up to) two classes in registers.
+            std::vector<int> run_start;                        // maximal runs of one class
+            for (int it = 0; it < n_items; ++it)
+                if (it == 0 || icls[it] != icls[it - 1]) run_start.push_back(it);
+            const int nruns = (int)run_start.size();
+            run_start.push_back(n_items);
+            std::vector<double> pre((size_t)n_items + 1, 0.0);
+            for (int it = 0; it < n_items; ++it) pre[it + 1] = pre[it] + cost[it];
+            std::vector<int32_t> wt_;
+            // (round 4 also sized the blocks by the wavefronts' measured speeds -- the older wavefronts of a SIMD finish the
+            // same work 10-19 % sooner -- to no effect: 221 +- 3 us for every weighting; a SIMD's total is what counts)
+            {
+                int cur = 0;
+                const double stot = nw;
+                double sacc = 0;
+                for (int w = 0; w < nw; ++w) {
+                    sacc += 1.0;
+                    if (cur >= n_items) { wt_.insert(wt_.end(), {n_items, n_items, n_items, 0}); continue; }
+                    int r0 = 0;
+                    while (run_start[r0 + 1] <= cur) ++r0;
+                    const int maxe = run_start[std::min(r0 + 2, nruns)];          // at most the rest of this run and the next
+                    const int rem = nw - w - 1;
+                    const int rmin = std::max(r0, nruns - 2 * rem);               // the rest must fit the remaining wavefronts
+                    int mine = rem == 0 ? n_items : run_start[std::min(rmin, nruns)];
+                    mine = std::max(mine, cur + 1);
+                    int e = cur;
+                    const double want = pre[n_items] * sacc / stot;
+                    while (e < n_items && pre[e + 1] <= want + 1e-9) ++e;
+                    e = std::min(std::max(e, mine), maxe);
+                    if (rem == 0) { e = n_items; if (e > maxe) ok = false; }
+                    const int isp = run_start[r0 + 1] < e ? run_start[r0 + 1] : e;
+                    wt_.insert(wt_.end(), {cur, e, isp, woff[cur] | (woff[std::min(isp, n_items - 1)] << 16)});
+                    cur = e;
+                }
+                if (cur < n_items) ok = false;
             }
-            if (cur < n_items2) tile2_ok = false;
+            return up((void**)waves_dev, wt_.data(), wt_.size() * 4);
+        };
+        if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, &items2, &wave_first2, n_items2, tile2_ok))) return rc;
+        tile3_ok = false;
+        if (cols2 == 32 && TILE_G == 4) {
+            // (SSQ_TILE3_NW = 12: both classes' weights resident at 168 registers; 16: one class, 128 registers)
+            nw3 = 16;
+            if (const char* e = getenv("SSQ_TILE3_NW")) if (atoi(e) == 12) nw3 = 12;
+            float rb3 = 0.6f;
+            if (const char* e = getenv("SSQ_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
+            if ((rc = build(4, nw3, true, rb3, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
         }
-        if ((rc = up((void**)&wave_first2, wt_.data(), wt_.size() * 4))) return rc;
     }
     {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
@@ -272,8 +286,8 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw, items2, wave_first2};
-    items2 = nullptr; wave_first2 = nullptr;
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw, items2, wave_first2, items3, wave_first3};
+    items2 = nullptr; wave_first2 = nullptr; items3 = nullptr; wave_first3 = nullptr;
     for (void* p : ptrs) if (p) (void)hipFree(p);
     steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = Y = ftw = nullptr;
     counters = nullptr;
@@ -282,15 +296,28 @@ void TilePlan::destroy() {
 // SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
 // 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
 bool tile_ordered() { return reassign_ordered(); }
+// tile3_kernel (two columns per lane): a pair of columns must start at an even padded index and both kinds of 16-byte
+// access be aligned -- n1 and N even; SSQ_TILE_PAIR=0 keeps tile2_kernel (read at every call)
+bool TilePlan::pair_ok() const {
+    if (!tile3_ok || cols2 != 32 || (n1 & 1) || (N & 1)) return false;
+    const char* e = getenv("SSQ_TILE_PAIR");
+    return !(e && atoi(e) == 0);
+}
 bool TilePlan::usable() const {
-    if (!tile_ordered() && tile2_ok) return true;
+    if (!tile_ordered() && (tile2_ok || pair_ok())) return true;
     return tile_lds_bytes(na) <= 160 * 1024;
 }
-int TilePlan::tile_cols() const { return !usable() ? 0 : (tile_ordered() || !tile2_ok) ? TILE_COLS : cols2; }
+int TilePlan::tile_kernel() const {
+    if (!usable()) return 0;
+    if (tile_ordered()) return 1;
+    return pair_ok() ? 3 : (tile2_ok ? 2 : 1);
+}
+int TilePlan::tile_cols() const { return !usable() ? 0 : (tile_ordered() || !(tile2_ok || pair_ok())) ? TILE_COLS : cols2; }
 
 int TilePlan::run(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                   const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump) {
     SSQ_REQUIRE(usable(), "na = %lld: no tile kernel can run in this mode (the executor asks usable() first)", (long long)na);
+    if (!tile_ordered() && pair_ok()) return run_pair(sig, nsig, Wx, dWx, Tx, kidx, cst, cst0, sp, stream, kdump);
     if (!tile_ordered() && tile2_ok) return run_f64(sig, nsig, Wx, dWx, Tx, kidx, cst, cst0, sp, stream, kdump);
     SSQ_REQUIRE(!kdump, "bin dump: the default tile kernel only (unset SSQ_TILE_ORDER)");
     return run_ordered(sig, nsig, Wx, dWx, Tx, kidx, cst, cst0, sp, stream);

@@ -875,7 +875,7 @@ extern "C" __attribute__((weak)) const char ssq_build_sha_value[] = "unknown";
 extern "C" {
 
 const char* ssq_build_sha(void) { return ssq_build_sha_value; }
-int ssq_version(void) { return 104; }   // 104: ssq_build_sha, ssq_cwt_plan_set_bin_dump; 103: ssq_ridge_*_batch; 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
+int ssq_version(void) { return 105; }   // 105: ssq_cwt_plan_tile_kernel; 104: ssq_build_sha, ssq_cwt_plan_set_bin_dump; 103: ssq_ridge_*_batch; 102: ssq_cwt_plan_tile_cols; 101: ssq_cwt_blocks_desc.classes has 5 columns (analytic classes)
 const char* ssq_last_error(void) { return g_last_error.c_str(); }
 
 int ssq_device_count(int* count) {

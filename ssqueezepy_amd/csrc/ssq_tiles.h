@@ -80,6 +80,13 @@ struct TilePlan {
     int n_items2 = 0, cols2 = 32;
     int lgr_max2 = 0;                       // largest decimation (log2) among the interpolated classes
     bool tile2_ok = false;                  // the items could be cut into blocks of at most two classes
+    // tile3_kernel (two columns per lane, ssq_tile_pair.hip): items of FOUR rows x 32 columns, the wavefronts' blocks
+    // for nw3 wavefronts per workgroup (12: both classes of a block resident; 16: one, re-read at a class change)
+    void* items3 = nullptr; int32_t* wave_first3 = nullptr;
+    int n_items3 = 0, nw3 = 16;
+    bool tile3_ok = false;
+    bool pair_ok() const;                   // tile3_kernel takes this plan (n1 and N even, 32-column tile, SSQ_TILE_PAIR != 0)
+    int tile_kernel() const;                // 0 none, 1 ordered, 2 tile2_kernel, 3 tile3_kernel (what `run` launches now)
     int tile_cols() const;                  // columns per tile of the kernel that `run` launches (0: none can run)
     // Can `run` launch a tile kernel for this plan in the mode selected right now? The default kernel needs the
     // items cut into blocks of at most two classes (tile2_ok), the ordered one (SSQ_TILE_ORDER=ordered, also the
@@ -117,6 +124,8 @@ struct TilePlan {
                 const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump);
     int run_ordered(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                     const void* cst, float cst0, const SsqParams& sp, hipStream_t stream);
+    int run_pair(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
+                 const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump);
     // tiles finished by the tile kernel so far (synchronises `stream`): what actually ran
     int64_t tiles_done(hipStream_t stream);
 };

@@ -43,6 +43,8 @@ typedef float ssq_f2 __attribute__((ext_vector_type(2)));
         (A).x = __builtin_fmaf((w)[t_].x, s_[t_].x, (A).x); (A).y = __builtin_fmaf((w)[t_].x, s_[t_].y, (A).y); \
         (D).x = __builtin_fmaf((w)[t_].y, s_[t_].x, (D).x); (D).y = __builtin_fmaf((w)[t_].y, s_[t_].y, (D).y); \
     } } while (0)
+#define SSQ_TAPS8X2(A0, D0, A1, D1, wa, wb, s0, s1, s2, s3, s4, s5, s6, s7) do {                                 \
+    SSQ_TAPS8(A0, D0, wa, s0, s1, s2, s3, s4, s5, s6, s7); SSQ_TAPS8(A1, D1, wb, s0, s1, s2, s3, s4, s5, s6, s7); } while (0)
 #define SSQ_BPERMUTE_OFF(d, addr, v, off) ((d) = emu_ds_bpermute((addr) + (off), (v)))
 #define SSQ_CMUL_PK(d, a, b) do { const float tx_ = (a).x * (b).x, ty_ = (a).x * (b).y;                      \
     (d).x = __builtin_fmaf(-(a).y, (b).y, tx_); (d).y = __builtin_fmaf((a).y, (b).x, ty_); } while (0)

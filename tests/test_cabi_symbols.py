@@ -25,7 +25,7 @@ def test_library_builds_loads_and_exports_header_symbols():
     # the ctypes binding covers the same set
     assert sorted(_lib.EXPORTS) == declared
     lib.ssq_version.restype = ctypes.c_int
-    assert lib.ssq_version() >= 104
+    assert lib.ssq_version() >= 105
 
 
 def test_product_path_never_imports_the_oracle():
