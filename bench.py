@@ -301,8 +301,10 @@ def main():
                        "sharding": "independent signals per rank, no data-path "
                                    "collective; one all_gather of checksums",
                        "algo": plan.algo, "build_sha": build_sha,
-                       "tile_kernel": ("ordered (ticketed float32 tile)" if os.environ.get('SSQ_TILE_ORDER') == 'ordered'
-                                       else "float64 tile, unordered ds_add_f64") if 'tiles' in plan.algo else None},
+                       "tile_kernel": {1: "ordered (ticketed float32 tile)",
+                                       2: "float64 tile, unordered ds_add_f64, one column per lane (tile2_kernel)",
+                                       3: "float64 tile, unordered ds_add_f64, column pair per lane (tile3_kernel)"
+                                       }.get(plan.tile_kernel) if 'tiles' in plan.algo else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_measured_at": traffic_sha,
@@ -323,7 +325,7 @@ def main():
             if tiles:
                 # the column-tile kernel: writes Wx of the rows it interpolates and all of Tx,
                 # reads Wx + 2-byte bin of the rows the block / exact kernels left in HBM
-                kname = "ssq::tile_kernel" if os.environ.get('SSQ_TILE_ORDER') == 'ordered' else "ssq::tile2_kernel"
+                kname = {1: "ssq::tile_kernel", 2: "ssq::tile2_kernel", 3: "ssq::tile3_kernel"}.get(plan.tile_kernel, "?")
                 acc_bytes = N * (plan.tile_rows * 8 + na * 8 + (na - plan.tile_rows) * 10)
             else:
                 # the reassignment: Wx (8 B) + bin map (2 B) in and Tx (8 B) out per point

@@ -348,6 +348,10 @@ int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
  * column pair per lane (tile3_kernel: the default whenever the signal's length and its left padding are even and
  * the tile holds 32 columns; SSQ_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
 int  ssq_cwt_plan_tile_kernel(const ssq_cwt_plan* plan);
+/* Diagnostic (ABI 105): the first `n` (<= 512) 64-bit words of the tile path's counter block -- word 0 = tiles done (as
+ * above); words 64.. = per-wavefront shader-clock sums per phase of workgroup 0, filled by profiling builds of the tile
+ * kernel only (-DSSQ_T3_PROF=1, tools/r6), zero otherwise. Synchronises `stream`. */
+int  ssq_cwt_plan_tile_counters(ssq_cwt_plan* plan, unsigned long long* out, int n, void* stream);
 
 /* Diagnostic (tests; not needed by a caller of the transforms): from now on every fused execute
  * (Tx requested, bins from dWx) also writes the bin index of every point AS THE REASSIGNMENT CONSUMED

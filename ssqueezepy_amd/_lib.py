@@ -122,6 +122,7 @@ _PROTOS = {
     'ssq_cwt_plan_tiles_done': (c_int64, [c_void_p, c_void_p]),
     'ssq_cwt_plan_tile_cols': (c_int, [c_void_p]),
     'ssq_cwt_plan_tile_kernel': (c_int, [c_void_p]),
+    'ssq_cwt_plan_tile_counters': (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     'ssq_cwt_plan_set_bin_dump': (c_int, [c_void_p, c_void_p]),
     'ssq_build_sha': (c_char_p, []),
     'ssq_cwt_tile_rows_per_step': (c_int, []),

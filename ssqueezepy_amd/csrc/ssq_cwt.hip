@@ -373,6 +373,14 @@ int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* pl, void* stream) {
     return pl->tile->tiles_done(as_stream(stream));
 }
 int ssq_cwt_plan_tile_cols(const ssq_cwt_plan* pl) { return (pl && pl->tile) ? pl->tile->tile_cols() : 0; }
+int ssq_cwt_plan_tile_counters(ssq_cwt_plan* pl, unsigned long long* out, int n, void* stream) {
+    SSQ_REQUIRE(pl && out && n >= 0 && n <= 512, "ssq_cwt_plan_tile_counters: bad arguments");
+    memset(out, 0, (size_t)n * 8);
+    if (!pl->tile || !pl->tile->counters) return 0;
+    SSQ_CHECK_HIP(hipStreamSynchronize(as_stream(stream)));
+    SSQ_CHECK_HIP(hipMemcpy(out, pl->tile->counters, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
 int ssq_cwt_plan_tile_kernel(const ssq_cwt_plan* pl) { return (pl && pl->tile) ? pl->tile->tile_kernel() : 0; }
 int64_t ssq_cwt_plan_bytes(const ssq_cwt_plan* pl) { return pl ? pl->bytes : 0; }
 const char* ssq_cwt_plan_algo(const ssq_cwt_plan* pl) { return pl ? pl->algo.c_str() : ""; }

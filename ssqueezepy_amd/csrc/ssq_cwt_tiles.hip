@@ -98,8 +98,10 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         for (int i = 0; i < nsegs; ++i) if (sg[i].kind) lgr_max2 = std::max(lgr_max2, (int)sg[i].lgR);
         // (what a row read back costs next to an interpolated one when the rows are dealt to the wavefronts; measured
         // 0.5 .. 1.2: 221 / 223 / 222 / 228 / 225 us, round 4)
-        auto build = [&](int rpi, int nw, bool woff_in_record, float rb_cost, void** items_dev, int32_t** waves_dev,
-                         int& n_items, bool& ok) -> int {
+        // chg_cost < 0: tile2_kernel's contiguous blocks; >= 0: tile3_kernel's dealt lists (see below), a class change
+        // inside a wavefront's list costing that many items (max_cls = 2: both classes' weights resident, no cost)
+        auto build = [&](int rpi, int nw, bool woff_in_record, float rb_cost, float chg_cost, int max_cls,
+                         void** items_dev, int32_t** waves_dev, int& n_items, bool& ok) -> int {
             SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
             n_items = nsteps * TILE_G / rpi;
             std::vector<int32_t> hi8((size_t)n_items * 8, 0);
@@ -133,6 +135,109 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                 }
             }
             int rcb;
+            if (chg_cost >= 0.f) {
+                // tile3_kernel: per-wavefront LISTS instead of contiguous row blocks. Round 6's stamps showed the
+                // wavefronts waiting 22 % of their time at the tile's end for the slowest of them (4-row items: a block
+                // is 4 or 5 items, a class change costs 0.65 of one, rows read back 0.45). So:
+                //   1. the interpolated items, class by class, are cut into `nw` chunks minimising the largest
+                //      (a chunk of several classes pays `chg_cost` per class: the weights are re-read per tile);
+                //   2. the items of rows read back need no weights: each goes to the wavefront with the least work;
+                //   3. the wavefronts w, w + 4, w + 8, ... share a SIMD: the lists are dealt so that the SIMDs' sums agree;
+                //   4. the item table is permuted so that a wavefront's list is contiguous (chunk, then rows read back).
+                std::vector<int> iin, irb;
+                for (int it = 0; it < n_items; ++it) (icls[it] ? iin : irb).push_back(it);
+                const int ni = (int)iin.size();
+                auto chunk_cost = [&](int a, int b) -> double {        // interpolated items [a, b) of `iin`
+                    if (b <= a) return 0.0;
+                    int ncl = 1;
+                    for (int j = a + 1; j < b; ++j) if (icls[iin[j]] != icls[iin[j - 1]]) ++ncl;
+                    if (ncl > max_cls) return 1e30;
+                    return (double)(b - a) + (ncl > 1 && max_cls > 2 ? chg_cost * ncl : 0.0);
+                };
+                // (the wavefronts of a SIMD do not run at one speed: the arbiter serves the oldest first, and the stamps show the
+                // youngest taking a third longer per item. speed[w]: what wavefront w gets done relative to the mean, by its
+                // age rank w / 4 -- chunk k goes to wavefront k, and "largest" above means largest time = cost / speed.)
+                // (measured at config 2, one box: skew 0 / 0.1 / 0.2 / 0.3 -> 193-196 / 187 / 184-186 / 191 us with 16 wavefronts;
+                // no gain with 12)
+                float skew = nw == 16 ? 0.2f : 0.f;
+                if (const char* e = getenv("SSQ_TILE3_SKEW")) skew = (float)atof(e);
+                std::vector<double> speed(nw, 1.0);
+                {
+                    const int nr = nw / 4;
+                    for (int w = 0; w < nw; ++w) speed[w] = 1.0 + skew * (nr > 1 ? 1.0 - 2.0 * (w / 4) / (double)(nr - 1) : 0.0);
+                }
+                std::vector<std::vector<double>> f(nw + 1, std::vector<double>(ni + 1, 1e30));
+                std::vector<std::vector<int>> arg(nw + 1, std::vector<int>(ni + 1, 0));
+                f[0][0] = 0.0;
+                for (int k = 1; k <= nw; ++k)
+                    for (int j = 0; j <= ni; ++j)
+                        for (int a = 0; a <= j; ++a) {
+                            if (f[k - 1][a] >= 1e30) continue;
+                            const double c = std::max(f[k - 1][a], chunk_cost(a, j) / speed[k - 1]);
+                            // (ties: the later cut -- chunks of equal size rather than one long and one empty)
+                            if (c < f[k][j] - 1e-12 || (c <= f[k][j] + 1e-12 && a >= arg[k][j])) { f[k][j] = c; arg[k][j] = a; }
+                        }
+                if (f[nw][ni] >= 1e30) ok = false;
+                std::vector<std::vector<int>> lists(nw);
+                std::vector<double> load(nw, 0.0);
+                if (ok) {
+                    int j = ni;
+                    for (int k = nw; k >= 1; --k) {
+                        const int a = arg[k][j];
+                        for (int q = a; q < j; ++q) lists[k - 1].push_back(iin[q]);
+                        load[k - 1] = chunk_cost(a, j);
+                        j = a;
+                    }
+                    for (int it : irb) {
+                        int best = 0;
+                        for (int w = 1; w < nw; ++w)
+                            if ((load[w] + rb_cost) / speed[w] < (load[best] + rb_cost) / speed[best] - 1e-12) best = w;
+                        lists[best].push_back(it);
+                        load[best] += rb_cost;
+                    }
+                }
+                // the SIMDs: heaviest list first, each to the SIMD with the least work that still has a slot
+                const int nsimd = 4, per = nw / nsimd;
+                std::vector<int> order(nw), slot_of(nw, -1);
+                for (int w = 0; w < nw; ++w) order[w] = w;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return load[a] > load[b]; });
+                std::vector<double> ssum(nsimd, 0.0);
+                std::vector<int> scnt(nsimd, 0);
+                for (int w : order) {
+                    int g = -1;
+                    for (int q = 0; q < nsimd; ++q) if (scnt[q] < per && (g < 0 || ssum[q] < ssum[g] - 1e-12)) g = q;
+                    slot_of[w] = scnt[g] * nsimd + g;
+                    ssum[g] += load[w]; ++scnt[g];
+                }
+                if (skew != 0.f) for (int w = 0; w < nw; ++w) slot_of[w] = w;      // (the speeds were the slots')
+                std::vector<int32_t> hp((size_t)n_items * 8, 0), wrec((size_t)nw * 4, 0);
+                int pos = 0;
+                std::vector<int> list_of_slot(nw, 0);
+                for (int w = 0; w < nw; ++w) list_of_slot[slot_of[w]] = w;
+                for (int sl = 0; sl < nw; ++sl) {
+                    const std::vector<int>& L = lists[list_of_slot[sl]];
+                    const int first = pos;
+                    int isp = -1;
+                    for (size_t q = 0; q < L.size(); ++q) {
+                        if (q > 0 && icls[L[q]] && icls[L[q - 1]] && icls[L[q]] != icls[L[q - 1]] && isp < 0) isp = pos;
+                        memcpy(&hp[(size_t)pos * 8], &hi8[(size_t)L[q] * 8], 32);
+                        ++pos;
+                    }
+                    // (isp: the first item of the list's second class -- or of its rows read back, or its end)
+                    int e_int = first;
+                    for (size_t q = 0; q < L.size(); ++q) if (icls[L[q]]) e_int = first + (int)q + 1;
+                    if (isp < 0) isp = e_int;
+                    wrec[4 * sl] = first; wrec[4 * sl + 1] = pos; wrec[4 * sl + 2] = isp; wrec[4 * sl + 3] = 0;
+                }
+                if (pos != n_items) ok = false;
+                if (getenv("SSQ_TILE_PLAN_PRINT")) {
+                    for (int sl = 0; sl < nw; ++sl)
+                        fprintf(stderr, "tile3 wave %2d (simd %d): items %3d..%3d second class at %3d, load %.2f\n", sl, sl % nsimd,
+                                wrec[4 * sl], wrec[4 * sl + 1], wrec[4 * sl + 2], load[list_of_slot[sl]]);
+                }
+                if ((rcb = up(items_dev, hp.data(), hp.size() * 4))) return rcb;
+                return up((void**)waves_dev, wrec.data(), wrec.size() * 4);
+            }
             if ((rcb = up(items_dev, hi8.data(), hi8.size() * 4))) return rcb;
             // Contiguous, cost-balanced blocks of items per wavefront, each spanning at most TWO classes
             // (kind / decimation): the kernels keep the weights of (up to) two classes in registers.
@@ -173,15 +278,18 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
             }
             return up((void**)waves_dev, wt_.data(), wt_.size() * 4);
         };
-        if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, &items2, &wave_first2, n_items2, tile2_ok))) return rc;
+        if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, -1.f, 2, &items2, &wave_first2, n_items2, tile2_ok))) return rc;
         tile3_ok = false;
         if (cols2 == 32 && TILE_G == 4) {
             // (SSQ_TILE3_NW = 12: both classes' weights resident at 168 registers; 16: one class, 128 registers)
             nw3 = 16;
             if (const char* e = getenv("SSQ_TILE3_NW")) if (atoi(e) == 12) nw3 = 12;
-            float rb3 = 0.6f;
+            // (measured with shader-clock stamps, round 6: an item of rows read back costs 0.45 of an interpolated one,
+            // re-reading a class's weights 0.65)
+            float rb3 = 0.45f, chg3 = 0.65f;
             if (const char* e = getenv("SSQ_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
-            if ((rc = build(4, nw3, true, rb3, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
+            if (const char* e = getenv("SSQ_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
+            if ((rc = build(4, nw3, true, rb3, chg3, nw3 == 12 ? 2 : 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
         }
     }
     {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]

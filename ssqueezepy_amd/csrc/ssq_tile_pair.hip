@@ -40,12 +40,23 @@ namespace ssq {
 #include "ssq_tile_dev.h"
 
 constexpr int T3_COLS = 32, T3_RPI = 4, T3_LGC = 5;
+#ifndef SSQ_T3_PROF
+#define SSQ_T3_PROF 0      // shader-clock stamps per phase (workgroup 0 -> A.counters + 64): tools/r6/gpu_e.sh
+#endif
+#if SSQ_T3_PROF
+#define T3_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define T3_STAMP(i) ((void)0)
+#endif
+#ifndef SSQ_T3_ABL
+#define SSQ_T3_ABL 0       // ablation builds (timing only, wrong results): see tools/r6/gpu_c.sh
+#endif
 typedef float ssq_f4u __attribute__((ext_vector_type(4), aligned(8)));     // 16 bytes at an 8-byte boundary (samples)
 
 struct Tile3Args {
     const int* items;        // [n_items][8]: row0 | npad << 9 | kind << 12 | lgR << 13 | weights' offset << 18, samples'
                              // offset of sub-row 0 (class + row), row0 * N * 8, entries between two signals' rows of
-                             // the class, kc of the four sub-rows
+                             // the class (these four: scalar loads), kc of the four sub-rows (read per lane)
     const int4* waves;       // [NW]: first item, end, first item of the wavefront's second class (= end: none), 0
     const float4* wtab; const float2* U;
     const void* cst;
@@ -106,8 +117,12 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - bid + G - 1) / G) : per_sig * A.nsig;
     const auto* waves = SSQ_CONST_PTR(int4, A.waves);
     const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
+#if SSQ_T3_PROF
+    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     int prio = (wv >> 2) & 1;
-    auto rotate_priority = [&]() { SSQ_PRIO_TOGGLE(prio); };   // (two levels, swapped with every item: see tile2_kernel)
+    auto rotate_priority = [&]() { if (!(SSQ_T3_ABL & 256)) SSQ_PRIO_TOGGLE(prio); };   // (two levels, swapped with every item: see tile2_kernel)
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
@@ -119,7 +134,9 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     // tile free again (barrier). A lane takes its column pair of a row: four LDS reads, one 16-byte store; a wavefront
     // instruction = 4 rows.
     auto finish_tile = [&](int tx, int sg) {
+        T3_STAMP(6);
         SSQ_WG_BARRIER();
+        T3_STAMP(7);
         float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
         constexpr int NA_CAP = 320;
         constexpr int ROUNDS = (NA_CAP + RR - 1) / RR;
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
                 SSQ_OPAQUE_S(fr); SSQ_OPAQUE_S(step);          // (re-read as scalars at every use: see tile2_kernel)
                 if (m < fr) {                                  // (wave-uniform)
                     const float4 v = take(k0 + m * RR);
-                    *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
+                    if (!(SSQ_T3_ABL & 512) || v.x == 123.25f) *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
                     tb += step;
                     asm volatile("" ::: "memory");             // (keeps the rounds from being batched into registers)
                 }
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             {   // the last round: the rows left, and the scratch row cleared by the lanes past them
                 const int k = k0 + fr * RR;
                 const float4 v = take(k < na ? k : na);
-                if (k < na) *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
+                if (k < na && (!(SSQ_T3_ABL & 512) || v.x == 123.25f)) *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
             }
         } else {
             const unsigned col = (unsigned)(tx * COLS + cp * 2);      // (N even: a pair exists or does not)
@@ -165,7 +182,9 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
         }
         if (threadIdx.x == 0 && A.counters)
             __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
+        T3_STAMP(8);
         SSQ_WG_BARRIER();
+        T3_STAMP(9);
     };
 
     if (ni <= 0) {                                             // more wavefronts than items: write-outs only
@@ -195,8 +214,12 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
         return (wrap && r.sg >= A.nsig) ? q : r;               // (the tile after the last: the last)
     };
     const int total = ntl * ni;                                // positions of this wavefront
-    typedef int int8v __attribute__((ext_vector_type(8)));
-    const auto* items = SSQ_CONST_PTR(int8v, A.items);
+    // (a record's first four words through the scalar cache; its last four -- the sub-rows' centre bins -- are read per lane
+    // with the position's data, see load_data)
+    typedef int int8v __attribute__((ext_vector_type(4)));
+    struct alignas(32) Rec { int8v lo, hi; };
+    const auto* recs = SSQ_CONST_PTR(Rec, A.items);
+    auto items_at = [&](int it) { return recs[it].lo; };
     // per-lane constants of the addresses: the lane's place inside an item's rows
     const unsigned lane_row16 = ((unsigned)h * nN + (unsigned)cp * 2u) * 8u;   // bytes: sub-row h, first column of the pair
     const unsigned lane_col16 = (unsigned)cp * 16u;
@@ -207,12 +230,14 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     const char* const U8 = reinterpret_cast<const char*>(A.U);
     const char* const WX8 = reinterpret_cast<const char*>(A.Wx) + (size_t)((int64_t)A.sig0 * na * N) * 8u;
     const char* const KX8 = reinterpret_cast<const char*>(A.kidx);
-    auto load_data = [&](const int8v R, const Pos& q) {
+    const unsigned lane_h4 = (unsigned)h * 4u;
+    auto load_data = [&](const int8v R, int it, const Pos& q) {
         Data d;
         const int w0 = R[0];
         const int kind = (w0 >> 12) & 1;
         const char* base; unsigned voff;
-        const char* kbase = reinterpret_cast<const char*>(A.items); unsigned koff = (unsigned)(lane & 7) * 4u;
+        // (interpolated rows: the lane's second load fetches the centre bin of its sub-row -- words 4 .. 7 of the item's record)
+        const char* kbase = reinterpret_cast<const char*>(A.items) + (size_t)(unsigned)it * 32u + 16u; unsigned koff = lane_h4;
         if (kind) {                                            // (wave-uniform; the loads themselves stay outside)
             // sample (qb + cp) mod L of row h of the item, h * L entries on: the 16 lanes of a sub-row hold the
             // window every column of the tile takes its eight taps from ((31 >> lgR) + 8 <= 15 for R >= 4)
@@ -237,8 +262,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             koff = lr >> 2;
         }
         d.u = *reinterpret_cast<const ssq_f4u*>(base + (size_t)voff);
-        // (the bins: a load either way, from a harmless address for interpolated rows -- a conditional load costs the
-        // compiler its count of loads in flight)
+        // (one load either way: the bins of rows read back, the centre bin of an interpolated sub-row)
         d.kq = (int)*reinterpret_cast<const unsigned*>(kbase + (size_t)koff);
         return d;
     };
@@ -258,11 +282,11 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     ssq_f2 wa0[TILE_W], wb0[TILE_W], wa1[WT2 ? TILE_W : 1], wb1[WT2 ? TILE_W : 1];
     int wcls = -1;                                             // (!WT2) the class whose weights are resident: w0 >> 13
     if constexpr (WT2) {
-        load_wt(wa0, wb0, items[i0][0]);
-        load_wt(wa1, wb1, items[isp < i1 ? isp : i0][0]);
+        load_wt(wa0, wb0, items_at(i0)[0]);
+        load_wt(wa1, wb1, items_at(isp < i1 ? isp : i0)[0]);
     } else {
-        int wsel = items[i0][0];                               // (a block that opens with rows read back: its second class)
-        if (!((wsel >> 12) & 1) && isp < i1) wsel = items[isp][0];
+        int wsel = items_at(i0)[0];                               // (a block that opens with rows read back: its second class)
+        if (!((wsel >> 12) & 1) && isp < i1) wsel = items_at(isp)[0];
         load_wt(wa0, wb0, wsel);
         wcls = wsel >> 13;
     }
@@ -276,13 +300,17 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     bool tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;   // the arithmetic's tile is a signal's last, partial one
     int left = total;                                          // positions not yet finished
     auto step_loads = [&]() { if (++it_l >= i1) { it_l = i0; tl = next_tile(tl); } };
-    int8v Rc = items[i0];
-    D[0] = load_data(Rc, tl);
+    int8v Rc = items_at(i0);
+    // (the ring's slots are loaded in the order the loop leaves them at its back edge -- slot 2 oldest, then 0, then 1:
+    // the compiler merges the two states at the loop's head per register, and with slot 2 the youngest here the first
+    // body waited for all but one of the loads in flight -- s_waitcnt vmcnt(1) -- before it reused slot 2's registers.
+    // Slot 2 gets position 0 again, a load like the loop's; its data are never used.)
+    D[2] = load_data(Rc, i0, tc);
+    D[0] = load_data(Rc, i0, tl);
     step_loads();
-    D[1] = load_data(items[it_l], tl);
+    D[1] = load_data(items_at(it_l), it_l, tl);
     step_loads();
-    D[2] = load_data(Rc, tc);                                  // (a load like the loop's: see tile2_kernel)
-    int8v Rn = items[it_l];
+    int8v Rn = items_at(it_l);
     w_t csn[RPI];
     auto load_cs = [&](int row0) {
         if (CSTK != 0) {
@@ -293,21 +321,27 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     load_cs(Rc[0] & 0x1FF);
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
-    bool more = true;
     auto body = [&](auto KK) {
         constexpr int k0 = decltype(KK)::value, k2 = (k0 + 2) % 3;
         const Pos pc = tc;
         rotate_priority();
-        D[k2] = load_data(Rn, tl);                             // the data of p + 2
+        T3_STAMP(0);
+        D[k2] = load_data(Rn, it_l, tl);                       // the data of p + 2
         step_loads();
+        T3_STAMP(1);
+#if SSQ_T3_PROF
+        SSQ_OPAQUE_V(D[k0].u); SSQ_OPAQUE_V(D[k0].kq);
+        T3_STAMP(2);
+#endif
         const Data dc = D[k0];
         const int w0 = Rc[0];
         const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
         const int nabs = pc.nabs0 + cp * 2;                    // (lanes past the last column: results unused)
         // (every lane's points count, except in a class's last item -- padded sub-rows -- and in the last tile of a
         // signal when N is not a multiple of the tile: a wave-uniform test keeps the rest free)
+        const bool alive = left > 0;                          // (past the wavefront's last position: see the loop below)
         bool livept = true;
-        if ((w0 & 0xE00) != 0 || tc_last) livept = h < RPI - npad && nabs - A.n1 < (int)N;
+        if ((w0 & 0xE00) != 0 || tc_last || !alive) livept = alive && h < RPI - npad && nabs - A.n1 < (int)N;
         int cell0, cell1; float t0x, t0y, t1x, t1y;
         if (kind == 0) {
             const int ka = dc.kq & 0xFFFF, kb = (int)((unsigned)dc.kq >> 16);
@@ -326,6 +360,10 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             {
                 int fr[TILE_W], fi[TILE_W];
                 int ur = __float_as_int(dc.u.x), ui = __float_as_int(dc.u.y);
+#if SSQ_T3_ABL & 1
+#pragma unroll
+                for (int t = 0; t < TILE_W; ++t) { fr[t] = ur + t + baddr; fi[t] = ui + t; }
+#else
                 SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
                 SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
                 SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
@@ -335,10 +373,14 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
                 SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
                 SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                 SSQ_LDS_WAIT();
+#endif
                 // (A = (a_re, a_im), D = (a'_re, a'_im) of the pair's two columns: what the modulation multiplies)
                 ssq_f2 sv[TILE_W];
 #pragma unroll
                 for (int t = 0; t < TILE_W; ++t) { sv[t].x = __int_as_float(fr[t]); sv[t].y = __int_as_float(fi[t]); }
+#if SSQ_T3_ABL & 2
+                A0 = sv[0] + sv[1] * wa0[0] + sv[4]; D0 = sv[2] + sv[5]; A1 = sv[3] + sv[6] * wb0[1]; D1 = sv[7];
+#else
                 if constexpr (WT2) {
                     if (it_c < isp) {   // (wave-uniform: the wavefront's first or second class)
                         SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
@@ -348,10 +390,10 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
                 } else {
                     SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
                 }
+#endif
             }
-            int kcs = Rc[4];                                   // centre bin of the lane's row
-#pragma unroll
-            for (int k = 1; k < RPI; ++k) if (h == k) kcs = Rc[4 + k];
+            T3_STAMP(3);
+            const int kcs = dc.kq;                             // centre bin of the lane's row
             const float theta = (float)kcs * A.theta_scale;
             // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
             D0.x = __builtin_fmaf(-theta, A0.y, D0.x);
@@ -363,28 +405,37 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             const unsigned ph1 = (ph0 + (unsigned)kcs) & (unsigned)A.mmask;
             const float rev0 = (float)ph0 * A.inv_m, rev1 = (float)ph1 * A.inv_m;
             ssq_f2 tw0, tw1, W0, V0, W1, V1;
+#if SSQ_T3_ABL & 4
+            W0 = A0 + rev0; W1 = A1 + rev1; V0 = D0; V1 = D1;
+#else
             tw0.x = __builtin_amdgcn_cosf(rev0); tw0.y = __builtin_amdgcn_sinf(rev0);
             tw1.x = __builtin_amdgcn_cosf(rev1); tw1.y = __builtin_amdgcn_sinf(rev1);
             SSQ_CMUL_PK(W0, tw0, A0);
             SSQ_CMUL_PK(W1, tw1, A1);
             SSQ_CMUL_PK(V0, tw0, D0);
             SSQ_CMUL_PK(V1, tw1, D1);
+#endif
             // (lanes past the last column hold other columns' weights, padded sub-rows another row's samples: their
             // values go nowhere)
             char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off8 + (unsigned)Rc[2]);
             float4 Wq; Wq.x = W0.x; Wq.y = W0.y; Wq.z = W1.x; Wq.w = W1.y;
-            if (livept) *reinterpret_cast<float4*>(wx8 + (size_t)lane_row16) = Wq;
+            if (livept && (!(SSQ_T3_ABL & 8) || Wq.x == 123.25f)) *reinterpret_cast<float4*>(wx8 + (size_t)lane_row16) = Wq;
             if (STORE_D) {
                 char* dwx8 = reinterpret_cast<char*>(A.dWx) + ((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]);
                 float4 Vq; Vq.x = V0.x; Vq.y = V0.y; Vq.z = V1.x; Vq.w = V1.y;
                 if (livept) *reinterpret_cast<float4*>(dwx8 + (size_t)lane_row16) = Vq;
             }
+            T3_STAMP(4);
             // phase transform and bin: as emit_point<LEAN> of the block kernels, per column
+#if SSQ_T3_ABL & 16
+            int ko0 = (__float_as_int(W0.x + V0.y) & 63) + h, ko1 = (__float_as_int(W1.y + V1.x) & 63) + h;
+#else
             bool pend0, pend1;
             int ko0 = pair_bin<GRID>(W0, V0, livept, m2hi, m2lo, sp, omax, fx, fa, pend0);
             int ko1 = pair_bin<GRID>(W1, V1, livept, m2hi, m2lo, sp, omax, fx, fa, pend1);
             if (pend0) ko0 = exact_bin(make_float2(W0.x, W0.y), make_float2(V0.x, V0.y), sp, omax, A.gamma);
             if (pend1) ko1 = exact_bin(make_float2(W1.x, W1.y), make_float2(V1.x, V1.y), sp, omax, A.gamma);
+#endif
             cell0 = ko0 >= 0 ? ko0 * 512 + c8 : scratch8;
             cell1 = ko1 >= 0 ? ko1 * 512 + c8 : scratch8;
             t0x = W0.x; t0y = W0.y; t1x = W1.x; t1y = W1.y;
@@ -403,34 +454,60 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             }
             const double a0 = (double)TM::make(t0x, cs), b0 = (double)TM::make(t0y, cs);
             const double a1 = (double)TM::make(t1x, cs), b1 = (double)TM::make(t1y, cs);
+#if SSQ_T3_ABL & 32
+            if (a0 + b0 + a1 + b1 == 123.25 + (double)(cell0 ^ cell1)) SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
+#else
             SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
             SSQ_LDS_ADD_F64_AT(cell0, 256, b0);
             SSQ_LDS_ADD_F64_AT(cell1, 128, a1);
             SSQ_LDS_ADD_F64_AT(cell1, 384, b1);
+#endif
         }
-        more = --left > 0;
-        const bool tile_end = ++it_c >= i1;                    // (the block's last item: the tile is complete)
+        T3_STAMP(5);
+        --left;
+        const bool tile_end = alive && ++it_c >= i1;           // (the block's last item: the tile is complete)
         if (tile_end) it_c = i0;
-        Rc = items[it_c];                                      // the next position's records
-        Rn = items[it_l];
+        Rc = items_at(it_c);                                      // the next position's records
+        Rn = items_at(it_l);
         load_cs(Rc[0] & 0x1FF);                                // ... and its rows' weights, when there is one per row
+#if SSQ_T3_PROF
+        SSQ_OPAQUE_S(Rc[0]); SSQ_OPAQUE_S(Rn[0]);
+        T3_STAMP(10);
+#endif
         if constexpr (!WT2) {
             // the next position is of another class: its weights replace the ones in hand (512 bytes per lane out of
             // the L2 -- at most twice per tile and wavefront, the host cuts the row blocks that way)
             const int wn = Rc[0];
-            if (((wn >> 12) & 1) && (wn >> 13) != wcls) { load_wt(wa0, wb0, wn); wcls = wn >> 13; }
+            if (((wn >> 12) & 1) && (wn >> 13) != wcls) {
+                load_wt(wa0, wb0, wn); wcls = wn >> 13;
+                // (the weights are waited for HERE, inside the rare branch: left pending, every item's taps would wait
+                // for all loads older than the newest data -- s_waitcnt vmcnt(2) -- whether a class changed or not)
+#pragma unroll
+                for (int t = 0; t < TILE_W; ++t) { SSQ_OPAQUE_V(wa0[t]); SSQ_OPAQUE_V(wb0[t]); }
+            }
         }
         if (tile_end) {
-            finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg);
+            if (!(SSQ_T3_ABL & 64) || left <= 0) finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg);
             tc = next_tile(tc);
             tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;
         }
     };
-    for (;;) {
-        body(K0{}); if (!more) break;
-        body(K1{}); if (!more) break;
-        body(K2{}); if (!more) break;
+    // Whole turns of the ring, ONE back edge: with an exit behind every body the compiler's control flow has edges from
+    // the middle of a turn to the loop's head, the count of loads in flight it can rely on there drops to one, and the
+    // first body of every turn drained the prefetch (s_waitcnt vmcnt(1)). The up to two positions past the
+    // wavefront's last are dead: valid loads, no lane alive, no tile end.
+    for (int turn = (total + 2) / 3; turn > 0; --turn) {
+        body(K0{});
+        body(K1{});
+        body(K2{});
     }
+#if SSQ_T3_PROF
+    T3_STAMP(11);
+    if (blockIdx.x == 0 && lane == 0 && A.counters) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) A.counters[64 + wv * 12 + i] += prof[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------- host side
