@@ -334,7 +334,8 @@ int  ssq_cwt_plan_group(const ssq_cwt_plan* plan);
 
 /* What executed: the number of column tiles the column-tile kernel has finished on this plan
  * since its creation (0 without tile tables). Synchronises `stream`. An execute that took the
- * tile path adds batch * ceil(n / ssq_cwt_plan_tile_cols(plan)); one that took the block path +
+ * tile path adds batch * ceil(n / ssq_cwt_plan_tile_cols(plan)) (tile kernel 3 with an odd left padding: ceil((n + 1) /
+ * 32) -- its tiles start one column early); one that took the block path +
  * separate reassignment adds nothing. (Tests assert on this rather than on the plan's `algo`
  * label.) */
 int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
@@ -345,8 +346,8 @@ int64_t ssq_cwt_plan_tiles_done(ssq_cwt_plan* plan, void* stream);
 int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
 /* Which column-tile kernel the next execute launches (ABI 105): 0 none, 1 the ordered float32 tile
  * (SSQ_TILE_ORDER=ordered), 2 the float64 tile with one column per lane (tile2_kernel), 3 the float64 tile with a
- * column pair per lane (tile3_kernel: the default whenever the signal's length and its left padding are even and
- * the tile holds 32 columns; SSQ_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
+ * column pair per lane (tile3_kernel: the default whenever the tile holds 32 columns, i.e. up to 318 rows;
+ * SSQ_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
 int  ssq_cwt_plan_tile_kernel(const ssq_cwt_plan* plan);
 /* Diagnostic (ABI 105): the first `n` (<= 512) 64-bit words of the tile path's counter block -- word 0 = tiles done (as
  * above); words 64.. = per-wavefront shader-clock sums per phase of workgroup 0, filled by profiling builds of the tile

@@ -238,7 +238,11 @@ class CwtPlan():
         self._kdump = kmap
 
     def tiles_per_signal(self, N):
-        return -(-int(N) // self.tile_cols) if self.tile_cols else 0
+        if not self.tile_cols:
+            return 0
+        # (the pair kernel's tiles start a column early when the left padding is odd: csrc/ssq_tile_pair.hip)
+        lead = (self.n1 & 1) if self.tile_kernel == 3 else 0
+        return -(-(int(N) + lead) // self.tile_cols)
 
     @property
     def device_bytes(self):

@@ -281,15 +281,12 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, -1.f, 2, &items2, &wave_first2, n_items2, tile2_ok))) return rc;
         tile3_ok = false;
         if (cols2 == 32 && TILE_G == 4) {
-            // (SSQ_TILE3_NW = 12: both classes' weights resident at 168 registers; 16: one class, 128 registers)
-            nw3 = 16;
-            if (const char* e = getenv("SSQ_TILE3_NW")) if (atoi(e) == 12) nw3 = 12;
             // (measured with shader-clock stamps, round 6: an item of rows read back costs 0.45 of an interpolated one,
             // re-reading a class's weights 0.65)
             float rb3 = 0.45f, chg3 = 0.65f;
             if (const char* e = getenv("SSQ_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
             if (const char* e = getenv("SSQ_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
-            if ((rc = build(4, nw3, true, rb3, chg3, nw3 == 12 ? 2 : 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
+            if ((rc = build(4, TILE3_NW, true, rb3, chg3, 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
         }
     }
     {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]
@@ -404,10 +401,10 @@ void TilePlan::destroy() {
 // SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
 // 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
 bool tile_ordered() { return reassign_ordered(); }
-// tile3_kernel (two columns per lane): a pair of columns must start at an even padded index and both kinds of 16-byte
-// access be aligned -- n1 and N even; SSQ_TILE_PAIR=0 keeps tile2_kernel (read at every call)
+// tile3_kernel (two columns per lane): 32-column tiles (up to 318 rows); SSQ_TILE_PAIR=0 keeps tile2_kernel (read at
+// every call)
 bool TilePlan::pair_ok() const {
-    if (!tile3_ok || cols2 != 32 || (n1 & 1) || (N & 1)) return false;
+    if (!tile3_ok || cols2 != 32 || N < 64) return false;
     const char* e = getenv("SSQ_TILE_PAIR");
     return !(e && atoi(e) == 0);
 }

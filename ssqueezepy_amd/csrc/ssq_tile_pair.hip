@@ -17,17 +17,18 @@
 //   * the two columns' chains (taps -> modulation -> phase transform -> bin -> ds_add_f64) are independent: the SIMD
 //     has two instructions to choose from per wavefront instead of one;
 //   * Wx leaves as one 16-byte store per lane, the tile's write-out as 16 bytes per lane too.
-// A lane's weights now depend on two column phases: 32 registers per class. WT2 = true keeps the (up to) two classes
-// of a wavefront's row block resident (64 registers: 12 wavefronts per workgroup at 168 registers); WT2 = false keeps
-// the class in hand only and re-reads 512 bytes per lane at a class change (16 wavefronts at 128 registers).
+// A lane's weights now depend on two column phases: 32 registers per class. The kernel keeps the class in hand only and
+// re-reads 512 bytes per lane at a class change (16 wavefronts at 123 registers); the host deals the items so that few
+// wavefronts hold more than one class (ssq_cwt_tiles.hip). Measured beside it and dropped: 12 wavefronts at 168
+// registers with the two classes of a list resident -- the same time (profiles/r6_ab_history.txt).
 //
 // The Tx tile: row k = 512 bytes = [re of the even columns | re of the odd ones | im even | im odd], 16 doubles each:
 // the 16 lanes of a sub-row add at consecutive 8-byte addresses whatever rows their points go to (a row's stride is a
 // multiple of the bank span), both for a lane's first and for its second column.
 //
-// Needs the padded column index of a tile's first column to be even and N even (n1, N even: then a pair never
-// straddles a decimation interval and every 16-byte access is aligned); the launcher sends other shapes to
-// tile2_kernel. Compiled with -ffp-contract=off (bin indices); explicit fmaf where a multiply-add may fuse.
+// A pair never straddles a decimation interval because its first padded index is even: when the left padding n1 is odd
+// the tiles start one column early (column -1 dead). Wx / Tx pairs and bin pairs are accessed as 16- / 4-byte words at
+// whatever 8- / 2-byte boundary the signal's length and that shift leave them. Compiled with -ffp-contract=off (bin indices); explicit fmaf where a multiply-add may fuse.
 #include "ssq_common.h"
 #include "ssq_tiles.h"
 #include <algorithm>
@@ -40,18 +41,9 @@ namespace ssq {
 #include "ssq_tile_dev.h"
 
 constexpr int T3_COLS = 32, T3_RPI = 4, T3_LGC = 5;
-#ifndef SSQ_T3_PROF
-#define SSQ_T3_PROF 0      // shader-clock stamps per phase (workgroup 0 -> A.counters + 64): tools/r6/gpu_e.sh
-#endif
-#if SSQ_T3_PROF
-#define T3_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tprev; tprev = t_; } while (0)
-#else
-#define T3_STAMP(i) ((void)0)
-#endif
-#ifndef SSQ_T3_ABL
-#define SSQ_T3_ABL 0       // ablation builds (timing only, wrong results): see tools/r6/gpu_c.sh
-#endif
-typedef float ssq_f4u __attribute__((ext_vector_type(4), aligned(8)));     // 16 bytes at an 8-byte boundary (samples)
+typedef float ssq_f4u __attribute__((ext_vector_type(4), aligned(8)));     // 16 bytes at an 8-byte boundary (samples; Wx, Tx
+                                                                            // pairs at an odd column)
+typedef unsigned ssq_u32u __attribute__((aligned(2)));                      // two 16-bit bins at a 2-byte boundary
 
 struct Tile3Args {
     const int* items;        // [n_items][8]: row0 | npad << 9 | kind << 12 | lgR << 13 | weights' offset << 18, samples'
@@ -87,8 +79,11 @@ __device__ __forceinline__ int pair_bin(const ssq_f2 W, const ssq_f2 V, bool liv
     return (above && live) ? kf : -1;
 }
 
-template <int GRID, bool STORE_D, int NW, int CSTK, bool WT2, bool STORE_K = false>
-__global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams sp) {
+__device__ __forceinline__ ssq_f4u as_f4u(const float4 v) { ssq_f4u r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+
+template <int GRID, bool STORE_D, int CSTK, bool STORE_K = false>
+__global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqParams sp) {
+    constexpr int NW = TILE3_NW;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int COLS = T3_COLS, RPI = T3_RPI, LGC = T3_LGC;
     const int lane = threadIdx.x & 63;
@@ -108,7 +103,10 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     constexpr int RR = NW * RPI;                               // rows per write-out round
     const int full_rounds = na / RR;
 
-    const int ntx = (int)((N + COLS - 1) / COLS);
+    // A pair must start at an even padded index (then n and n + 1 share their decimation interval): when the left
+    // padding n1 is odd the tiles start one column early -- tile t = columns 32 t - sh .. 32 t - sh + 31, column -1 dead
+    const int sh = A.n1 & 1, n1e = A.n1 - sh;
+    const int ntx = (int)((N + sh + COLS - 1) / COLS);
     const int G = (int)gridDim.x;
     // (the walk over the tiles, the XCD permutation of the first tiles and the carry through the signals' boundaries:
     // as tile2_kernel, see there)
@@ -117,12 +115,8 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - bid + G - 1) / G) : per_sig * A.nsig;
     const auto* waves = SSQ_CONST_PTR(int4, A.waves);
     const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
-#if SSQ_T3_PROF
-    unsigned long long prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
-#endif
     int prio = (wv >> 2) & 1;
-    auto rotate_priority = [&]() { if (!(SSQ_T3_ABL & 256)) SSQ_PRIO_TOGGLE(prio); };   // (two levels, swapped with every item: see tile2_kernel)
+    auto rotate_priority = [&]() { SSQ_PRIO_TOGGLE(prio); };   // (two levels, swapped with every item: see tile2_kernel)
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
@@ -134,9 +128,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     // tile free again (barrier). A lane takes its column pair of a row: four LDS reads, one 16-byte store; a wavefront
     // instruction = 4 rows.
     auto finish_tile = [&](int tx, int sg) {
-        T3_STAMP(6);
         SSQ_WG_BARRIER();
-        T3_STAMP(7);
         float2* Tx = A.Tx + (int64_t)(A.sig0 + sg) * na * N;
         constexpr int NA_CAP = 320;
         constexpr int ROUNDS = (NA_CAP + RR - 1) / RR;
@@ -149,9 +141,10 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             v.x = (float)r0; v.y = (float)q0; v.z = (float)r1; v.w = (float)q1;
             return v;
         };
-        if ((tx + 1) * COLS <= (int)nN) {
+        const int tcol0 = tx * COLS - sh;                      // the tile's first column
+        if (tcol0 >= 0 && tcol0 + COLS <= (int)nN) {
             // every column of the tile exists: the rounds below the last need no masks
-            char* tb = reinterpret_cast<char*>(Tx) + (size_t)tx * (COLS * 8);
+            char* tb = reinterpret_cast<char*>(Tx) + (int64_t)tcol0 * 8;
             const unsigned voff = ((unsigned)k0 * nN + (unsigned)cp * 2u) * 8u;
             int fr = full_rounds;
             size_t step = (size_t)RR * (size_t)N * 8;
@@ -160,7 +153,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
                 SSQ_OPAQUE_S(fr); SSQ_OPAQUE_S(step);          // (re-read as scalars at every use: see tile2_kernel)
                 if (m < fr) {                                  // (wave-uniform)
                     const float4 v = take(k0 + m * RR);
-                    if (!(SSQ_T3_ABL & 512) || v.x == 123.25f) *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
+                    *reinterpret_cast<ssq_f4u*>(tb + (size_t)voff) = as_f4u(v);
                     tb += step;
                     asm volatile("" ::: "memory");             // (keeps the rounds from being batched into registers)
                 }
@@ -168,23 +161,23 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             {   // the last round: the rows left, and the scratch row cleared by the lanes past them
                 const int k = k0 + fr * RR;
                 const float4 v = take(k < na ? k : na);
-                if (k < na && (!(SSQ_T3_ABL & 512) || v.x == 123.25f)) *reinterpret_cast<float4*>(tb + (size_t)voff) = v;
+                if (k < na) *reinterpret_cast<ssq_f4u*>(tb + (size_t)voff) = as_f4u(v);
             }
         } else {
-            const unsigned col = (unsigned)(tx * COLS + cp * 2);      // (N even: a pair exists or does not)
-            const bool ok = col < nN;
+            // a signal's first tile when n1 is odd, its last when it is partial: column by column
+            const int col = tcol0 + cp * 2;
+            const bool ok0 = (unsigned)col < nN, ok1 = (unsigned)(col + 1) < nN;
 #pragma unroll 1
             for (int m = 0; m * RR < na + 1; ++m) {
                 const int k = k0 + m * RR;
                 const float4 v = take(k < na ? k : na);
-                if (ok && k < na) *reinterpret_cast<float4*>(&Tx[(unsigned)k * nN + col]) = v;
+                if (ok0 && k < na) Tx[(int64_t)k * N + col] = make_float2(v.x, v.y);
+                if (ok1 && k < na) Tx[(int64_t)k * N + col + 1] = make_float2(v.z, v.w);
             }
         }
         if (threadIdx.x == 0 && A.counters)
             __scoped_atomic_fetch_add(A.counters, 1ull, __ATOMIC_RELAXED, __MEMORY_SCOPE_DEVICE);
-        T3_STAMP(8);
         SSQ_WG_BARRIER();
-        T3_STAMP(9);
     };
 
     if (ni <= 0) {                                             // more wavefronts than items: write-outs only
@@ -200,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
     // ---- the wavefront's sequence of (tile, item) positions: two cursors (the loads' two positions ahead of the
     // arithmetic's), each an item index and the tile as the kernel uses it -- see tile2_kernel
     struct Pos { int nabs0, sg; int64_t off8; };
-    const int nabs_step = G * COLS, nabs_first = A.n1 + bid * COLS, nabs_last = A.n1 + (ntx - 1) * COLS;
+    const int nabs_step = G * COLS, nabs_first = n1e + bid * COLS, nabs_last = n1e + (ntx - 1) * COLS;
     const int64_t off8_step = (int64_t)G * COLS * 8;
     const int64_t off8_wrap = A.carry ? ((int64_t)na * N + (int64_t)(G - ntx) * COLS) * 8
                                       : ((int64_t)na * N - (int64_t)(per_sig - 1) * G * COLS) * 8;
@@ -213,6 +206,8 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
         if (wrap) { r.nabs0 = A.carry ? r.nabs0 - nabs_back : nabs_first; ++r.sg; }
         return (wrap && r.sg >= A.nsig) ? q : r;               // (the tile after the last: the last)
     };
+    // a tile with dead columns: a signal's first when the tiles start a column early, its last when it is partial
+    auto edge_tile = [&](int nabs0) { return (sh != 0 && nabs0 == n1e) || nabs0 - n1e - sh + COLS > (int)N; };
     const int total = ntl * ni;                                // positions of this wavefront
     // (a record's first four words through the scalar cache; its last four -- the sub-rows' centre bins -- are read per lane
     // with the position's data, see load_data)
@@ -252,24 +247,27 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             const int npad = (w0 >> 9) & 7;
             unsigned lr = lane_row16;
             if (npad) lr = (unsigned)min(h, RPI - 1 - npad) * nN * 8u + lane_col16;
-            if (q.nabs0 == nabs_last) {                        // (the last tile may be partial)
-                const int col = q.nabs0 - A.n1 + cp * 2;
-                if (col >= (int)N) lr -= (unsigned)(col - ((int)N - 2)) * 8u;
+            lr += 16u;                                         // (the bases below start 16 bytes early: lr stays >= 0)
+            if (edge_tile(q.nabs0)) {
+                // pairs with a dead column read the nearest pair inside the row (the body puts the halves in place)
+                const int col = q.nabs0 - n1e - sh + cp * 2;
+                const int cc = min(max(col, 0), (int)N - 2);
+                lr += (unsigned)((cc - col) * 8);
             }
             voff = lr;
-            base = WX8 + ((size_t)q.off8 + (unsigned)R[2]);
-            kbase = KX8 + (((size_t)q.off8 + (unsigned)R[2]) >> 2);
+            base = WX8 + ((int64_t)q.off8 + (unsigned)R[2] - 16);
+            kbase = KX8 + (((int64_t)q.off8 + (unsigned)R[2] - 16) >> 2);
             koff = lr >> 2;
         }
         d.u = *reinterpret_cast<const ssq_f4u*>(base + (size_t)voff);
         // (one load either way: the bins of rows read back, the centre bin of an interpolated sub-row)
-        d.kq = (int)*reinterpret_cast<const unsigned*>(kbase + (size_t)koff);
+        d.kq = (int)*reinterpret_cast<const ssq_u32u*>(kbase + (size_t)koff);
         return d;
     };
     // the weights of a class for the lane's two column phases (every tile of this workgroup: the same n mod R)
     auto load_wt = [&](ssq_f2 (&wa)[TILE_W], ssq_f2 (&wb)[TILE_W], int w0) {
         const int lgR = (w0 >> 13) & 31, woff = (int)((unsigned)w0 >> 18);
-        const int nabs = A.n1 + bid * COLS + cp * 2;
+        const int nabs = n1e + bid * COLS + cp * 2;
         const int R = 1 << lgR;
         const float4* wp = A.wtab + (int64_t)woff * 4 + (nabs & (R - 1));   // (nabs even: nabs + 1 is the next phase)
 #pragma unroll
@@ -279,13 +277,10 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             wb[2 * t].x = u.x; wb[2 * t].y = u.y; wb[2 * t + 1].x = u.z; wb[2 * t + 1].y = u.w;
         }
     };
-    ssq_f2 wa0[TILE_W], wb0[TILE_W], wa1[WT2 ? TILE_W : 1], wb1[WT2 ? TILE_W : 1];
-    int wcls = -1;                                             // (!WT2) the class whose weights are resident: w0 >> 13
-    if constexpr (WT2) {
-        load_wt(wa0, wb0, items_at(i0)[0]);
-        load_wt(wa1, wb1, items_at(isp < i1 ? isp : i0)[0]);
-    } else {
-        int wsel = items_at(i0)[0];                               // (a block that opens with rows read back: its second class)
+    ssq_f2 wa0[TILE_W], wb0[TILE_W];
+    int wcls;                                                  // the class whose weights are resident: w0 >> 13
+    {
+        int wsel = items_at(i0)[0];                            // (a list that opens with rows read back: its first interpolated item)
         if (!((wsel >> 12) & 1) && isp < i1) wsel = items_at(isp)[0];
         load_wt(wa0, wb0, wsel);
         wcls = wsel >> 13;
@@ -293,11 +288,11 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
 
     Data D[3];
     Pos tc, tl;                                                // the tile of the arithmetic's cursor, of the loads'
-    tc.nabs0 = nabs_first; tc.sg = 0; tc.off8 = (int64_t)bid * COLS * 8;
+    tc.nabs0 = nabs_first; tc.sg = 0; tc.off8 = ((int64_t)bid * COLS - sh) * 8;
     tl = tc;
     if (total <= 0) return;
     int it_c = i0, it_l = i0;
-    bool tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;   // the arithmetic's tile is a signal's last, partial one
+    bool tc_edge = edge_tile(tc.nabs0);                        // the arithmetic's tile has dead columns
     int left = total;                                          // positions not yet finished
     auto step_loads = [&]() { if (++it_l >= i1) { it_l = i0; tl = next_tile(tl); } };
     int8v Rc = items_at(i0);
@@ -325,33 +320,46 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
         constexpr int k0 = decltype(KK)::value, k2 = (k0 + 2) % 3;
         const Pos pc = tc;
         rotate_priority();
-        T3_STAMP(0);
         D[k2] = load_data(Rn, it_l, tl);                       // the data of p + 2
         step_loads();
-        T3_STAMP(1);
-#if SSQ_T3_PROF
-        SSQ_OPAQUE_V(D[k0].u); SSQ_OPAQUE_V(D[k0].kq);
-        T3_STAMP(2);
-#endif
         const Data dc = D[k0];
         const int w0 = Rc[0];
         const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
         const int nabs = pc.nabs0 + cp * 2;                    // (lanes past the last column: results unused)
-        // (every lane's points count, except in a class's last item -- padded sub-rows -- and in the last tile of a
-        // signal when N is not a multiple of the tile: a wave-uniform test keeps the rest free)
+        // (every lane's two points count, except in a class's last item -- padded sub-rows --, in a tile with dead
+        // columns and past the wavefront's last position: a wave-uniform test keeps the rest free)
         const bool alive = left > 0;                          // (past the wavefront's last position: see the loop below)
-        bool livept = true;
-        if ((w0 & 0xE00) != 0 || tc_last || !alive) livept = alive && h < RPI - npad && nabs - A.n1 < (int)N;
+        const bool rare = (w0 & 0xE00) != 0 || tc_edge || !alive;
+        const int col = nabs - n1e - sh;                       // the pair's first column
+        bool live0 = true, live1 = true;
+        if (rare) {
+            const bool rowok = alive && h < RPI - npad;
+            live0 = rowok && (unsigned)col < nN;
+            live1 = rowok && (unsigned)(col + 1) < nN;
+        }
+        // (byte offset of (signal, the item's first row, the tile's first column) in Wx, dWx; a quarter of it in the bins)
+        const int64_t row8 = (int64_t)A.sig0 * na * N * 8 + pc.off8 + (unsigned)Rc[2];
+        auto dump_bins = [&](unsigned kk) {                    // (STORE_K builds)
+            char* kd = reinterpret_cast<char*>(A.kdump) + (row8 >> 2) + (lane_row16 >> 2);
+            if (!rare) *reinterpret_cast<ssq_u32u*>(kd) = kk;
+            else {
+                if (live0) *reinterpret_cast<unsigned short*>(kd) = (unsigned short)kk;
+                if (live1) *reinterpret_cast<unsigned short*>(kd + 2) = (unsigned short)(kk >> 16);
+            }
+        };
         int cell0, cell1; float t0x, t0y, t1x, t1y;
         if (kind == 0) {
-            const int ka = dc.kq & 0xFFFF, kb = (int)((unsigned)dc.kq >> 16);
-            cell0 = (livept && ka != TILE_NOBIN) ? ka * 512 + c8 : scratch8;
-            cell1 = (livept && kb != TILE_NOBIN) ? kb * 512 + c8 : scratch8;
-            t0x = dc.u.x; t0y = dc.u.y; t1x = dc.u.z; t1y = dc.u.w;
-            if constexpr (STORE_K) {
-                char* kd8 = reinterpret_cast<char*>(A.kdump) + (((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]) >> 2);
-                if (livept) *reinterpret_cast<unsigned*>(kd8 + (size_t)(lane_row16 >> 2)) = (unsigned)dc.kq;
+            ssq_f4u u = dc.u;
+            unsigned kq = (unsigned)dc.kq;
+            if (tc_edge) {                                     // (a pair with a dead column read its neighbour: see load_data)
+                if (col < 0) { u.z = u.x; u.w = u.y; kq <<= 16; }
+                else if (col == (int)N - 1) { u.x = u.z; u.y = u.w; kq >>= 16; }
             }
+            const int ka = (int)(kq & 0xFFFFu), kb = (int)(kq >> 16);
+            cell0 = (live0 && ka != TILE_NOBIN) ? ka * 512 + c8 : scratch8;
+            cell1 = (live1 && kb != TILE_NOBIN) ? kb * 512 + c8 : scratch8;
+            t0x = u.x; t0y = u.y; t1x = u.z; t1y = u.w;
+            if constexpr (STORE_K) dump_bins(kq);
         } else {
             const int lgR = (w0 >> 13) & 31;
             const int qb3 = pc.nabs0 >> lgR;                   // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
@@ -360,10 +368,6 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             {
                 int fr[TILE_W], fi[TILE_W];
                 int ur = __float_as_int(dc.u.x), ui = __float_as_int(dc.u.y);
-#if SSQ_T3_ABL & 1
-#pragma unroll
-                for (int t = 0; t < TILE_W; ++t) { fr[t] = ur + t + baddr; fi[t] = ui + t; }
-#else
                 SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
                 SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
                 SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
@@ -373,26 +377,12 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
                 SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
                 SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
                 SSQ_LDS_WAIT();
-#endif
                 // (A = (a_re, a_im), D = (a'_re, a'_im) of the pair's two columns: what the modulation multiplies)
                 ssq_f2 sv[TILE_W];
 #pragma unroll
                 for (int t = 0; t < TILE_W; ++t) { sv[t].x = __int_as_float(fr[t]); sv[t].y = __int_as_float(fi[t]); }
-#if SSQ_T3_ABL & 2
-                A0 = sv[0] + sv[1] * wa0[0] + sv[4]; D0 = sv[2] + sv[5]; A1 = sv[3] + sv[6] * wb0[1]; D1 = sv[7];
-#else
-                if constexpr (WT2) {
-                    if (it_c < isp) {   // (wave-uniform: the wavefront's first or second class)
-                        SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
-                    } else {
-                        SSQ_TAPS8X2(A0, D0, A1, D1, wa1, wb1, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
-                    }
-                } else {
-                    SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
-                }
-#endif
+                SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
             }
-            T3_STAMP(3);
             const int kcs = dc.kq;                             // centre bin of the lane's row
             const float theta = (float)kcs * A.theta_scale;
             // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
@@ -405,45 +395,36 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             const unsigned ph1 = (ph0 + (unsigned)kcs) & (unsigned)A.mmask;
             const float rev0 = (float)ph0 * A.inv_m, rev1 = (float)ph1 * A.inv_m;
             ssq_f2 tw0, tw1, W0, V0, W1, V1;
-#if SSQ_T3_ABL & 4
-            W0 = A0 + rev0; W1 = A1 + rev1; V0 = D0; V1 = D1;
-#else
             tw0.x = __builtin_amdgcn_cosf(rev0); tw0.y = __builtin_amdgcn_sinf(rev0);
             tw1.x = __builtin_amdgcn_cosf(rev1); tw1.y = __builtin_amdgcn_sinf(rev1);
             SSQ_CMUL_PK(W0, tw0, A0);
             SSQ_CMUL_PK(W1, tw1, A1);
             SSQ_CMUL_PK(V0, tw0, D0);
             SSQ_CMUL_PK(V1, tw1, D1);
-#endif
             // (lanes past the last column hold other columns' weights, padded sub-rows another row's samples: their
             // values go nowhere)
-            char* wx8 = const_cast<char*>(WX8) + ((size_t)pc.off8 + (unsigned)Rc[2]);
-            float4 Wq; Wq.x = W0.x; Wq.y = W0.y; Wq.z = W1.x; Wq.w = W1.y;
-            if (livept && (!(SSQ_T3_ABL & 8) || Wq.x == 123.25f)) *reinterpret_cast<float4*>(wx8 + (size_t)lane_row16) = Wq;
-            if (STORE_D) {
-                char* dwx8 = reinterpret_cast<char*>(A.dWx) + ((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]);
-                float4 Vq; Vq.x = V0.x; Vq.y = V0.y; Vq.z = V1.x; Vq.w = V1.y;
-                if (livept) *reinterpret_cast<float4*>(dwx8 + (size_t)lane_row16) = Vq;
-            }
-            T3_STAMP(4);
+            // (one 16-byte store per lane; a pair with a dead point: the live one alone)
+            auto store_pair = [&](char* dst, const ssq_f2 a, const ssq_f2 b) {
+                char* q = dst + row8 + (size_t)lane_row16;
+                if (!rare) { ssq_f4u v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; *reinterpret_cast<ssq_f4u*>(q) = v; }
+                else {
+                    if (live0) *reinterpret_cast<float2*>(q) = make_float2(a.x, a.y);
+                    if (live1) *reinterpret_cast<float2*>(q + 8) = make_float2(b.x, b.y);
+                }
+            };
+            store_pair(reinterpret_cast<char*>(A.Wx), W0, W1);
+            if (STORE_D) store_pair(reinterpret_cast<char*>(A.dWx), V0, V1);
             // phase transform and bin: as emit_point<LEAN> of the block kernels, per column
-#if SSQ_T3_ABL & 16
-            int ko0 = (__float_as_int(W0.x + V0.y) & 63) + h, ko1 = (__float_as_int(W1.y + V1.x) & 63) + h;
-#else
             bool pend0, pend1;
-            int ko0 = pair_bin<GRID>(W0, V0, livept, m2hi, m2lo, sp, omax, fx, fa, pend0);
-            int ko1 = pair_bin<GRID>(W1, V1, livept, m2hi, m2lo, sp, omax, fx, fa, pend1);
+            int ko0 = pair_bin<GRID>(W0, V0, live0, m2hi, m2lo, sp, omax, fx, fa, pend0);
+            int ko1 = pair_bin<GRID>(W1, V1, live1, m2hi, m2lo, sp, omax, fx, fa, pend1);
             if (pend0) ko0 = exact_bin(make_float2(W0.x, W0.y), make_float2(V0.x, V0.y), sp, omax, A.gamma);
             if (pend1) ko1 = exact_bin(make_float2(W1.x, W1.y), make_float2(V1.x, V1.y), sp, omax, A.gamma);
-#endif
             cell0 = ko0 >= 0 ? ko0 * 512 + c8 : scratch8;
             cell1 = ko1 >= 0 ? ko1 * 512 + c8 : scratch8;
             t0x = W0.x; t0y = W0.y; t1x = W1.x; t1y = W1.y;
-            if constexpr (STORE_K) {
-                char* kd8 = reinterpret_cast<char*>(A.kdump) + (((size_t)((int64_t)A.sig0 * na * N) * 8u + (size_t)pc.off8 + (unsigned)Rc[2]) >> 2);
-                const unsigned kk = (unsigned)(ko0 >= 0 ? ko0 : TILE_NOBIN) | ((unsigned)(ko1 >= 0 ? ko1 : TILE_NOBIN) << 16);
-                if (livept) *reinterpret_cast<unsigned*>(kd8 + (size_t)(lane_row16 >> 2)) = kk;
-            }
+            if constexpr (STORE_K)
+                dump_bins((unsigned)(ko0 >= 0 ? ko0 : TILE_NOBIN) | ((unsigned)(ko1 >= 0 ? ko1 : TILE_NOBIN) << 16));
         }
         {
             w_t cs = (w_t)A.cst0;
@@ -454,27 +435,18 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             }
             const double a0 = (double)TM::make(t0x, cs), b0 = (double)TM::make(t0y, cs);
             const double a1 = (double)TM::make(t1x, cs), b1 = (double)TM::make(t1y, cs);
-#if SSQ_T3_ABL & 32
-            if (a0 + b0 + a1 + b1 == 123.25 + (double)(cell0 ^ cell1)) SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
-#else
             SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
             SSQ_LDS_ADD_F64_AT(cell0, 256, b0);
             SSQ_LDS_ADD_F64_AT(cell1, 128, a1);
             SSQ_LDS_ADD_F64_AT(cell1, 384, b1);
-#endif
         }
-        T3_STAMP(5);
         --left;
         const bool tile_end = alive && ++it_c >= i1;           // (the block's last item: the tile is complete)
         if (tile_end) it_c = i0;
         Rc = items_at(it_c);                                      // the next position's records
         Rn = items_at(it_l);
         load_cs(Rc[0] & 0x1FF);                                // ... and its rows' weights, when there is one per row
-#if SSQ_T3_PROF
-        SSQ_OPAQUE_S(Rc[0]); SSQ_OPAQUE_S(Rn[0]);
-        T3_STAMP(10);
-#endif
-        if constexpr (!WT2) {
+        {
             // the next position is of another class: its weights replace the ones in hand (512 bytes per lane out of
             // the L2 -- at most twice per tile and wavefront, the host cuts the row blocks that way)
             const int wn = Rc[0];
@@ -487,9 +459,9 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
             }
         }
         if (tile_end) {
-            if (!(SSQ_T3_ABL & 64) || left <= 0) finish_tile((pc.nabs0 - A.n1) >> LGC, pc.sg);
+            finish_tile((pc.nabs0 - n1e) >> LGC, pc.sg);
             tc = next_tile(tc);
-            tc_last = tc.nabs0 == nabs_last && (N & (COLS - 1)) != 0;
+            tc_edge = edge_tile(tc.nabs0);
         }
     };
     // Whole turns of the ring, ONE back edge: with an exit behind every body the compiler's control flow has edges from
@@ -501,23 +473,16 @@ __global__ __launch_bounds__(64 * NW) void tile3_kernel(Tile3Args A, SsqParams s
         body(K1{});
         body(K2{});
     }
-#if SSQ_T3_PROF
-    T3_STAMP(11);
-    if (blockIdx.x == 0 && lane == 0 && A.counters) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) A.counters[64 + wv * 12 + i] += prof[i];
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------- host side
-template <int GRID, bool STORE_D, int NW, int CSTK, bool WT2, bool STORE_K = false>
+template <int GRID, bool STORE_D, int CSTK, bool STORE_K = false>
 static int launch_tile3_c(const TilePlan& P, const Tile3Args& A, const SsqParams& sp, hipStream_t stream) {
-    auto kern = tile3_kernel<GRID, STORE_D, NW, CSTK, WT2, STORE_K>;
+    auto kern = tile3_kernel<GRID, STORE_D, CSTK, STORE_K>;
     const size_t lds = tile2_lds_bytes(P.na, T3_COLS);
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    const int64_t ntx = (P.N + T3_COLS - 1) / T3_COLS;
+    const int64_t ntx = (P.N + (P.n1 & 1) + T3_COLS - 1) / T3_COLS;     // (the tiles start a column early when n1 is odd)
     // persistent workgroups, one per CU; G * COLS a multiple of the largest R (the lanes keep their weights' phase)
     const int64_t cap = (int64_t)P.ncu;
     const int64_t q = std::max<int64_t>(1, ((int64_t)1 << P.lgr_max2) / T3_COLS);
@@ -528,25 +493,25 @@ static int launch_tile3_c(const TilePlan& P, const Tile3Args& A, const SsqParams
     B.carry = (carry_on && ntx > G && ntx % q == 0) ? 1 : 0;
     const char* xe = getenv("SSQ_TILE2_XCD");                 // (read per launch)
     B.xcd = !(xe && atoi(xe) == 0) && G >= 16;
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, B, sp);
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * TILE3_NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();
     return 0;
 }
-template <int GRID, bool STORE_D, int NW, bool WT2>
+template <int GRID, bool STORE_D>
 static int launch_tile3_k(const TilePlan& P, const Tile3Args& A, const SsqParams& sp, hipStream_t stream) {
     const int cstk = sp.cst_f64 ? 2 : (sp.cst_uniform ? 0 : 1);
     if (A.kdump) {
         SSQ_REQUIRE(cstk == 0, "bin dump: built for uniform reassignment weights ('log' scales)");
-        return launch_tile3_c<GRID, STORE_D, NW, 0, WT2, true>(P, A, sp, stream);
+        return launch_tile3_c<GRID, STORE_D, 0, true>(P, A, sp, stream);
     }
-    if (cstk == 0) return launch_tile3_c<GRID, STORE_D, NW, 0, WT2>(P, A, sp, stream);
-    if (cstk == 1) return launch_tile3_c<GRID, STORE_D, NW, 1, WT2>(P, A, sp, stream);
-    return launch_tile3_c<GRID, STORE_D, NW, 2, WT2>(P, A, sp, stream);
+    if (cstk == 0) return launch_tile3_c<GRID, STORE_D, 0>(P, A, sp, stream);
+    if (cstk == 1) return launch_tile3_c<GRID, STORE_D, 1>(P, A, sp, stream);
+    return launch_tile3_c<GRID, STORE_D, 2>(P, A, sp, stream);
 }
 
 int TilePlan::run_pair(int sig, int nsig, float* Wx, float* dWx, float* Tx, const unsigned short* kidx,
                        const void* cst, float cst0, const SsqParams& sp, hipStream_t stream, unsigned short* kdump) {
-    SSQ_REQUIRE(pair_ok(), "the pair kernel does not take this plan (odd n1 or N, more than 318 rows, or row blocks of more than two classes)");
+    SSQ_REQUIRE(pair_ok(), "the pair kernel does not take this plan (more than 318 rows, or fewer than 64 columns)");
     Tile3Args B;
     B.kdump = kdump;
     B.items = reinterpret_cast<const int*>(items3);
@@ -558,11 +523,7 @@ int TilePlan::run_pair(int sig, int nsig, float* Wx, float* dWx, float* Tx, cons
     B.sig0 = sig; B.nsig = nsig; B.group = group; B.inv_m = 1.0f / (float)M;
     B.theta_scale = (float)(6.283185307179586 / ((double)M * dt)); B.cst0 = cst0;
     B.counters = counters; B.gamma = sp.gamma; B.carry = 0; B.xcd = 0;
-#define TILE3_LAUNCH(G)                                                                                       \
-    if (nw3 == 12) return dWx ? launch_tile3_k<G, true, 12, true>(*this, B, sp, stream)                       \
-                              : launch_tile3_k<G, false, 12, true>(*this, B, sp, stream);                     \
-    return dWx ? launch_tile3_k<G, true, 16, false>(*this, B, sp, stream)                                     \
-               : launch_tile3_k<G, false, 16, false>(*this, B, sp, stream);
+#define TILE3_LAUNCH(G) return dWx ? launch_tile3_k<G, true>(*this, B, sp, stream) : launch_tile3_k<G, false>(*this, B, sp, stream);
     if (sp.grid == SSQ_GRID_LOG) { TILE3_LAUNCH(SSQ_GRID_LOG) }
     if (sp.grid == SSQ_GRID_LOG_PIECEWISE) { TILE3_LAUNCH(SSQ_GRID_LOG_PIECEWISE) }
     TILE3_LAUNCH(SSQ_GRID_LIN)

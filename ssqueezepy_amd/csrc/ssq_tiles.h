@@ -53,7 +53,8 @@ constexpr int TILE_COLS = 64;           // ordered kernel: columns per tile (one
 #define SSQ_TILE_G 4
 #endif
 constexpr int TILE_G = SSQ_TILE_G;      // rows per step of the host's tables (_tiles.py: RSUB)
-constexpr int TILE2_NW = 16;            // default kernel: wavefronts per workgroup (one workgroup per CU)
+constexpr int TILE2_NW = 16;            // tile2_kernel: wavefronts per workgroup (one workgroup per CU)
+constexpr int TILE3_NW = 16;            // tile3_kernel: the same
 // LDS of a workgroup: the ordered kernel's (na + 1) x 64 float32 pairs + ticket words; the default kernel's
 // (na + 1) x cols float64 pairs
 __host__ __device__ inline size_t tile_lds_bytes(int64_t na) { return (size_t)(na + 1) * TILE_COLS * 8 + 16; }
@@ -80,12 +81,12 @@ struct TilePlan {
     int n_items2 = 0, cols2 = 32;
     int lgr_max2 = 0;                       // largest decimation (log2) among the interpolated classes
     bool tile2_ok = false;                  // the items could be cut into blocks of at most two classes
-    // tile3_kernel (two columns per lane, ssq_tile_pair.hip): items of FOUR rows x 32 columns, the wavefronts' blocks
-    // for nw3 wavefronts per workgroup (12: both classes of a block resident; 16: one, re-read at a class change)
+    // tile3_kernel (two columns per lane, ssq_tile_pair.hip): items of FOUR rows x 32 columns, permuted so that every
+    // wavefront's list is contiguous, and the lists' bounds ([TILE3_NW][4])
     void* items3 = nullptr; int32_t* wave_first3 = nullptr;
-    int n_items3 = 0, nw3 = 16;
+    int n_items3 = 0;
     bool tile3_ok = false;
-    bool pair_ok() const;                   // tile3_kernel takes this plan (n1 and N even, 32-column tile, SSQ_TILE_PAIR != 0)
+    bool pair_ok() const;                   // tile3_kernel takes this plan (32-column tile, SSQ_TILE_PAIR != 0)
     int tile_kernel() const;                // 0 none, 1 ordered, 2 tile2_kernel, 3 tile3_kernel (what `run` launches now)
     int tile_cols() const;                  // columns per tile of the kernel that `run` launches (0: none can run)
     // Can `run` launch a tile kernel for this plan in the mode selected right now? The default kernel needs the

@@ -65,6 +65,8 @@ def test_config2_ssq_cwt_full_size_vs_oracle(S, orc):
     if os.environ.get('SSQ_CWT_TILES', '1') != '0':
         # what executed, not what was planned: the tile kernel finished every tile of the call
         assert plan.tile_rows > 0.7 * na and plan.tiles_done() == plan.tiles_per_signal(N), (plan.algo, plan.tiles_done())
+        # ... and which kernel: the ticketed one in the ordered mode, else the float64 tile with a column pair per lane
+        assert plan.tile_kernel == (1 if tile_order() == 'ordered' else 3), plan.tile_kernel
 
     # the reference's algorithm: dense (na, M) bank, two length-M inverse FFTs per row
     sc32 = np.asarray(scales, dtype='float32')

@@ -5,7 +5,8 @@ time vectors, odd n_fft, short windows, single-scale banks, plan-cache reuse."""
 import os
 import numpy as np
 import pytest
-from conftest import two_chirps, assert_tx_vs_oracle, assert_tx_repeat, tile_mode, needs_tile_path  # noqa: F401
+from conftest import (two_chirps, assert_tx_vs_oracle, assert_tx_repeat, tile_mode, needs_tile_path,  # noqa: F401
+                      tile_order)
 from pipeline import oracle_ssq_cwt, oracle_ssq_stft, GRIDNAME
 
 pytestmark = pytest.mark.gpu
@@ -387,4 +388,34 @@ def test_more_rows_than_the_32_column_tile_holds(S, orc, tile_mode):
     ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'], True, typing=0,
                        parallel=True)
     assert_tx_vs_oracle(Tx, ref, tiles=True)
+    _cwt.clear_plan_cache()
+
+
+@pytest.mark.parametrize('N', [4096, 4098, 4099, 4097, 8192 - 2 * 33, 8192 - 2 * 32 - 1, 20010])
+def test_pair_kernel_equals_single_column_kernel(S, N, monkeypatch):
+    """Round 6: the default tile kernel gives a lane a PAIR of neighbouring columns (csrc/ssq_tile_pair.hip,
+    `plan.tile_kernel == 3`); `SSQ_TILE_PAIR=0` keeps the one-column-per-lane kernel of rounds 4-5 (2). Same arithmetic
+    per point, so `Wx` and `dWx` must agree bit for bit and `Tx` as two runs of one kernel do -- for even and odd
+    lengths, odd left paddings (the pair kernel's tiles then start one column early: n1 = 2047, 2046, 33, 33 here), a
+    partial last tile, a first tile with a dead column, and a batch that the walk carries through."""
+    needs_tile_path()
+    if tile_order() == 'ordered':
+        pytest.skip('the ordered mode runs the ticketed kernel')
+    from ssqueezepy_amd import _cwt
+    xb = np.stack([two_chirps(N, seed=40 + s) for s in range(3)])
+    wav = S.Wavelet()
+    out = {}
+    for pair in ('1', '0'):
+        monkeypatch.setenv('SSQ_TILE_PAIR', pair)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(xb, wav, scales='log', nv=16, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan.tile_kernel == (3 if pair == '1' else 2), plan.tile_kernel
+        assert plan.tiles_done() == 3 * plan.tiles_per_signal(N)
+        T1, W1, *_ = S.ssq_cwt(xb[1], wav, scales='log-piecewise', nv=16, astensor=False)
+        out[pair] = (Tx, Wx, dWx, T1, W1)
+    for k in (1, 2, 4):
+        assert np.array_equal(out['1'][k], out['0'][k]), k
+    assert_tx_repeat(out['1'][0], out['0'][0])
+    assert_tx_repeat(out['1'][3], out['0'][3])
     _cwt.clear_plan_cache()

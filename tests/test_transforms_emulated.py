@@ -381,3 +381,29 @@ def test_tile_path_emulated_fewer_steps_than_wavefronts(tile_mode):
             ref = orc.ssqueeze(Wx, dWx, GRIDNAME[r['grid']], r['params'], r['const'], r['gamma'],
                                True, typing=0)
             assert_tx_vs_oracle(Tx, ref)
+
+
+def test_pair_kernel_equals_single_column_kernel_emulated(monkeypatch):
+    """Round 6, under the emulator: the tile kernel with a column PAIR per lane (csrc/ssq_tile_pair.hip, the default) against
+    the one-column-per-lane kernel (`SSQ_TILE_PAIR=0`): the same arithmetic per point -- `Wx`, `dWx` bit for bit, `Tx` as
+    two runs of one kernel -- for even / odd lengths, odd left paddings (tiles start one column early), partial last
+    tiles, a two-signal batch and both default grids. See tests/test_gpu_edge_cases.py for the device's run."""
+    import emu_backend
+    from conftest import two_chirps, assert_tx_repeat
+    monkeypatch.delenv('SSQ_TILE_ORDER', raising=False)
+    with emu_backend.emulated() as S:
+        from ssqueezepy_amd import _cwt
+        for N, st in ((2500, 'log'), (2502, 'log-piecewise'), (2499, 'log'), (2558, 'log'), (2049, 'log-piecewise')):
+            xb = np.stack([two_chirps(N, seed=N + s) for s in range(2)])
+            out = {}
+            for pair in ('1', '0'):
+                monkeypatch.setenv('SSQ_TILE_PAIR', pair)
+                _cwt.clear_plan_cache()
+                Tx, Wx, sf, sc, dWx = S.ssq_cwt(xb, S.Wavelet(), scales=st, nv=16, get_dWx=True, astensor=False)
+                plan = next(iter(_cwt._PLAN_CACHE.values()))
+                assert plan.tile_kernel == (3 if pair == '1' else 2)
+                assert plan.tiles_done() == 2 * plan.tiles_per_signal(N)
+                out[pair] = (Tx, Wx, dWx)
+            assert np.array_equal(out['1'][1], out['0'][1]) and np.array_equal(out['1'][2], out['0'][2]), N
+            assert_tx_repeat(out['1'][0], out['0'][0], what=N)
+        _cwt.clear_plan_cache()
