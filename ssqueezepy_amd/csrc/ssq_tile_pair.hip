@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
     using TM = TileTerm<CSTK == 2>;
     using w_t = typename TM::wtype;
-    const auto* cstv = SSQ_CONST_PTR(w_t, A.cst);
+    const w_t* const cstv = reinterpret_cast<const w_t*>(A.cst);
 
     // ---- a tile's end: all terms in (barrier), every wavefront writes its share of the rows to Tx and clears them,
     // tile free again (barrier). A lane takes its column pair of a row: four LDS reads, one 16-byte store; a wavefront
@@ -306,12 +306,13 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
     D[1] = load_data(items_at(it_l), it_l, tl);
     step_loads();
     int8v Rn = items_at(it_l);
-    w_t csn[RPI];
+    // the reassignment weight of the lane's row of the position in hand, when there is one per row: read per lane (four
+    // addresses per wavefront), asked for with the position's records. (Four scalar loads and a select by the lane's
+    // sub-row were compiled into a detour through scratch memory -- two stores and a load per item: 312 us instead of
+    // 250 for the reference's default call.)
+    w_t csv = (w_t)A.cst0;
     auto load_cs = [&](int row0) {
-        if (CSTK != 0) {
-#pragma unroll
-            for (int k = 0; k < RPI; ++k) csn[k] = cstv[min(row0 + k, omax)];
-        }
+        if (CSTK != 0) csv = cstv[min(row0 + h, omax)];
     };
     load_cs(Rc[0] & 0x1FF);
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -429,9 +430,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
         {
             w_t cs = (w_t)A.cst0;
             if (CSTK != 0) {
-                cs = csn[0];
-#pragma unroll
-                for (int k = 1; k < RPI; ++k) if (h == k) cs = csn[k];
+                cs = csv;
             }
             const double a0 = (double)TM::make(t0x, cs), b0 = (double)TM::make(t0y, cs);
             const double a1 = (double)TM::make(t1x, cs), b1 = (double)TM::make(t1y, cs);
