@@ -229,26 +229,21 @@ def main():
         # in chunks of a few signals: one collective moves (world - 1) x chunk x na x N x 8 bytes per
         # rank over the xGMI links (point to point, ~153 GB/s each), the receive buffer stays small
         # enough to sit next to the transform's own outputs (config 4: 24.6 GB of Tx per GPU)
+        from ssqueezepy_amd.sharding import gather_tx
         chunk = max(1, min(B, int(os.environ.get('SSQ_GATHER_CHUNK', '8'))))
+        seen = [0]
+        def consume(c0, block):                           # (a real caller reduces / stores the block here)
+            seen[0] += int(block.shape[0] * block.shape[1])
         Tx = step()[0]
-        big = torch.empty((world, chunk) + tuple(Tx.shape[1:]), dtype=Tx.dtype, device=dev)
+        gather_tx(Tx[:chunk], chunk=chunk, consume=consume)   # (warm-up of the collective and its buffer)
         torch.cuda.synchronize(); dist.barrier()
         t1 = time.perf_counter()
         Tx = step()[0]
-        for c0 in range(0, B, chunk):
-            part = Tx[c0:c0 + chunk]
-            if part.shape[0] < chunk:                     # last, short chunk
-                part = torch.cat([part, part.new_zeros((chunk - part.shape[0],) + tuple(part.shape[1:]))])
-            if backend == 'nccl':
-                dist.all_gather_into_tensor(big, part.contiguous())
-            else:
-                parts = [torch.empty_like(part).cpu() for _ in range(world)]
-                dist.all_gather(parts, part.cpu())
+        gather_tx(Tx, chunk=chunk, consume=consume)
         torch.cuda.synchronize(); dist.barrier()
         tg = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather_ms = tg.item() * 1e3
-        del big
 
     # per-stage times of the same workload, HIP events inside the plan on the launch
     # stream (outside the timed region: the plan synchronises while it measures)

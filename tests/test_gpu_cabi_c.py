@@ -49,3 +49,25 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert line['n_gpus'] == 2 and line['ranks'] == 2 and line['scaling'] == 'weak'
     assert line['per_gpu']['signals_per_step'] == 4 and line['value'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_on_one_device_with_the_full_gather(tmp_path):
+    """The driver's N = 8 line, rehearsed: `bench.py --gpus 8 --batch 1 --gather-tx` over gloo with all eight ranks on
+    cuda:0 (round 6). What it checks is plumbing only -- rank arithmetic, each rank's share of the host threads, the
+    summary table at N = 8 and `sharding.gather_tx` (one signal per rank, eight blocks received) -- so that the first
+    run on eight GPUs cannot fail on any of it; no hardware claim follows from its numbers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSQ_BENCH_BACKEND='gloo', SSQ_BENCH_ONE_DEVICE='1')
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '1',
+                          '--warmup', '1', '--batch', '1', '--no-cpu', '--gather-tx', '--n', '20000', '--na', '100'],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 8 and line['ranks'] == 8 and line['scaling'] == 'weak'
+    assert line['per_gpu']['signals_per_step'] == 1 and line['value'] > 0
+    g = line['with_full_tx_gather']
+    assert g['gathered_bytes_per_rank'] == 7 * 1 * 100 * 20000 * 8 and g['transforms_per_s'] > 0

@@ -129,3 +129,52 @@ def test_two_rank_sharded_batch_through_the_emulated_kernels():
         r = oracle_ssq_cwt(orc, two_chirps(256, seed=s), 'float32', scales='log', nv=8)
         ref.append([np.abs(r['Tx']).sum(dtype=np.float64), np.abs(r['Wx']).sum(dtype=np.float64)])
     assert np.allclose(got[0][1], np.array(ref), rtol=1e-5)
+
+
+def _worker_gather_tx(rank, world, port, q):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch
+    from ssqueezepy_amd.sharding import gather_tx
+    b, na, N = 5, 7, 33
+    g = torch.Generator().manual_seed(100 + rank)
+    Tx = torch.complex(torch.randn(b, na, N, generator=g), torch.randn(b, na, N, generator=g))
+    full = gather_tx(Tx, chunk=2)                            # chunks of 2, 2, 1 signals: the last one short
+    blocks = []
+    none = gather_tx(Tx, chunk=3, consume=lambda c0, blk: blocks.append((c0, blk.clone())))
+    q.put((rank, full.numpy(), none is None, [(c0, blk.numpy()) for c0, blk in blocks]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_tx_two_ranks_chunked():
+    """`sharding.gather_tx` (the full-`Tx` gather at the end of a sharded job, round 6: an API of the package instead
+    of a loop inside bench.py): two gloo ranks, 5 signals each, chunks that do not divide the count -- the gathered
+    array is every rank's block in rank order on every rank, and the `consume` form hands out the same data chunk by
+    chunk without keeping it."""
+    import torch
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gather_tx, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b, na, N = 5, 7, 33
+    want = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        want.append(torch.complex(torch.randn(b, na, N, generator=g), torch.randn(b, na, N, generator=g)).numpy())
+    want = np.concatenate(want)
+    for rank, full, none, blocks in got:
+        assert none and full.shape == (world * b, na, N) and np.array_equal(full, want)
+        assert [c0 for c0, _ in blocks] == [0, 3] and [blk.shape[1] for _, blk in blocks] == [3, 2]
+        for c0, blk in blocks:
+            for r in range(world):
+                assert np.array_equal(blk[r], want[r * b + c0: r * b + c0 + blk.shape[1]])
