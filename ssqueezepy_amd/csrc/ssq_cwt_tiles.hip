@@ -287,6 +287,9 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
             if (const char* e = getenv("SSQ_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
             if (const char* e = getenv("SSQ_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
             if ((rc = build(4, TILE3_NW, true, rb3, chg3, 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
+            // (the 16 lanes of a sub-row hold the sample window of the tile's 32 columns: (31 >> lgR) + 8 + 1 <= 16 needs
+            // a decimation of 4 or more -- R_MIN of _tiles.py; SSQ_TILE_RMIN=2 plans go to tile2_kernel)
+            for (int i = 0; i < nsegs; ++i) if (sg[i].kind && sg[i].lgR < 2) tile3_ok = false;
         }
     }
     {   // weights, per class (R phases from wtab_off on): [phase][4 tap pairs] -> [tap pair][phase]
