@@ -347,7 +347,7 @@ int  ssq_cwt_plan_tile_cols(const ssq_cwt_plan* plan);
 /* Which column-tile kernel the next execute launches (ABI 105): 0 none, 1 the ordered float32 tile
  * (SSQ_TILE_ORDER=ordered), 2 the float64 tile with one column per lane (tile2_kernel), 3 the float64 tile with a
  * column pair per lane (tile3_kernel: the default whenever the tile holds 32 columns, i.e. up to 318 rows;
- * SSQ_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
+ * SSQ_DEBUG_TILE_PAIR=0 switches it off). Same results in 2 and 3. */
 int  ssq_cwt_plan_tile_kernel(const ssq_cwt_plan* plan);
 /* Diagnostic (ABI 105): the first `n` (<= 512) 64-bit words of the tile path's counter block -- word 0 = tiles done (as
  * above); words 64.. = per-wavefront shader-clock sums per phase of workgroup 0, filled by profiling builds of the tile

@@ -80,7 +80,7 @@ class CwtPlan():
         self.extended_rows = 0           # Nyquist-cut rows run as block rows (analytic signal)
         self.tile_rows = 0
         self.dt = float(dt)
-        if algo == 0 and os.environ.get('SSQ_CWT_ALGO', 'auto') != 'generic':
+        if algo == 0 and os.environ.get('SSQ_DEBUG_CWT_ALGO', 'auto') != 'generic':
             self._try_blocks(wavelet, vals, off, lo)
 
     def _try_blocks(self, wavelet, vals, off, lo):
@@ -88,7 +88,7 @@ class CwtPlan():
         configuration admits it (padded power-of-two length, analytic
         bank); see _blocks.py. Impulse-response margins are measured on the
         wavelet evaluated in float64 when it is a built-in family."""
-        if self.padtype is None or os.environ.get('SSQ_CWT_ALGO') == 'generic':
+        if self.padtype is None or os.environ.get('SSQ_DEBUG_CWT_ALGO') == 'generic':
             return
         vals64 = None
         fn64 = wavelet.fn if self.dtype == 'float64' else None
@@ -105,9 +105,9 @@ class CwtPlan():
                 vals64 = None
         # rows cut by the Nyquist bin are continued past it and run as block rows over the
         # analytic signal (_blocks.extend_past_nyquist) when the wavelet can be evaluated in
-        # float64 (built-in families); SSQ_CWT_NYQ_EXT=0 keeps them on the exact path
+        # float64 (built-in families); SSQ_DEBUG_CWT_NYQ_EXT=0 keeps them on the exact path
         extension = None
-        if fn64 is not None and os.environ.get('SSQ_CWT_NYQ_EXT', '1') != '0':
+        if fn64 is not None and os.environ.get('SSQ_DEBUG_CWT_NYQ_EXT', '1') != '0':
             tol = self._band_tol if self._band_tol is not None else 1e-3 * np.finfo(self.dtype).eps
             try:
                 _, w_hi = support_hull(wavelet.fn, np.dtype(self.dtype), tol,
@@ -136,13 +136,13 @@ class CwtPlan():
         # block kernels when `Tx` is requested -- their items go to the end of each list
         tp = None
         if self.dtype == 'float32' and os.environ.get('SSQ_CWT_TILES', '1') != '0':
-            # (SSQ_TILE_RMIN: least decimation for which a row leaves the block kernels; tuning aid)
+            # (SSQ_DEBUG_TILE_RMIN: least decimation for which a row leaves the block kernels; tuning aid)
             # (candidates: block rows whose band lies below Nyquist -- the rows continued past it are
             # described by another band than the one plan_tiles is given, and stay block rows)
             tp = plan_tiles(vals, off, lo, self.M, self.N, self.n1, self.dt,
                             (rows[:, 0] >= 0) & ~np.asarray(bp['extended'], bool),
                             self.group, row_scale=self._bank[3],
-                            r_min=int(os.environ.get('SSQ_TILE_RMIN', _tiles_rmin)))
+                            r_min=int(os.environ.get('SSQ_DEBUG_TILE_RMIN', _tiles_rmin)))
         n_items_tile = [0] * 5
         keep = [cls, rows, pbank, pxi, ctw, ctw_off, ftw, gen]
         d = CwtBlocksDesc()
@@ -179,8 +179,7 @@ class CwtPlan():
         wtab, tbank = c(tp['wtab'], np.float32), c(tp['tbank'], np.float32)
         irows, classes = c(tp['irows'], np.int64), c(tp['classes'], np.int64)
         if self.lib.ssq_cwt_tile_rows_per_step() != _tiles_rsub:
-            raise RuntimeError("tile tables built for %d rows per step, the library walks %d "
-                               "(SSQ_TILE_RSUB goes with a -DSSQ_TILE_G build)"
+            raise RuntimeError("tile tables built for %d rows per step, the library walks %d"
                                % (_tiles_rsub, self.lib.ssq_cwt_tile_rows_per_step()))
         d = CwtTilesDesc()
         d.n_segs, d.segs = len(segs), segs.ctypes.data

@@ -53,8 +53,7 @@ COLS = 64             # columns per workgroup of the ordered tile kernel (one pe
 NA_MAX = 512          # rows: a packed record holds 9 bits of row; the float64 tile of the default
                       # kernel (16 B per cell) takes 32 columns up to 318 rows, 16 columns beyond
                       # (the ordered kernel, SSQ_TILE_ORDER=ordered, stops at 318 rows)
-RSUB = int(__import__('os').environ.get('SSQ_TILE_RSUB', '4'))   # rows per step (TILE_G of the kernel; the
-                      # environment override pairs with an A/B build -DSSQ_TILE_G=n)
+RSUB = 4              # rows per step (TILE_G of the kernels)
 STEPS_PER_TICKET = 1  # (steps are handed out one at a time)
 KIND_READBACK, KIND_INTERP = 0, 1
 

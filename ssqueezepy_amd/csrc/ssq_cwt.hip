@@ -235,7 +235,7 @@ int ssq_cwt_plan_create(ssq_cwt_plan** out, const ssq_cwt_desc* desc) {
         // default: up to 16 signals per launch (measured at config 2: 16 -> +1 % over 8), bin maps
         // bounded to ~2 GiB
         int64_t g = std::min<int64_t>(16, std::max<int64_t>(1, ((int64_t)1 << 30) / (d.na * d.n)));
-        if (const char* e = getenv("SSQ_CWT_GROUP")) g = atoi(e);
+        if (const char* e = getenv("SSQ_DEBUG_CWT_GROUP")) g = atoi(e);
         pl->group = (int)std::max<int64_t>(1, std::min<int64_t>(g, pl->d.max_batch));
     }
     TRY(dev_alloc((void**)&pl->kidx, ((size_t)pl->group * d.na * d.n + 64) * 2, pl->bytes));
@@ -478,11 +478,10 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
         mark(2 + 4 * slot + 1);
         if (use_blocks && pl->blk->exact_ok && n_gen > 0) {
             if constexpr (sizeof(T) == 4) {
-                // (SSQ_EXACT_GROUP = n: sub-groups of n signals, so that the four-step intermediate Z --
-                // 4 MB per row and signal -- could stay in the 256 MiB Infinity Cache between the two
-                // passes. Measured on the MI355X at config 2: 16 signals at once 68.9 us per transform,
-                // 4: 76.2, 2: 73.7, 1: 85.3 -- the cache does not pay for the smaller launches.)
-                static const int eg = [] { const char* e = getenv("SSQ_EXACT_GROUP"); int v = e ? atoi(e) : 1 << 20; return v < 1 ? 1 : v; }();
+                // (sub-groups of n signals, so that the four-step intermediate Z -- 4 MB per row and signal -- could stay
+                // in the 256 MiB Infinity Cache between the two passes, were measured on the MI355X at config 2: 16 signals
+                // at once 68.9 us per transform, 4: 76.2, 2: 73.7, 1: 85.3 -- the cache does not pay for the smaller launches)
+                const int eg = ng;
                 for (int s0 = 0; s0 < ng; s0 += eg) {
                     const int ns = std::min(eg, ng - s0);
                     int rc = pl->blk->run_exact((int)b0 + s0, ns, pl->xh, (float*)Wx, (float*)dWx, (float*)w,

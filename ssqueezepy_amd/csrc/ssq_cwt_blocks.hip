@@ -853,8 +853,8 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
         }
     }
     n_generic = d.n_generic;
-    // (SSQ_BLOCK_SPECTRA=rocfft: every class through gather + rocFFT, as in rounds 1-4)
-    own4096 = dtype == SSQ_F32 && M > 4096 && !(getenv("SSQ_BLOCK_SPECTRA") && !strcmp(getenv("SSQ_BLOCK_SPECTRA"), "rocfft"));
+    // (SSQ_DEBUG_BLOCK_SPECTRA=rocfft: every class through gather + rocFFT, as in rounds 1-4)
+    own4096 = dtype == SSQ_F32 && M > 4096 && !(getenv("SSQ_DEBUG_BLOCK_SPECTRA") && !strcmp(getenv("SSQ_DEBUG_BLOCK_SPECTRA"), "rocfft"));
     {   // the CU count of the device the plan lives on (the multi-class launch asks how full a launch is)
         int dev = 0; hipDeviceProp_t pr;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
@@ -977,8 +977,8 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
     A.gamma = sp.gamma; A.sig = sig;
     int rc = 0;
     {   // A transform too small to fill the GPU class by class (C1: five launches of 10-18 us each): one launch.
-        // (SSQ_CWT_BLOCKS_MULTI=0/1 forces; default: when no class has more than two workgroups per CU)
-        const char* fe = getenv("SSQ_CWT_BLOCKS_MULTI");                 // (read per call: tests switch it)
+        // (SSQ_DEBUG_CWT_BLOCKS_MULTI=0/1 forces; default: when no class has more than two workgroups per CU)
+        const char* fe = getenv("SSQ_DEBUG_CWT_BLOCKS_MULTI");                 // (read per call: tests switch it)
         const int force = fe ? atoi(fe) : -1;
         int64_t total = 0, biggest = 0; int used = 0;
         for (int s = 0; s < 5; ++s) {

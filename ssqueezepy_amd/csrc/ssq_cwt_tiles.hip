@@ -27,7 +27,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         SSQ_CHECK_HIP(hipGetDevice(&dev));
         SSQ_CHECK_HIP(hipGetDeviceProperties(&pr, dev));
         ncu = pr.multiProcessorCount;
-        if (const char* e = getenv("SSQ_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
+        if (const char* e = getenv("SSQ_DEBUG_TILE_GRID")) if (atoi(e) > 0) ncu = atoi(e);
         // both tile kernels keep a tile of up to 160 KB in a workgroup's LDS (gfx950); a device with
         // less refuses the tile path here instead of failing at the first launch
         SSQ_REQUIRE((size_t)pr.maxSharedMemoryPerMultiProcessor >= 160 * 1024,
@@ -92,7 +92,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         const TileRow* rw = reinterpret_cast<const TileRow*>(d.rows);
         const TileSeg* sg = reinterpret_cast<const TileSeg*>(d.segs);
         cols2 = tile2_lds_bytes(na, 32) <= 160 * 1024 ? 32 : 16;
-        if (const char* e = getenv("SSQ_TILE2_COLS")) if (atoi(e) == 16) cols2 = 16;     // (tuning aid)
+        if (const char* e = getenv("SSQ_DEBUG_TILE2_COLS")) if (atoi(e) == 16) cols2 = 16;     // (tuning aid)
         SSQ_REQUIRE(tile2_lds_bytes(na, cols2) <= 160 * 1024, "na = %lld: the Tx tile exceeds the LDS", (long long)na);
         lgr_max2 = 0;
         for (int i = 0; i < nsegs; ++i) if (sg[i].kind) lgr_max2 = std::max(lgr_max2, (int)sg[i].lgR);
@@ -160,7 +160,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                 // (measured at config 2, one box: skew 0 / 0.1 / 0.2 / 0.3 -> 193-196 / 187 / 184-186 / 191 us with 16 wavefronts;
                 // no gain with 12)
                 float skew = nw == 16 ? 0.2f : 0.f;
-                if (const char* e = getenv("SSQ_TILE3_SKEW")) skew = (float)atof(e);
+                if (const char* e = getenv("SSQ_DEBUG_TILE3_SKEW")) skew = (float)atof(e);
                 std::vector<double> speed(nw, 1.0);
                 {
                     const int nr = nw / 4;
@@ -230,7 +230,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                     wrec[4 * sl] = first; wrec[4 * sl + 1] = pos; wrec[4 * sl + 2] = isp; wrec[4 * sl + 3] = 0;
                 }
                 if (pos != n_items) ok = false;
-                if (getenv("SSQ_TILE_PLAN_PRINT")) {
+                if (getenv("SSQ_DEBUG_TILE_PLAN_PRINT")) {
                     for (int sl = 0; sl < nw; ++sl)
                         fprintf(stderr, "tile3 wave %2d (simd %d): items %3d..%3d second class at %3d, load %.2f\n", sl, sl % nsimd,
                                 wrec[4 * sl], wrec[4 * sl + 1], wrec[4 * sl + 2], load[list_of_slot[sl]]);
@@ -284,11 +284,11 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
             // (measured with shader-clock stamps, round 6: an item of rows read back costs 0.45 of an interpolated one,
             // re-reading a class's weights 0.65)
             float rb3 = 0.45f, chg3 = 0.65f;
-            if (const char* e = getenv("SSQ_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
-            if (const char* e = getenv("SSQ_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
+            if (const char* e = getenv("SSQ_DEBUG_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
+            if (const char* e = getenv("SSQ_DEBUG_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
             if ((rc = build(4, TILE3_NW, true, rb3, chg3, 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
             // (the 16 lanes of a sub-row hold the sample window of the tile's 32 columns: (31 >> lgR) + 8 + 1 <= 16 needs
-            // a decimation of 4 or more -- R_MIN of _tiles.py; SSQ_TILE_RMIN=2 plans go to tile2_kernel)
+            // a decimation of 4 or more -- R_MIN of _tiles.py; SSQ_DEBUG_TILE_RMIN=2 plans go to tile2_kernel)
             for (int i = 0; i < nsegs; ++i) if (sg[i].kind && sg[i].lgR < 2) tile3_ok = false;
         }
     }
@@ -313,8 +313,8 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
     if ((rc = up(&tbank, d.tbank, (size_t)4 * d.n_tbank))) return rc;
     cls.resize(d.n_classes);
     // classes of 2^14 entries and more: four-step kernels, L = A B with A <= B, both 128 .. 2048
-    // (SSQ_TILE_FFT=rocfft keeps every class on rocFFT)
-    const bool own_fft = !(getenv("SSQ_TILE_FFT") && !strcmp(getenv("SSQ_TILE_FFT"), "rocfft"));
+    // (SSQ_DEBUG_TILE_FFT=rocfft keeps every class on rocFFT)
+    const bool own_fft = !(getenv("SSQ_DEBUG_TILE_FFT") && !strcmp(getenv("SSQ_DEBUG_TILE_FFT"), "rocfft"));
     int64_t y_entries = 0;
     for (int c = 0; c < d.n_classes; ++c) {
         cls[c] = {d.classes[4 * c], d.classes[4 * c + 1], d.classes[4 * c + 2], 0, 0, 0};
@@ -379,11 +379,9 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         ffts.push_back(fp);
     }
     for (int t = 0; t < 5; ++t) n_items_tile[t] = d.n_items_tile[t];
-    if (!getenv("SSQ_TILE_SERIAL")) {
-        SSQ_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-        SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    }
+    SSQ_CHECK_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    SSQ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return 0;
 }
 
@@ -404,11 +402,11 @@ void TilePlan::destroy() {
 // SSQ_TILE_ORDER = ordered: the ticketed kernel (float32 sums in the reference's order, bit for bit; na <=
 // 318); default: tile2_kernel (float64 tile, unordered adds: the same bins, sums rounded once)
 bool tile_ordered() { return reassign_ordered(); }
-// tile3_kernel (two columns per lane): 32-column tiles (up to 318 rows); SSQ_TILE_PAIR=0 keeps tile2_kernel (read at
+// tile3_kernel (two columns per lane): 32-column tiles (up to 318 rows); SSQ_DEBUG_TILE_PAIR=0 keeps tile2_kernel (read at
 // every call)
 bool TilePlan::pair_ok() const {
     if (!tile3_ok || cols2 != 32 || N < 64) return false;
-    const char* e = getenv("SSQ_TILE_PAIR");
+    const char* e = getenv("SSQ_DEBUG_TILE_PAIR");
     return !(e && atoi(e) == 0);
 }
 bool TilePlan::usable() const {

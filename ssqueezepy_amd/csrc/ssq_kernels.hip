@@ -611,8 +611,8 @@ template <typename T, bool CST64>
 static int launch_accumulate_f64(const void* Wx, const void* kidx, void* Tx, const void* cst,
                                  const SsqParams& sp, int64_t batch, int64_t na, int64_t n,
                                  int cols, hipStream_t stream) {
-    // wavefronts per tile (SSQ_ACC64_NW = 4 / 8 / 16, tuning aid; default 8)
-    static const int nw = getenv("SSQ_ACC64_NW") ? atoi(getenv("SSQ_ACC64_NW")) : 8;
+    // wavefronts per tile (SSQ_DEBUG_ACC64_NW = 4 / 8 / 16, tuning aid; default 8)
+    static const int nw = getenv("SSQ_DEBUG_ACC64_NW") ? atoi(getenv("SSQ_DEBUG_ACC64_NW")) : 8;
     if (nw == 16) return launch_accumulate_f64_w<T, CST64, 16>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
     if (nw == 4) return launch_accumulate_f64_w<T, CST64, 4>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
     return launch_accumulate_f64_w<T, CST64, 8>(Wx, kidx, Tx, cst, sp, batch, na, n, cols, stream);
@@ -654,7 +654,7 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
         // known bins: the unordered float64 tile (see accumulate_f64_kernel) unless the caller
         // asked for the ordered sums or wants the bin map back
         int cols = f64_tile_cols<T>(na, lds_cap);
-        static const int cols_env = getenv("SSQ_ACC64_COLS") ? atoi(getenv("SSQ_ACC64_COLS")) : 0;   // (tuning aid)
+        static const int cols_env = getenv("SSQ_DEBUG_ACC64_COLS") ? atoi(getenv("SSQ_DEBUG_ACC64_COLS")) : 0;   // (tuning aid)
         if ((cols_env == 8 || cols_env == 16 || cols_env == 32) && (size_t)na * cols_env * 16 <= lds_cap) cols = cols_env;
         if (!reassign_ordered() && !kmap && cols && (size_t)na * (size_t)n < ((size_t)1 << 31))
             return launch_accumulate_f64<T, CST64>(Wx, src, Tx, cst, sp, batch, na, n, cols, stream);
@@ -676,7 +676,7 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
         size_t lds = (size_t)na * 16 * cell;
         if ((size_t)na * (size_t)n < ((size_t)1 << 31)) {      // 32-bit offsets inside
             dim3 grid((unsigned)(((n + 15) / 16 + 7) / 8 * 8), (unsigned)batch);
-            static const int variant = getenv("SSQ_ACC_VARIANT") ? atoi(getenv("SSQ_ACC_VARIANT")) : 0;
+            static const int variant = getenv("SSQ_DEBUG_ACC_VARIANT") ? atoi(getenv("SSQ_DEBUG_ACC_VARIANT")) : 0;
             if (variant != 2) {        // row-lane layouts (variant 2: one wavefront per tile, quads)
                 // Row batches in flight per lane. Measured (config 2, float32), 16 row-lanes:
                 // U = 2: 257 us, 3: 263, 4: 259, 8: 278; 8 row-lanes: U = 1: 314, 2: 246, 3: 240,
@@ -688,7 +688,7 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
                 // per wavefront, 2 wavefronts per 16-column tile (240 us at config 2 vs 250 with 16
                 // row-lanes); float64 -> 16 row-lanes x 4 columns, 4 wavefronts (config 5: 22.7 vs
                 // 23.6 ms).
-                // SSQ_ACC_VARIANT = 1 / 3 force the 16- / 8-lane layout.
+                // SSQ_DEBUG_ACC_VARIANT = 1 / 3 force the 16- / 8-lane layout.
                 if ((variant == 0 || variant == 9) && sizeof(T) == 4 &&
                     (size_t)na * 32 * cell <= lds_cap / 2) {
                     // float32 default: 32-column tiles of four 8-lane wavefronts (256-byte row
@@ -715,7 +715,7 @@ static int launch_accumulate_t(const void* Wx, const void* src, const void* Sfs,
                 hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, (const T*)Wx, src, (const T*)Sfs,
                                    (T*)Tx, cst, sp, na, n, kmap);
                 }
-            } else {                   // SSQ_ACC_VARIANT=2: one wave per tile, quads (tuning aid)
+            } else {                   // SSQ_DEBUG_ACC_VARIANT=2: one wave per tile, quads (tuning aid)
                 constexpr int U = sizeof(T) == 4 ? 16 : 8;
                 auto kern = accumulate_quad_kernel<T, BINSRC, STFT, CST64, U>;
                 SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

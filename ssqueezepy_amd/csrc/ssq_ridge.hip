@@ -193,7 +193,7 @@ template <typename T, typename TP>
 static RidgeGeom ridge_geometry(int64_t na) {
     RidgeGeom g;
     g.F = 4; g.creg = 0; g.nt = 1024;
-    static const bool no_reg = getenv("SSQ_RIDGE_GENERIC") != nullptr;
+    static const bool no_reg = getenv("SSQ_DEBUG_RIDGE_GENERIC") != nullptr;
     if (sizeof(TP) == 4 && !no_reg) {
         const int fc[3][2] = {{4, 16}, {4, 32}, {5, 40}};      // instantiated below
         for (int i = 0; i < (sizeof(T) == 4 ? 3 : 1); ++i)

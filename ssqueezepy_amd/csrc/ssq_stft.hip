@@ -154,7 +154,7 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
 template <int L, int G, int R1, int R2, int R3>
 static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_t batch, hipStream_t stream) {
     SSQ_REQUIRE(!A.Tx || A.rows == L / 2 + 1, "fused reassignment: %lld rows, transform of %d", (long long)A.rows, L);
-    static const bool remap = [] { const char* e = getenv("SSQ_STFT_XCD"); return !e || atoi(e) != 0; }();
+    static const bool remap = [] { const char* e = getenv("SSQ_DEBUG_STFT_XCD"); return !e || atoi(e) != 0; }();
     StftFusedArgs B = A;
     unsigned nb = (unsigned)((A.n_hops + G - 1) / G);
     B.xcd = remap && nb >= 64;
@@ -266,9 +266,9 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
     TRYA(pl->xp, (size_t)pl->d.max_batch * pl->padlen * rs);
 #undef TRYA
     const bool pow2 = (d.n_fft & (d.n_fft - 1)) == 0;
-    // (SSQ_STFT_MIXED=1: the mixed-radix kernel for the powers of two as well -- A/B aid)
-    const bool prefer_mixed = getenv("SSQ_STFT_MIXED") && atoi(getenv("SSQ_STFT_MIXED")) != 0;
-    if (d.dtype == SSQ_F32 && pow2 && d.n_fft >= 128 && d.n_fft <= 2048 && !getenv("SSQ_STFT_GENERIC") && !prefer_mixed) {
+    // (SSQ_DEBUG_STFT_MIXED=1: the mixed-radix kernel for the powers of two as well -- A/B aid)
+    const bool prefer_mixed = getenv("SSQ_DEBUG_STFT_MIXED") && atoi(getenv("SSQ_DEBUG_STFT_MIXED")) != 0;
+    if (d.dtype == SSQ_F32 && pow2 && d.n_fft >= 128 && d.n_fft <= 2048 && !getenv("SSQ_DEBUG_STFT_GENERIC") && !prefer_mixed) {
         std::vector<float> tw((size_t)2 * d.n_fft);
         for (int64_t q = 0; q < d.n_fft; ++q) {
             double ang = 2.0 * 3.14159265358979323846 * (double)q / (double)d.n_fft;
@@ -277,7 +277,7 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
         if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
         SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
         pl->fused = true;
-    } else if (d.dtype == SSQ_F32 && !getenv("SSQ_STFT_GENERIC")
+    } else if (d.dtype == SSQ_F32 && !getenv("SSQ_DEBUG_STFT_GENERIC")
                && stft_generic_plan(d.n_fft, pl->gen_radix, &pl->gen_npass, &pl->gen_G)) {
         std::vector<float> tw((size_t)2 * d.n_fft);
         for (int64_t q = 0; q < d.n_fft; ++q) {
@@ -380,8 +380,8 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             use_kidx = true;
             // (measured, C3: one signal 68 us against 72 with the separate pass; 512 signals 2.75 ms against
             // 2.35 -- a workgroup's Tx goes out as G * 8-byte pieces and the tile halves the occupancy, so
-            // the fused sums serve the calls that do not fill the GPU; SSQ_STFT_FUSED_TX=0/1 forces)
-            const char* fe = getenv("SSQ_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
+            // the fused sums serve the calls that do not fill the GPU; SSQ_DEBUG_STFT_FUSED_TX=0/1 forces)
+            const char* fe = getenv("SSQ_DEBUG_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
             const int force = fe ? atoi(fe) : -1;
             fused_tx = pl->fused && !reassign_ordered() && rows == n_fft / 2 + 1 &&
                        (force >= 0 ? force != 0 : batch * n_hops <= 4096);

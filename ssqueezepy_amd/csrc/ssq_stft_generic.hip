@@ -200,7 +200,7 @@ bool stft_generic_plan(int64_t n, int* radix, int* npass, int* G) {
 
 int launch_stft_generic(const StftFusedArgs& A, const SsqParams& sp, const c32* tw, int n, const int* radix,
                                int npass, int G, int64_t batch, hipStream_t stream) {
-    static const bool remap = [] { const char* e = getenv("SSQ_STFT_XCD"); return !e || atoi(e) != 0; }();
+    static const bool remap = [] { const char* e = getenv("SSQ_DEBUG_STFT_XCD"); return !e || atoi(e) != 0; }();
     StftGenArgs B;
     B.F = A; B.tw = tw; B.n = n; B.G = G; B.npass = npass;
     B.lgG = 0; while ((1 << B.lgG) < G) ++B.lgG;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * NW) void tile2_kernel(Tile2Args A, SsqParams s
     // workgroups of an XCD walk 32 ADJACENT tiles at a time: neighbouring tiles read overlapping windows of the decimated
     // samples (8 taps of halo; for R >= 64 the very same samples), which then meet in one L2 instead of being fetched
     // from HBM once per tile. The stride between a workgroup's tiles stays G, so the lanes' weight phase is kept.
-    // (SSQ_TILE2_XCD=0 in the launcher's environment: the identity.)
+    // (SSQ_DEBUG_TILE2_XCD=0 in the launcher's environment: the identity.)
     const int bid = (A.xcd && (G & 7) == 0) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     const int per_sig = bid < ntx ? (ntx - bid + G - 1) / G : 0;
     const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - bid + G - 1) / G)
@@ -476,12 +476,12 @@ static int launch_tile2_c(const TilePlan& P, const Tile2Args& A, const SsqParams
     const int64_t q = std::max<int64_t>(1, ((int64_t)1 << P.lgr_max2) / COLS);
     const int64_t G = ntx <= cap ? ntx : std::max<int64_t>(q, cap / q * q);
     // ... and through the signals' boundaries when a signal's tile count keeps that phase too
-    // (SSQ_TILE2_CARRY=0: every signal's walk starts at the workgroup's own tile)
-    const char* ce = getenv("SSQ_TILE2_CARRY");              // (read per launch: tests switch it)
+    // (SSQ_DEBUG_TILE2_CARRY=0: every signal's walk starts at the workgroup's own tile)
+    const char* ce = getenv("SSQ_DEBUG_TILE2_CARRY");              // (read per launch: tests switch it)
     const bool carry_on = !(ce && atoi(ce) == 0);
     Tile2Args B = A;
     B.carry = (carry_on && ntx > G && ntx % q == 0) ? 1 : 0;
-    const char* xe = getenv("SSQ_TILE2_XCD");                 // (read per launch)
+    const char* xe = getenv("SSQ_DEBUG_TILE2_XCD");                 // (read per launch)
     B.xcd = !(xe && atoi(xe) == 0) && G >= 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();

@@ -7,7 +7,7 @@
 //   classes of 2^13 .. 2^22 entries: `tilefft_four_kernel<1 / 2>`, a four-step transform whose first pass forms
 //   the band on the fly (the zero-padded spectrum never exists in memory). Three launches per launch group for
 //   all classes. `tile_spectra_kernel` + a batched rocFFT inverse per class is the older route
-//   (SSQ_TILE_FFT=rocfft). Math and planning: ssqueezepy_amd/_tiles.py; the reference evaluates the same rows as
+//   (SSQ_DEBUG_TILE_FFT=rocfft). Math and planning: ssqueezepy_amd/_tiles.py; the reference evaluates the same rows as
 //   full-length inverse FFTs (ssqueezepy/_cwt.py:167-177).
 #include "ssq_common.h"
 #include "ssq_tiles.h"
@@ -356,7 +356,7 @@ int TilePlan::spectra(int sig, int nsig, const void* xh_all, hipStream_t stream)
 // ---- the analytic signal through the four-step kernels (ssq_tiles.h)
 bool AnalyticFft::supports(int dtype, int64_t M) {
     if (dtype != SSQ_F32 || (M & (M - 1))) return false;
-    if (getenv("SSQ_TILE_FFT") && !strcmp(getenv("SSQ_TILE_FFT"), "rocfft")) return false;
+    if (getenv("SSQ_DEBUG_TILE_FFT") && !strcmp(getenv("SSQ_DEBUG_TILE_FFT"), "rocfft")) return false;
     return M >= ((int64_t)1 << 13) && M <= ((int64_t)1 << 22);
 }
 int AnalyticFft::create(int64_t M_, int64_t max_batch_, int64_t& bytes) {

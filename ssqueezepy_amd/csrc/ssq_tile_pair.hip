@@ -486,11 +486,11 @@ static int launch_tile3_c(const TilePlan& P, const Tile3Args& A, const SsqParams
     const int64_t cap = (int64_t)P.ncu;
     const int64_t q = std::max<int64_t>(1, ((int64_t)1 << P.lgr_max2) / T3_COLS);
     const int64_t G = ntx <= cap ? ntx : std::max<int64_t>(q, cap / q * q);
-    const char* ce = getenv("SSQ_TILE2_CARRY");              // (read per launch: tests switch it)
+    const char* ce = getenv("SSQ_DEBUG_TILE2_CARRY");              // (read per launch: tests switch it)
     const bool carry_on = !(ce && atoi(ce) == 0);
     Tile3Args B = A;
     B.carry = (carry_on && ntx > G && ntx % q == 0) ? 1 : 0;
-    const char* xe = getenv("SSQ_TILE2_XCD");                 // (read per launch)
+    const char* xe = getenv("SSQ_DEBUG_TILE2_XCD");                 // (read per launch)
     B.xcd = !(xe && atoi(xe) == 0) && G >= 16;
     hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(64 * TILE3_NW), lds, stream, B, sp);
     SSQ_LAUNCH_CHECK();

@@ -86,7 +86,7 @@ struct TilePlan {
     void* items3 = nullptr; int32_t* wave_first3 = nullptr;
     int n_items3 = 0;
     bool tile3_ok = false;
-    bool pair_ok() const;                   // tile3_kernel takes this plan (32-column tile, SSQ_TILE_PAIR != 0)
+    bool pair_ok() const;                   // tile3_kernel takes this plan (32-column tile, SSQ_DEBUG_TILE_PAIR != 0)
     int tile_kernel() const;                // 0 none, 1 ordered, 2 tile2_kernel, 3 tile3_kernel (what `run` launches now)
     int tile_cols() const;                  // columns per tile of the kernel that `run` launches (0: none can run)
     // Can `run` launch a tile kernel for this plan in the mode selected right now? The default kernel needs the

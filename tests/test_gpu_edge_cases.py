@@ -139,13 +139,13 @@ def test_fused_stft_every_size(S, orc, n_fft):
         assert np.array_equal(Sxb[0], Sx)
         assert_tx_vs_oracle(Txb[0], Tx)        # (bin map + float64 sums vs the ordered sums above)
         # the generic (rocFFT) path of this engine on the same input
-        os.environ['SSQ_STFT_GENERIC'] = '1'
+        os.environ['SSQ_DEBUG_STFT_GENERIC'] = '1'
         try:
             _stft._PLAN_CACHE.clear()
             Sx2, dSx2 = S.stft(x, n_fft=n_fft, hop_len=hop, modulated=mod, derivative=True,
                                dtype='float32', astensor=False)
         finally:
-            del os.environ['SSQ_STFT_GENERIC']
+            del os.environ['SSQ_DEBUG_STFT_GENERIC']
             _stft._PLAN_CACHE.clear()
         assert relmax(Sx2, ro['Sx']) <= 1e-5 and relmax(Sx, Sx2) <= 1e-5
         assert relmax(dSx, dSx2) <= 1e-5
@@ -230,7 +230,7 @@ def test_batches_larger_than_a_launch_group(S):
 @pytest.mark.parametrize('N', [100000, 1 << 20])
 def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
     """The long classes of the tile path's intermediates on the four-step kernels (default) against
-    the same transform with every class on rocFFT (SSQ_TILE_FFT=rocfft): N = 100 000 covers
+    the same transform with every class on rocFFT (SSQ_DEBUG_TILE_FFT=rocfft): N = 100 000 covers
     L = 2^14 .. 2^16, N = 2^20 (padded to 2^21) the factors up to 512 x 1024; batched == single."""
     needs_tile_path()
     from ssqueezepy_amd import _cwt
@@ -241,7 +241,7 @@ def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
     wav = S.Wavelet()
     res = {}
     for mode in ('own', 'rocfft'):
-        monkeypatch.setenv('SSQ_TILE_FFT', mode)
+        monkeypatch.setenv('SSQ_DEBUG_TILE_FFT', mode)
         _cwt.clear_plan_cache()
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -252,7 +252,7 @@ def test_tile_intermediates_four_step_vs_rocfft(S, N, monkeypatch):
     for k in range(2):
         d = np.abs(res['own'][k] - res['rocfft'][k]).max() / np.abs(res['rocfft'][k]).max()
         assert d <= 2e-6, (k, d)
-    monkeypatch.setenv('SSQ_TILE_FFT', 'own')
+    monkeypatch.setenv('SSQ_DEBUG_TILE_FFT', 'own')
     _cwt.clear_plan_cache()
     xb = np.stack([x, x[::-1].copy()])
     Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
@@ -394,7 +394,7 @@ def test_more_rows_than_the_32_column_tile_holds(S, orc, tile_mode):
 @pytest.mark.parametrize('N', [4096, 4098, 4099, 4097, 8192 - 2 * 33, 8192 - 2 * 32 - 1, 20010])
 def test_pair_kernel_equals_single_column_kernel(S, N, monkeypatch):
     """Round 6: the default tile kernel gives a lane a PAIR of neighbouring columns (csrc/ssq_tile_pair.hip,
-    `plan.tile_kernel == 3`); `SSQ_TILE_PAIR=0` keeps the one-column-per-lane kernel of rounds 4-5 (2). Same arithmetic
+    `plan.tile_kernel == 3`); `SSQ_DEBUG_TILE_PAIR=0` keeps the one-column-per-lane kernel of rounds 4-5 (2). Same arithmetic
     per point, so `Wx` and `dWx` must agree bit for bit and `Tx` as two runs of one kernel do -- for even and odd
     lengths, odd left paddings (the pair kernel's tiles then start one column early: n1 = 2047, 2046, 33, 33 here), a
     partial last tile, a first tile with a dead column, and a batch that the walk carries through."""
@@ -406,7 +406,7 @@ def test_pair_kernel_equals_single_column_kernel(S, N, monkeypatch):
     wav = S.Wavelet()
     out = {}
     for pair in ('1', '0'):
-        monkeypatch.setenv('SSQ_TILE_PAIR', pair)
+        monkeypatch.setenv('SSQ_DEBUG_TILE_PAIR', pair)
         _cwt.clear_plan_cache()
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(xb, wav, scales='log', nv=16, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))

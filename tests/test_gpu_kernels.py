@@ -190,7 +190,7 @@ def test_error_paths(A):
 
 
 def test_quad_variant_of_accumulate_is_bit_identical(orc):
-    """SSQ_ACC_VARIANT=2 selects the one-wave-per-tile (DPP quad) build of the
+    """SSQ_DEBUG_ACC_VARIANT=2 selects the one-wave-per-tile (DPP quad) build of the
     reassignment kernel; it must produce the same bits. Run in a subprocess because the
     variant is latched at first launch."""
     import subprocess, sys, os
@@ -214,7 +214,7 @@ for dtype in ('float32', 'float64'):
 print("QUAD_OK")
 ''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
        os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSQ_ACC_VARIANT='2')
+    env = dict(os.environ, SSQ_DEBUG_ACC_VARIANT='2')
     res = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True,
                          timeout=600)
     assert 'QUAD_OK' in res.stdout, res.stdout + res.stderr

@@ -307,7 +307,7 @@ def test_full_size_bin_map_exact(S, orc):
 @pytest.mark.parametrize('N,nv,wavelet', [(20011, 8, 'gmw'), (70001, 8, 'morlet'), (70001, 4, 'morlet')])
 def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, monkeypatch):
     """Rows cut by the Nyquist bin: continued past it and run by the block kernels over the
-    analytic signal (default; _blocks.extend_past_nyquist) -- and, with SSQ_CWT_NYQ_EXT=0, on the
+    analytic signal (default; _blocks.extend_past_nyquist) -- and, with SSQ_DEBUG_CWT_NYQ_EXT=0, on the
     exact paths they had before (float32: four-step kernels, float64: banded multiply + rocFFT).
     Both against the oracle of the reference's full-length algorithm, and against each other."""
     from ssqueezepy_amd import _cwt
@@ -317,7 +317,7 @@ def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, mo
     r = oracle_ssq_cwt(orc, x, dtype, wavelet=wavelet, scales='log', nv=nv, typing=1)
     out = {}
     for ext in ('1', '0'):
-        monkeypatch.setenv('SSQ_CWT_NYQ_EXT', ext)
+        monkeypatch.setenv('SSQ_DEBUG_CWT_NYQ_EXT', ext)
         _cwt.clear_plan_cache()
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -363,7 +363,7 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
     check_Tx(orc, Tx, Wx, dWx, r, dtype)
     assert np.abs(Tx.sum(0) - r['Tx'].sum(0)).max() <= 10 * tol * np.abs(r['Tx'].sum(0)).max()
     # exact path of this engine on the same input
-    os.environ['SSQ_CWT_ALGO'] = 'generic'
+    os.environ['SSQ_DEBUG_CWT_ALGO'] = 'generic'
     try:
         _cwt.clear_plan_cache()
         Tx2, Wx2, _, _, dWx2 = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True,
@@ -371,7 +371,7 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
         plan2 = next(iter(_cwt._PLAN_CACHE.values()))
         assert plan2.algo == 'rocfft'
     finally:
-        del os.environ['SSQ_CWT_ALGO']
+        del os.environ['SSQ_DEBUG_CWT_ALGO']
         _cwt.clear_plan_cache()
     assert relmax(Wx2, r['Wx']) <= tol and relmax(dWx2, r['dWx']) <= tol
     assert relmax(Wx, Wx2) <= tol

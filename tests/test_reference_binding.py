@@ -50,7 +50,7 @@ def test_nyquist_rows_against_the_reference_itself():
     emu_backend.build()
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, 'oracle', 'refshim'), REF]),
                SSQ_GPU='0', MPLBACKEND='Agg')
-    env.pop('SSQ_CWT_NYQ_EXT', None)
+    env.pop('SSQ_DEBUG_CWT_NYQ_EXT', None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'refbinding', 'cwt_vs_reference.py')],
                          capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -91,7 +91,7 @@ def test_nyquist_rows_as_block_rows_vs_oracle(S, orc, dtype, monkeypatch):
     r = oracle_ssq_cwt(orc, x, dtype, scales='log', nv=nv, typing=1)
     out = {}
     for ext in ('1', '0'):
-        monkeypatch.setenv('SSQ_CWT_NYQ_EXT', ext)
+        monkeypatch.setenv('SSQ_DEBUG_CWT_NYQ_EXT', ext)
         _cwt.clear_plan_cache()
         Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -128,7 +128,7 @@ def test_block_classes_in_one_launch_emulated(S, monkeypatch):
     wav = S.Wavelet()
     out = {}
     for multi in ('0', '1'):
-        monkeypatch.setenv('SSQ_CWT_BLOCKS_MULTI', multi)
+        monkeypatch.setenv('SSQ_DEBUG_CWT_BLOCKS_MULTI', multi)
         _cwt.clear_plan_cache()
         Wx, sc, dWx = S.cwt(x, wav, scales='log', nv=16, derivative=True, astensor=False)
         plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -143,19 +143,19 @@ def test_block_classes_in_one_launch_emulated(S, monkeypatch):
 def test_tile_walk_through_signal_boundaries_emulated(S, monkeypatch):
     """tile2_kernel's workgroups walk tiles b, b + G, ... of the signals laid end to end (no short last round per
     signal) when the lanes' resident weights survive the boundary: same results as the walk that restarts at every
-    signal (SSQ_TILE2_CARRY=0); 6 and 4 workgroups over 80 / 126 tiles x 3 signals, so that the boundary shifts.
+    signal (SSQ_DEBUG_TILE2_CARRY=0); 6 and 4 workgroups over 80 / 126 tiles x 3 signals, so that the boundary shifts.
     (Round 5: with 16 workgroups and more the workgroups' first tiles are permuted per XCD -- workgroup b starts at tile
-    (b mod 8) G / 8 + b / 8 -- so that the workgroups of one XCD walk adjacent tiles; SSQ_TILE2_XCD=0 is the identity:
+    (b mod 8) G / 8 + b / 8 -- so that the workgroups of one XCD walk adjacent tiles; SSQ_DEBUG_TILE2_XCD=0 is the identity:
     same results, both walks.)"""
     from conftest import two_chirps
     from ssqueezepy_amd import _cwt
     for grid, N in (('6', 2560), ('4', 4003), ('16', 2560), ('24', 4003)):
-        monkeypatch.setenv('SSQ_TILE_GRID', grid)
+        monkeypatch.setenv('SSQ_DEBUG_TILE_GRID', grid)
         xb = np.stack([two_chirps(N, seed=s) for s in range(3)])
         out = {}
         for carry, xcd in (('0', '1'), ('1', '1'), ('0', '0'), ('1', '0')):
-            monkeypatch.setenv('SSQ_TILE2_CARRY', carry)
-            monkeypatch.setenv('SSQ_TILE2_XCD', xcd)
+            monkeypatch.setenv('SSQ_DEBUG_TILE2_CARRY', carry)
+            monkeypatch.setenv('SSQ_DEBUG_TILE2_XCD', xcd)
             _cwt.clear_plan_cache()
             Tx, Wx, *_ = S.ssq_cwt(xb, S.Wavelet(), scales='log', nv=16, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -320,7 +320,7 @@ def test_tile_intermediates_four_step_emulated(monkeypatch):
         wav = S.Wavelet()
         res = {}
         for mode in ('own', 'rocfft'):
-            monkeypatch.setenv('SSQ_TILE_FFT', mode)
+            monkeypatch.setenv('SSQ_DEBUG_TILE_FFT', mode)
             _cwt.clear_plan_cache()
             Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, get_dWx=True, astensor=False)
             plan = next(iter(_cwt._PLAN_CACHE.values()))
@@ -331,7 +331,7 @@ def test_tile_intermediates_four_step_emulated(monkeypatch):
         for k in range(2):
             assert relmax(res['own'][k], res['rocfft'][k]) <= 1e-6
         assert relmax(res['own'][0], r['Wx']) <= 1e-5 and relmax(res['own'][1], r['dWx']) <= 1e-5
-        monkeypatch.setenv('SSQ_TILE_FFT', 'own')
+        monkeypatch.setenv('SSQ_DEBUG_TILE_FFT', 'own')
         _cwt.clear_plan_cache()
         xb = np.stack([x, x[::-1].copy()])
         Tb, Wb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
@@ -385,7 +385,7 @@ def test_tile_path_emulated_fewer_steps_than_wavefronts(tile_mode):
 
 def test_pair_kernel_equals_single_column_kernel_emulated(monkeypatch):
     """Round 6, under the emulator: the tile kernel with a column PAIR per lane (csrc/ssq_tile_pair.hip, the default) against
-    the one-column-per-lane kernel (`SSQ_TILE_PAIR=0`): the same arithmetic per point -- `Wx`, `dWx` bit for bit, `Tx` as
+    the one-column-per-lane kernel (`SSQ_DEBUG_TILE_PAIR=0`): the same arithmetic per point -- `Wx`, `dWx` bit for bit, `Tx` as
     two runs of one kernel -- for even / odd lengths, odd left paddings (tiles start one column early), partial last
     tiles, a two-signal batch and both default grids. See tests/test_gpu_edge_cases.py for the device's run."""
     import emu_backend
@@ -397,7 +397,7 @@ def test_pair_kernel_equals_single_column_kernel_emulated(monkeypatch):
             xb = np.stack([two_chirps(N, seed=N + s) for s in range(2)])
             out = {}
             for pair in ('1', '0'):
-                monkeypatch.setenv('SSQ_TILE_PAIR', pair)
+                monkeypatch.setenv('SSQ_DEBUG_TILE_PAIR', pair)
                 _cwt.clear_plan_cache()
                 Tx, Wx, sf, sc, dWx = S.ssq_cwt(xb, S.Wavelet(), scales=st, nv=16, get_dWx=True, astensor=False)
                 plan = next(iter(_cwt._PLAN_CACHE.values()))

@@ -13,12 +13,12 @@ run() {  # label, env assignments...
 }
 run default            SSQ_NONE=1
 run default-again      SSQ_NONE=1
-run group=4            SSQ_CWT_GROUP=4
-run group=2            SSQ_CWT_GROUP=2
-run acc=16lanes        SSQ_ACC_VARIANT=1
-run acc=8lanes-tc16    SSQ_ACC_VARIANT=3
-run generic-cwt        SSQ_CWT_ALGO=generic
-for v in 1 0; do SSQ_STFT_XCD=$v python tools/run_configs.py c3 2>/dev/null | tail -1 | cut -c1-140; done
+run group=4            SSQ_DEBUG_CWT_GROUP=4
+run group=2            SSQ_DEBUG_CWT_GROUP=2
+run acc=16lanes        SSQ_DEBUG_ACC_VARIANT=1
+run acc=8lanes-tc16    SSQ_DEBUG_ACC_VARIANT=3
+run generic-cwt        SSQ_DEBUG_CWT_ALGO=generic
+for v in 1 0; do SSQ_DEBUG_STFT_XCD=$v python tools/run_configs.py c3 2>/dev/null | tail -1 | cut -c1-140; done
 python tools/stft_hop1_probe.py 2>/dev/null | tail -1 | cut -c1-120
 RIDGE_N=40000 python tools/run_configs.py ridges 2>/dev/null | tail -1
-SSQ_RIDGE_GENERIC=1 RIDGE_N=40000 python tools/run_configs.py ridges 2>/dev/null | tail -1
+SSQ_DEBUG_RIDGE_GENERIC=1 RIDGE_N=40000 python tools/run_configs.py ridges 2>/dev/null | tail -1

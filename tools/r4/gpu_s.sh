@@ -3,7 +3,7 @@
 cd /root/repo; O=gpurun_out/r4s; mkdir -p $O; rm -f gpurun_out/parity_measured.jsonl
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/gpu_suite.txt 2>&1; tail -5 $O/gpu_suite.txt | cut -c1-300
 cp gpurun_out/parity_measured.jsonl $O/ 2>/dev/null
-for v in "" "SSQ_TILE_ORDER=ordered" "SSQ_ACC64_NW=16" "SSQ_ACC64_NW=4" "SSQ_ACC64_COLS=16" "SSQ_ACC64_COLS=32"; do
+for v in "" "SSQ_TILE_ORDER=ordered" "SSQ_DEBUG_ACC64_NW=16" "SSQ_DEBUG_ACC64_NW=4" "SSQ_DEBUG_ACC64_COLS=16" "SSQ_DEBUG_ACC64_COLS=32"; do
   echo "== $v" >> $O/configs.txt
   env $v timeout 600 python tools/run_configs.py c3 c5 >> $O/configs.txt 2>&1
 done
