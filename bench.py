@@ -121,7 +121,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='signals per GPU per step')
-    ap.add_argument('--n', type=int, default=160000)
+    ap.add_argument('--n', '--length', dest='n', type=int, default=160000)
     ap.add_argument('--na', type=int, default=300)
     ap.add_argument('--scales', default='log', choices=['log', 'log-piecewise'],
                     help="'log' = BASELINE config 2 (the first --na of nv=32 log scales); "
@@ -145,7 +145,9 @@ def main():
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
                '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               '--master-port', str(port), os.path.abspath(__file__)]
+        # (torch.distributed.run's parser takes a bare `--n` for an abbreviation of its own options, even behind the script)
+        cmd += ['--length' + a[3:] if a == '--n' or a.startswith('--n=') else a for a in sys.argv[1:]]
         sys.exit(subprocess.call(cmd, env=env))
     if int(os.environ.get('WORLD_SIZE', 1)) != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get('WORLD_SIZE', '1')))

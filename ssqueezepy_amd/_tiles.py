@@ -49,6 +49,9 @@ SIGMA_MIN = 2.0       # least oversampling of a decimated row
 R_MIN = 4             # least decimation for which a row leaves the block kernels
 R_MAX = 4096
 L_MINLEN = 64         # shortest decimated row
+MIN_CLASS_ROWS = 16   # a shorter run of rows with a decimation of its own joins the run before it ...
+MERGE_MAX_OCTAVES = 3 # ... when that costs it at most 8 times the samples it needs ...
+MERGE_MIN_ROWS = 64   # ... in a plan with at least this many interpolated rows
 COLS = 64             # columns per workgroup of the ordered tile kernel (one per lane)
 NA_MAX = 512          # rows: a packed record holds 9 bits of row; the float64 tile of the default
                       # kernel (16 B per cell) takes 32 columns up to 318 rows, 16 columns beyond
@@ -115,6 +118,29 @@ def plan_tiles(vals, off, lo, M, N, n1, dt, block_rows, group, row_scale=None,
     interp = lgR >= 0
     if not interp.any():
         return None
+    # Short classes join their predecessor. The kernels keep one class's interpolation weights in registers and
+    # re-read them at a class change, and the host deals whole classes to wavefronts (csrc/ssq_cwt_tiles.hip): a run
+    # of a few rows with a decimation of its own -- 'log-piecewise' scales double every 8 rows in their upper part --
+    # costs more in class changes than its rows cost in arithmetic. A row may always be sampled MORE densely than it
+    # needs (smaller R: sigma grows, the kernel's error shrinks), so a run shorter than MIN_CLASS_ROWS takes the
+    # decimation of the run before it when that one is smaller (rows are in scale order: it is). Its samples take
+    # 2^d times the room of a class that had few rows and short rows anyway.
+    i = 0 if interp.sum() >= MERGE_MIN_ROWS else na              # (a handful of rows: more wavefronts than items anyway)
+    prev_lg, prev_len = None, 0
+    while i < na:
+        j = i
+        while j < na and lgR[j] == lgR[i]:
+            j += 1
+        lg = int(lgR[i])
+        if lg >= 0:
+            if prev_lg is not None and 0 <= prev_lg < lg <= prev_lg + MERGE_MAX_OCTAVES and (j - i) < MIN_CLASS_ROWS:
+                lgR[i:j] = prev_lg                       # (joins the run before it; the merged run goes on growing)
+                prev_len += j - i
+            else:
+                prev_lg, prev_len = lg, j - i
+        else:
+            prev_lg, prev_len = None, 0
+        i = j
 
     # ---- classes (one per decimation), intermediates layout, compensated band values
     used = sorted(set(int(v) for v in lgR[interp]))
