@@ -100,53 +100,14 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         // 0.5 .. 1.2: 221 / 223 / 222 / 228 / 225 us, round 4)
         // chg_cost < 0: tile2_kernel's contiguous blocks; >= 0: tile3_kernel's dealt lists (see below), a class change
         // inside a wavefront's list costing that many items (max_cls = 2: both classes' weights resident, no cost)
-        // pair_cost > 0 (tile3_kernel): an interpolated item is TWO consecutive steps of its class (8 rows: the item's
-        // scalar work is paid once for both; the last step of a class with an odd count stays alone) and costs
-        // pair_cost single steps; `kcb_dev` receives the centre bins of every item's second step
-        auto build = [&](int rpi, int nw, bool woff_in_record, float rb_cost, float chg_cost, int max_cls, float pair_cost,
-                         void** items_dev, int32_t** waves_dev, void** kcb_dev, int& n_items, bool& ok) -> int {
+        auto build = [&](int rpi, int nw, bool woff_in_record, float rb_cost, float chg_cost, int max_cls,
+                         void** items_dev, int32_t** waves_dev, int& n_items, bool& ok) -> int {
             SSQ_REQUIRE(TILE_G % rpi == 0, "tile tables: %d rows per step, %d per item", TILE_G, rpi);
             n_items = nsteps * TILE_G / rpi;
-            std::vector<int32_t> hi8((size_t)n_items * 8, 0), kcb((size_t)n_items * 4, 0);
+            std::vector<int32_t> hi8((size_t)n_items * 8, 0);
             std::vector<float> cost((size_t)n_items, 0.f);
             std::vector<int32_t> icls((size_t)n_items, 0), woff((size_t)n_items, 0);
             ok = true;
-            if (pair_cost > 0.f) {
-                SSQ_REQUIRE(rpi == TILE_G, "paired steps: %d rows per item, %d per step", rpi, TILE_G);
-                int it = 0;
-                for (int i = 0; i < nsegs; ++i) {
-                    const int64_t L = (int64_t)M >> sg[i].lgR;
-                    if (sg[i].kind && (sg[i].wtab_off >= 16384 || sg[i].sig_stride % L)) ok = false;
-                    for (int t = 0; t < sg[i].nsteps; ) {
-                        const int two = (sg[i].kind && t + 1 < sg[i].nsteps) ? 1 : 0;
-                        const TileRow* r = rw + ((size_t)sg[i].first + t) * TILE_G;
-                        int npad = 0;                                         // padded rows of the item's LAST step
-                        for (int k = 0; k < TILE_G * (1 + two); ++k) {
-                            if (r[k].row < 0) ++npad;
-                            else if (npad) ok = false;                        // padding trails
-                            if (r[k].row >= 0 && ((r[k].row & 0xFFFF) != (r[0].row & 0xFFFF) + k
-                                                  || (sg[i].kind && r[k].ubase != r[0].ubase + k * L))) ok = false;
-                            if (k < TILE_G) hi8[8 * (size_t)it + 4 + k] = r[k].kc;
-                            else kcb[4 * (size_t)it + k - TILE_G] = r[k].kc;
-                        }
-                        if (npad >= TILE_G) ok = false;                       // (a step of padding only does not exist)
-                        const int32_t row0 = r[0].row & 0xFFFF;
-                        hi8[8 * (size_t)it] = row0 | (npad << 9) | (two << 11) | (sg[i].kind << 12) | (sg[i].lgR << 13)
-                                              | (sg[i].kind ? (int32_t)((uint32_t)sg[i].wtab_off << 18) : 0);
-                        hi8[8 * (size_t)it + 1] = sg[i].kind ? sg[i].cls_base + r[0].ubase : 0;
-                        hi8[8 * (size_t)it + 2] = (int32_t)(uint32_t)((int64_t)row0 * N * 8);
-                        hi8[8 * (size_t)it + 3] = sg[i].kind ? sg[i].sig_stride : 0;
-                        cost[it] = sg[i].kind ? (two ? pair_cost : 1.0f) : rb_cost;
-                        icls[it] = sg[i].kind ? 1 + sg[i].lgR : 0;
-                        woff[it] = sg[i].kind ? sg[i].wtab_off : 0;
-                        ++it;
-                        t += 1 + two;
-                    }
-                }
-                n_items = it;
-                hi8.resize((size_t)n_items * 8); kcb.resize((size_t)n_items * 4);
-                cost.resize(n_items); icls.resize(n_items); woff.resize(n_items);
-            } else
             for (int i = 0; i < nsegs; ++i) {
                 const int64_t L = (int64_t)M >> sg[i].lgR;
                 if (sg[i].kind && (sg[i].wtab_off >= (woff_in_record ? 16384 : 65536) || sg[i].sig_stride % L)) ok = false;
@@ -191,16 +152,14 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                     int ncl = 1;
                     for (int j = a + 1; j < b; ++j) if (icls[iin[j]] != icls[iin[j - 1]]) ++ncl;
                     if (ncl > max_cls) return 1e30;
-                    double c = 0.0;
-                    for (int j = a; j < b; ++j) c += cost[iin[j]];
-                    return c + (ncl > 1 && max_cls > 2 ? chg_cost * ncl : 0.0);
+                    return (double)(b - a) + (ncl > 1 && max_cls > 2 ? chg_cost * ncl : 0.0);
                 };
                 // (the wavefronts of a SIMD do not run at one speed: the arbiter serves the oldest first, and the stamps show the
                 // youngest taking a third longer per item. speed[w]: what wavefront w gets done relative to the mean, by its
                 // age rank w / 4 -- chunk k goes to wavefront k, and "largest" above means largest time = cost / speed.)
                 // (measured at config 2, one box: skew 0 / 0.1 / 0.2 / 0.3 -> 193-196 / 187 / 184-186 / 191 us with 16 wavefronts;
                 // no gain with 12)
-                float skew = nw >= 12 ? 0.2f : 0.f;
+                float skew = nw == 16 ? 0.2f : 0.f;
                 if (const char* e = getenv("SSQ_DEBUG_TILE3_SKEW")) skew = (float)atof(e);
                 std::vector<double> speed(nw, 1.0);
                 {
@@ -251,7 +210,7 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                     ssum[g] += load[w]; ++scnt[g];
                 }
                 if (skew != 0.f) for (int w = 0; w < nw; ++w) slot_of[w] = w;      // (the speeds were the slots')
-                std::vector<int32_t> hp((size_t)n_items * 8, 0), kp((size_t)n_items * 4, 0), wrec((size_t)nw * 4, 0);
+                std::vector<int32_t> hp((size_t)n_items * 8, 0), wrec((size_t)nw * 4, 0);
                 int pos = 0;
                 std::vector<int> list_of_slot(nw, 0);
                 for (int w = 0; w < nw; ++w) list_of_slot[slot_of[w]] = w;
@@ -262,7 +221,6 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                     for (size_t q = 0; q < L.size(); ++q) {
                         if (q > 0 && icls[L[q]] && icls[L[q - 1]] && icls[L[q]] != icls[L[q - 1]] && isp < 0) isp = pos;
                         memcpy(&hp[(size_t)pos * 8], &hi8[(size_t)L[q] * 8], 32);
-                        memcpy(&kp[(size_t)pos * 4], &kcb[(size_t)L[q] * 4], 16);
                         ++pos;
                     }
                     // (isp: the first item of the list's second class -- or of its rows read back, or its end)
@@ -278,7 +236,6 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                                 wrec[4 * sl], wrec[4 * sl + 1], wrec[4 * sl + 2], load[list_of_slot[sl]]);
                 }
                 if ((rcb = up(items_dev, hp.data(), hp.size() * 4))) return rcb;
-                if (kcb_dev && (rcb = up(kcb_dev, kp.data(), kp.size() * 4))) return rcb;
                 return up((void**)waves_dev, wrec.data(), wrec.size() * 4);
             }
             if ((rcb = up(items_dev, hi8.data(), hi8.size() * 4))) return rcb;
@@ -321,16 +278,15 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
             }
             return up((void**)waves_dev, wt_.data(), wt_.size() * 4);
         };
-        if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, -1.f, 2, 0.f, &items2, &wave_first2, nullptr, n_items2, tile2_ok))) return rc;
+        if ((rc = build(64 / cols2, TILE2_NW, false, 0.7f, -1.f, 2, &items2, &wave_first2, n_items2, tile2_ok))) return rc;
         tile3_ok = false;
         if (cols2 == 32 && TILE_G == 4) {
             // (measured with shader-clock stamps, round 6: an item of rows read back costs 0.45 of an interpolated one,
             // re-reading a class's weights 0.65)
-            float rb3 = 0.45f, chg3 = 0.65f, pair3 = 1.55f;
+            float rb3 = 0.45f, chg3 = 0.65f;
             if (const char* e = getenv("SSQ_DEBUG_TILE3_RB")) if (atof(e) > 0) rb3 = (float)atof(e);
             if (const char* e = getenv("SSQ_DEBUG_TILE3_CHG")) if (atof(e) >= 0) chg3 = (float)atof(e);
-            if (const char* e = getenv("SSQ_DEBUG_TILE3_PAIR")) if (atof(e) > 0) pair3 = (float)atof(e);
-            if ((rc = build(4, TILE3_NW, true, rb3, chg3, 1 << 20, pair3, &items3, &wave_first3, &kcb3, n_items3, tile3_ok))) return rc;
+            if ((rc = build(4, TILE3_NW, true, rb3, chg3, 1 << 20, &items3, &wave_first3, n_items3, tile3_ok))) return rc;
             // (the 16 lanes of a sub-row hold the sample window of the tile's 32 columns: (31 >> lgR) + 8 + 1 <= 16 needs
             // a decimation of 4 or more -- R_MIN of _tiles.py; SSQ_DEBUG_TILE_RMIN=2 plans go to tile2_kernel)
             for (int i = 0; i < nsegs; ++i) if (sg[i].kind && sg[i].lgR < 2) tile3_ok = false;
@@ -408,10 +364,9 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
         }
         if ((rc = up(&ftw, tw.data(), tw.size() * 4))) return rc;
     }
-    // (+ 8 rows of slack: the tile kernels' padded sub-rows -- and tile3_kernel's second row group of an item that has
-    // none -- read, and discard, the rows behind a class's last)
-    SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * (group * u_total + 8 * lmax))); bytes += 8 * (group * u_total + 8 * lmax);
-    SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * (group * u_total + 8 * lmax)));
+    // (+ 4 rows of slack: tile2_kernel's padded sub-rows read, and discard, the rows behind a class's last)
+    SSQ_CHECK_HIP(hipMalloc(&U, (size_t)8 * (group * u_total + 4 * lmax))); bytes += 8 * (group * u_total + 4 * lmax);
+    SSQ_CHECK_HIP(hipMemset(U, 0, (size_t)8 * (group * u_total + 4 * lmax)));
     SSQ_CHECK_HIP(hipMalloc((void**)&counters, 4096));       // [0]: tiles done
     SSQ_CHECK_HIP(hipMemset(counters, 0, 4096));
     for (size_t c = 0; c < cls.size(); ++c) {
@@ -437,8 +392,8 @@ void TilePlan::destroy() {
     ev_fork = ev_join = nullptr;
     for (auto& f : ffts) f.destroy();
     ffts.clear();
-    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw, items2, wave_first2, items3, wave_first3, kcb3};
-    items2 = nullptr; wave_first2 = nullptr; items3 = nullptr; wave_first3 = nullptr; kcb3 = nullptr;
+    void* ptrs[] = {steps, rows, irows, wtab, tbank, U, counters, Y, ftw, items2, wave_first2, items3, wave_first3};
+    items2 = nullptr; wave_first2 = nullptr; items3 = nullptr; wave_first3 = nullptr;
     for (void* p : ptrs) if (p) (void)hipFree(p);
     steps = nullptr; rows = nullptr; irows = nullptr; wtab = tbank = U = Y = ftw = nullptr;
     counters = nullptr;

@@ -49,7 +49,6 @@ struct Tile3Args {
     const int* items;        // [n_items][8]: row0 | npad << 9 | kind << 12 | lgR << 13 | weights' offset << 18, samples'
                              // offset of sub-row 0 (class + row), row0 * N * 8, entries between two signals' rows of
                              // the class (these four: scalar loads), kc of the four sub-rows (read per lane)
-    const int* kcb;          // [n_items][4]: kc of the four sub-rows of an item's second step
     const int4* waves;       // [NW]: first item, end, first item of the wavefront's second class (= end: none), 0
     const float4* wtab; const float2* U;
     const void* cst;
@@ -222,8 +221,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
 
     // data of a position: (interpolated) the lane's sample of its sub-row's window (.xy; .zw: the sample behind it,
     // unused), or (rows read back) Wx of the lane's two points and their bins (two 16-bit words)
-    // ... and for an interpolated item of two steps (8 rows) the same of its second step's sub-row: sample, centre bin
-    struct Data { ssq_f4u u; int kq; float2 ub; int kqb; };
+    struct Data { ssq_f4u u; int kq; };
     const char* const U8 = reinterpret_cast<const char*>(A.U);
     const char* const WX8 = reinterpret_cast<const char*>(A.Wx) + (size_t)((int64_t)A.sig0 * na * N) * 8u;
     const char* const KX8 = reinterpret_cast<const char*>(A.kidx);
@@ -235,7 +233,6 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
         const char* base; unsigned voff;
         // (interpolated rows: the lane's second load fetches the centre bin of its sub-row -- words 4 .. 7 of the item's record)
         const char* kbase = reinterpret_cast<const char*>(A.items) + (size_t)(unsigned)it * 32u + 16u; unsigned koff = lane_h4;
-        unsigned gb8 = 0;                                      // bytes from a sub-row's samples to those of the row 4 further
         if (kind) {                                            // (wave-uniform; the loads themselves stay outside)
             // sample (qb + cp) mod L of row h of the item, h * L entries on: the 16 lanes of a sub-row hold the
             // window every column of the tile takes its eight taps from ((31 >> lgR) + 8 <= 15 for R >= 4)
@@ -243,12 +240,11 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
             const int qb = (q.nabs0 >> lgR) - (TILE_W / 2 - 1);
             const int lmask = A.mmask >> lgR;                  // L - 1, L = M / R
             voff = (((unsigned)((qb + cp) & lmask)) + ((unsigned)h << (A.lgM - lgR))) * 8u;
-            gb8 = 32u << (A.lgM - lgR);
             base = U8 + ((size_t)(unsigned)R[1] + (size_t)((unsigned)q.sg * (unsigned)R[3])) * 8u;
         } else {
             // points (row0 + h, column pair) -- the last pair's for lanes past it, the last real row's for padded
             // sub-rows -- and their bins
-            const int npad = (w0 >> 9) & 3;
+            const int npad = (w0 >> 9) & 7;
             unsigned lr = lane_row16;
             if (npad) lr = (unsigned)min(h, RPI - 1 - npad) * nN * 8u + lane_col16;
             lr += 16u;                                         // (the bases below start 16 bytes early: lr stays >= 0)
@@ -266,10 +262,6 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
         d.u = *reinterpret_cast<const ssq_f4u*>(base + (size_t)voff);
         // (one load either way: the bins of rows read back, the centre bin of an interpolated sub-row)
         d.kq = (int)*reinterpret_cast<const ssq_u32u*>(kbase + (size_t)koff);
-        // the second step of an interpolated item (rows read back and single steps: a repeat of valid addresses,
-        // unused -- all loads unconditional)
-        d.ub = *reinterpret_cast<const float2*>(base + (size_t)(voff + gb8));
-        d.kqb = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(A.kcb) + (size_t)(unsigned)it * 16u + lane_h4);
         return d;
     };
     // the weights of a class for the lane's two column phases (every tile of this workgroup: the same n mod R)
@@ -318,9 +310,9 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
     // addresses per wavefront), asked for with the position's records. (Four scalar loads and a select by the lane's
     // sub-row were compiled into a detour through scratch memory -- two stores and a load per item: 312 us instead of
     // 250 for the reference's default call.)
-    w_t csv = (w_t)A.cst0, csvb = (w_t)A.cst0;
+    w_t csv = (w_t)A.cst0;
     auto load_cs = [&](int row0) {
-        if (CSTK != 0) { csv = cstv[min(row0 + h, omax)]; csvb = cstv[min(row0 + RPI + h, omax)]; }
+        if (CSTK != 0) csv = cstv[min(row0 + h, omax)];
     };
     load_cs(Rc[0] & 0x1FF);
     using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -333,45 +325,31 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
         step_loads();
         const Data dc = D[k0];
         const int w0 = Rc[0];
-        const int npad = (w0 >> 9) & 3, kind = (w0 >> 12) & 1;
-        const bool two = (w0 & 0x800) != 0;                    // an interpolated item of two steps: 8 rows
+        const int npad = (w0 >> 9) & 7, kind = (w0 >> 12) & 1;
         const int nabs = pc.nabs0 + cp * 2;                    // (lanes past the last column: results unused)
-        // (every lane's points count, except in a class's last item -- padded sub-rows --, in a tile with dead
+        // (every lane's two points count, except in a class's last item -- padded sub-rows --, in a tile with dead
         // columns and past the wavefront's last position: a wave-uniform test keeps the rest free)
         const bool alive = left > 0;                          // (past the wavefront's last position: see the loop below)
-        const bool rare = (w0 & 0x600) != 0 || tc_edge || !alive;
+        const bool rare = (w0 & 0xE00) != 0 || tc_edge || !alive;
         const int col = nabs - n1e - sh;                       // the pair's first column
+        bool live0 = true, live1 = true;
+        if (rare) {
+            const bool rowok = alive && h < RPI - npad;
+            live0 = rowok && (unsigned)col < nN;
+            live1 = rowok && (unsigned)(col + 1) < nN;
+        }
         // (byte offset of (signal, the item's first row, the tile's first column) in Wx, dWx; a quarter of it in the bins)
         const int64_t row8 = (int64_t)A.sig0 * na * N * 8 + pc.off8 + (unsigned)Rc[2];
-        // one row group (= one step: the lane's sub-row h of it, its column pair): the terms into the tile
-        auto add_terms = [&](int cell0, int cell1, float t0x, float t0y, float t1x, float t1y, w_t cs) {
-            const double a0 = (double)TM::make(t0x, cs), b0 = (double)TM::make(t0y, cs);
-            const double a1 = (double)TM::make(t1x, cs), b1 = (double)TM::make(t1y, cs);
-            SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
-            SSQ_LDS_ADD_F64_AT(cell0, 256, b0);
-            SSQ_LDS_ADD_F64_AT(cell1, 128, a1);
-            SSQ_LDS_ADD_F64_AT(cell1, 384, b1);
-        };
-        // (`last`: the group holds the item's padded sub-rows, if any)
-        auto lives = [&](bool last, bool& live0, bool& live1) {
-            live0 = live1 = true;
-            if (rare) {
-                const bool rowok = alive && (!last || h < RPI - npad);
-                live0 = rowok && (unsigned)col < nN;
-                live1 = rowok && (unsigned)(col + 1) < nN;
-            }
-        };
-        auto dump_bins = [&](unsigned kk, int64_t r8, bool live0, bool live1) {      // (STORE_K builds)
-            char* kd = reinterpret_cast<char*>(A.kdump) + (r8 >> 2) + (lane_row16 >> 2);
+        auto dump_bins = [&](unsigned kk) {                    // (STORE_K builds)
+            char* kd = reinterpret_cast<char*>(A.kdump) + (row8 >> 2) + (lane_row16 >> 2);
             if (!rare) *reinterpret_cast<ssq_u32u*>(kd) = kk;
             else {
                 if (live0) *reinterpret_cast<unsigned short*>(kd) = (unsigned short)kk;
                 if (live1) *reinterpret_cast<unsigned short*>(kd + 2) = (unsigned short)(kk >> 16);
             }
         };
+        int cell0, cell1; float t0x, t0y, t1x, t1y;
         if (kind == 0) {
-            bool live0, live1;
-            lives(true, live0, live1);
             ssq_f4u u = dc.u;
             unsigned kq = (unsigned)dc.kq;
             if (tc_edge) {                                     // (a pair with a dead column read its neighbour: see load_data)
@@ -379,82 +357,87 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
                 else if (col == (int)N - 1) { u.x = u.z; u.y = u.w; kq >>= 16; }
             }
             const int ka = (int)(kq & 0xFFFFu), kb = (int)(kq >> 16);
-            const int cell0 = (live0 && ka != TILE_NOBIN) ? ka * 512 + c8 : scratch8;
-            const int cell1 = (live1 && kb != TILE_NOBIN) ? kb * 512 + c8 : scratch8;
-            if constexpr (STORE_K) dump_bins(kq, row8, live0, live1);
-            add_terms(cell0, cell1, u.x, u.y, u.z, u.w, CSTK != 0 ? csv : (w_t)A.cst0);
+            cell0 = (live0 && ka != TILE_NOBIN) ? ka * 512 + c8 : scratch8;
+            cell1 = (live1 && kb != TILE_NOBIN) ? kb * 512 + c8 : scratch8;
+            t0x = u.x; t0y = u.y; t1x = u.z; t1y = u.w;
+            if constexpr (STORE_K) dump_bins(kq);
         } else {
             const int lgR = (w0 >> 13) & 31;
             const int qb3 = pc.nabs0 >> lgR;                   // window start + 3: tap 0 of sample q0 sits in lane q0 - qb3
             const int baddr = (((nabs >> lgR) - qb3) << 2) + hb4;
-            // a step of the item: the lane's sample of its sub-row's window, the sub-row's centre bin, the step's place
-            // in Wx, whether it is the item's last, the sub-row's reassignment weight
-            auto interp_group = [&](float ux, float uy, int kcs, int64_t r8, bool last, w_t cs) {
-                bool live0, live1;
-                lives(last, live0, live1);
-                ssq_f2 A0, D0, A1, D1;
-                {
-                    int fr[TILE_W], fi[TILE_W];
-                    int ur = __float_as_int(ux), ui = __float_as_int(uy);
-                    SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
-                    SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
-                    SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
-                    SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
-                    SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
-                    SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
-                    SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
-                    SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
-                    SSQ_LDS_WAIT();
-                    // (A = (a_re, a_im), D = (a'_re, a'_im) of the pair's two columns: what the modulation multiplies)
-                    ssq_f2 sv[TILE_W];
+            ssq_f2 A0, D0, A1, D1;
+            {
+                int fr[TILE_W], fi[TILE_W];
+                int ur = __float_as_int(dc.u.x), ui = __float_as_int(dc.u.y);
+                SSQ_BPERMUTE_OFF(fr[0], baddr, ur, 0);  SSQ_BPERMUTE_OFF(fi[0], baddr, ui, 0);
+                SSQ_BPERMUTE_OFF(fr[1], baddr, ur, 4);  SSQ_BPERMUTE_OFF(fi[1], baddr, ui, 4);
+                SSQ_BPERMUTE_OFF(fr[2], baddr, ur, 8);  SSQ_BPERMUTE_OFF(fi[2], baddr, ui, 8);
+                SSQ_BPERMUTE_OFF(fr[3], baddr, ur, 12); SSQ_BPERMUTE_OFF(fi[3], baddr, ui, 12);
+                SSQ_BPERMUTE_OFF(fr[4], baddr, ur, 16); SSQ_BPERMUTE_OFF(fi[4], baddr, ui, 16);
+                SSQ_BPERMUTE_OFF(fr[5], baddr, ur, 20); SSQ_BPERMUTE_OFF(fi[5], baddr, ui, 20);
+                SSQ_BPERMUTE_OFF(fr[6], baddr, ur, 24); SSQ_BPERMUTE_OFF(fi[6], baddr, ui, 24);
+                SSQ_BPERMUTE_OFF(fr[7], baddr, ur, 28); SSQ_BPERMUTE_OFF(fi[7], baddr, ui, 28);
+                SSQ_LDS_WAIT();
+                // (A = (a_re, a_im), D = (a'_re, a'_im) of the pair's two columns: what the modulation multiplies)
+                ssq_f2 sv[TILE_W];
 #pragma unroll
-                    for (int t = 0; t < TILE_W; ++t) { sv[t].x = __int_as_float(fr[t]); sv[t].y = __int_as_float(fi[t]); }
-                    SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
+                for (int t = 0; t < TILE_W; ++t) { sv[t].x = __int_as_float(fr[t]); sv[t].y = __int_as_float(fi[t]); }
+                SSQ_TAPS8X2(A0, D0, A1, D1, wa0, wb0, sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7]);
+            }
+            const int kcs = dc.kq;                             // centre bin of the lane's row
+            const float theta = (float)kcs * A.theta_scale;
+            // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
+            D0.x = __builtin_fmaf(-theta, A0.y, D0.x);
+            D0.y = __builtin_fmaf(theta, A0.x, D0.y);
+            D1.x = __builtin_fmaf(-theta, A1.y, D1.x);
+            D1.y = __builtin_fmaf(theta, A1.x, D1.y);
+            // phases kc n mod M of the two columns, exact in integers
+            const unsigned ph0 = __umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask;
+            const unsigned ph1 = (ph0 + (unsigned)kcs) & (unsigned)A.mmask;
+            const float rev0 = (float)ph0 * A.inv_m, rev1 = (float)ph1 * A.inv_m;
+            ssq_f2 tw0, tw1, W0, V0, W1, V1;
+            tw0.x = __builtin_amdgcn_cosf(rev0); tw0.y = __builtin_amdgcn_sinf(rev0);
+            tw1.x = __builtin_amdgcn_cosf(rev1); tw1.y = __builtin_amdgcn_sinf(rev1);
+            SSQ_CMUL_PK(W0, tw0, A0);
+            SSQ_CMUL_PK(W1, tw1, A1);
+            SSQ_CMUL_PK(V0, tw0, D0);
+            SSQ_CMUL_PK(V1, tw1, D1);
+            // (lanes past the last column hold other columns' weights, padded sub-rows another row's samples: their
+            // values go nowhere)
+            // (one 16-byte store per lane; a pair with a dead point: the live one alone)
+            auto store_pair = [&](char* dst, const ssq_f2 a, const ssq_f2 b) {
+                char* q = dst + row8 + (size_t)lane_row16;
+                if (!rare) { ssq_f4u v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; *reinterpret_cast<ssq_f4u*>(q) = v; }
+                else {
+                    if (live0) *reinterpret_cast<float2*>(q) = make_float2(a.x, a.y);
+                    if (live1) *reinterpret_cast<float2*>(q + 8) = make_float2(b.x, b.y);
                 }
-                const float theta = (float)kcs * A.theta_scale;
-                // d/dt of e^{i theta n} a(n):  e^{i theta n} (i theta a + a')
-                D0.x = __builtin_fmaf(-theta, A0.y, D0.x);
-                D0.y = __builtin_fmaf(theta, A0.x, D0.y);
-                D1.x = __builtin_fmaf(-theta, A1.y, D1.x);
-                D1.y = __builtin_fmaf(theta, A1.x, D1.y);
-                // phases kc n mod M of the two columns, exact in integers
-                const unsigned ph0 = __umul24((unsigned)kcs, (unsigned)nabs) & (unsigned)A.mmask;
-                const unsigned ph1 = (ph0 + (unsigned)kcs) & (unsigned)A.mmask;
-                const float rev0 = (float)ph0 * A.inv_m, rev1 = (float)ph1 * A.inv_m;
-                ssq_f2 tw0, tw1, W0, V0, W1, V1;
-                tw0.x = __builtin_amdgcn_cosf(rev0); tw0.y = __builtin_amdgcn_sinf(rev0);
-                tw1.x = __builtin_amdgcn_cosf(rev1); tw1.y = __builtin_amdgcn_sinf(rev1);
-                SSQ_CMUL_PK(W0, tw0, A0);
-                SSQ_CMUL_PK(W1, tw1, A1);
-                SSQ_CMUL_PK(V0, tw0, D0);
-                SSQ_CMUL_PK(V1, tw1, D1);
-                // (lanes past the last column hold other columns' weights, padded sub-rows another row's samples: their
-                // values go nowhere; one 16-byte store per lane; a pair with a dead point: the live one alone)
-                auto store_pair = [&](char* dst, const ssq_f2 a, const ssq_f2 b) {
-                    char* q = dst + r8 + (size_t)lane_row16;
-                    if (!rare) { ssq_f4u v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; *reinterpret_cast<ssq_f4u*>(q) = v; }
-                    else {
-                        if (live0) *reinterpret_cast<float2*>(q) = make_float2(a.x, a.y);
-                        if (live1) *reinterpret_cast<float2*>(q + 8) = make_float2(b.x, b.y);
-                    }
-                };
-                store_pair(reinterpret_cast<char*>(A.Wx), W0, W1);
-                if (STORE_D) store_pair(reinterpret_cast<char*>(A.dWx), V0, V1);
-                // phase transform and bin: as emit_point<LEAN> of the block kernels, per column
-                bool pend0, pend1;
-                int ko0 = pair_bin<GRID>(W0, V0, live0, m2hi, m2lo, sp, omax, fx, fa, pend0);
-                int ko1 = pair_bin<GRID>(W1, V1, live1, m2hi, m2lo, sp, omax, fx, fa, pend1);
-                if (pend0) ko0 = exact_bin(make_float2(W0.x, W0.y), make_float2(V0.x, V0.y), sp, omax, A.gamma);
-                if (pend1) ko1 = exact_bin(make_float2(W1.x, W1.y), make_float2(V1.x, V1.y), sp, omax, A.gamma);
-                const int cell0 = ko0 >= 0 ? ko0 * 512 + c8 : scratch8;
-                const int cell1 = ko1 >= 0 ? ko1 * 512 + c8 : scratch8;
-                if constexpr (STORE_K)
-                    dump_bins((unsigned)(ko0 >= 0 ? ko0 : TILE_NOBIN) | ((unsigned)(ko1 >= 0 ? ko1 : TILE_NOBIN) << 16), r8, live0, live1);
-                add_terms(cell0, cell1, W0.x, W0.y, W1.x, W1.y, cs);
             };
-            interp_group(dc.u.x, dc.u.y, dc.kq, row8, !two, CSTK != 0 ? csv : (w_t)A.cst0);
-            // (wave-uniform; the step's loads went out with the first's, whether it exists or not)
-            if (two) interp_group(dc.ub.x, dc.ub.y, dc.kqb, row8 + (int64_t)RPI * N * 8, true, CSTK != 0 ? csvb : (w_t)A.cst0);
+            store_pair(reinterpret_cast<char*>(A.Wx), W0, W1);
+            if (STORE_D) store_pair(reinterpret_cast<char*>(A.dWx), V0, V1);
+            // phase transform and bin: as emit_point<LEAN> of the block kernels, per column
+            bool pend0, pend1;
+            int ko0 = pair_bin<GRID>(W0, V0, live0, m2hi, m2lo, sp, omax, fx, fa, pend0);
+            int ko1 = pair_bin<GRID>(W1, V1, live1, m2hi, m2lo, sp, omax, fx, fa, pend1);
+            if (pend0) ko0 = exact_bin(make_float2(W0.x, W0.y), make_float2(V0.x, V0.y), sp, omax, A.gamma);
+            if (pend1) ko1 = exact_bin(make_float2(W1.x, W1.y), make_float2(V1.x, V1.y), sp, omax, A.gamma);
+            cell0 = ko0 >= 0 ? ko0 * 512 + c8 : scratch8;
+            cell1 = ko1 >= 0 ? ko1 * 512 + c8 : scratch8;
+            t0x = W0.x; t0y = W0.y; t1x = W1.x; t1y = W1.y;
+            if constexpr (STORE_K)
+                dump_bins((unsigned)(ko0 >= 0 ? ko0 : TILE_NOBIN) | ((unsigned)(ko1 >= 0 ? ko1 : TILE_NOBIN) << 16));
+        }
+        {
+            w_t cs = (w_t)A.cst0;
+            if (CSTK != 0) {
+                cs = csv;
+            }
+            const double a0 = (double)TM::make(t0x, cs), b0 = (double)TM::make(t0y, cs);
+            const double a1 = (double)TM::make(t1x, cs), b1 = (double)TM::make(t1y, cs);
+            SSQ_LDS_ADD_F64_AT(cell0, 0, a0);
+            SSQ_LDS_ADD_F64_AT(cell0, 256, b0);
+            SSQ_LDS_ADD_F64_AT(cell1, 128, a1);
+            SSQ_LDS_ADD_F64_AT(cell1, 384, b1);
         }
         --left;
         const bool tile_end = alive && ++it_c >= i1;           // (the block's last item: the tile is complete)
@@ -532,7 +515,6 @@ int TilePlan::run_pair(int sig, int nsig, float* Wx, float* dWx, float* Tx, cons
     B.kdump = kdump;
     B.items = reinterpret_cast<const int*>(items3);
     B.waves = reinterpret_cast<const int4*>(wave_first3);
-    B.kcb = reinterpret_cast<const int*>(kcb3);
     B.wtab = (const float4*)wtab; B.U = (const float2*)U; B.cst = cst;
     B.Wx = (float2*)Wx; B.dWx = (float2*)dWx; B.Tx = (float2*)Tx; B.kidx = kidx;
     B.N = N; B.na = na; B.n_items = n_items3; B.n1 = (int)n1; B.mmask = (int)(M - 1);

@@ -54,7 +54,7 @@ constexpr int TILE_COLS = 64;           // ordered kernel: columns per tile (one
 #endif
 constexpr int TILE_G = SSQ_TILE_G;      // rows per step of the host's tables (_tiles.py: RSUB)
 constexpr int TILE2_NW = 16;            // tile2_kernel: wavefronts per workgroup (one workgroup per CU)
-constexpr int TILE3_NW = 12;            // tile3_kernel: 12 (168 registers: an item's two row groups' data in flight)
+constexpr int TILE3_NW = 16;            // tile3_kernel: the same
 // LDS of a workgroup: the ordered kernel's (na + 1) x 64 float32 pairs + ticket words; the default kernel's
 // (na + 1) x cols float64 pairs
 __host__ __device__ inline size_t tile_lds_bytes(int64_t na) { return (size_t)(na + 1) * TILE_COLS * 8 + 16; }
@@ -84,7 +84,6 @@ struct TilePlan {
     // tile3_kernel (two columns per lane, ssq_tile_pair.hip): items of FOUR rows x 32 columns, permuted so that every
     // wavefront's list is contiguous, and the lists' bounds ([TILE3_NW][4])
     void* items3 = nullptr; int32_t* wave_first3 = nullptr;
-    void* kcb3 = nullptr;                   // [n_items3][4]: centre bins of the rows of an item's second step
     int n_items3 = 0;
     bool tile3_ok = false;
     bool pair_ok() const;                   // tile3_kernel takes this plan (32-column tile, SSQ_DEBUG_TILE_PAIR != 0)
