@@ -41,6 +41,10 @@ namespace ssq {
 #include "ssq_tile_dev.h"
 
 constexpr int T3_COLS = 32, T3_RPI = 4, T3_LGC = 5;
+// Wx and Tx are written once and never read here: nontemporal stores (measured, one box: tile stage 179.2-179.5 us with
+// plain stores, Wx alone 180.9, Tx alone 175.7, both 172.0-176.1 -- profiles/r6_ab_history.txt r6n; the L2 keeps the
+// sample windows and the rows read back instead)
+template <typename V> __device__ __forceinline__ void t3_store(V* p, const V v) { __builtin_nontemporal_store(v, p); }
 typedef float ssq_f4u __attribute__((ext_vector_type(4), aligned(8)));     // 16 bytes at an 8-byte boundary (samples; Wx, Tx
                                                                             // pairs at an odd column)
 typedef unsigned ssq_u32u __attribute__((aligned(2)));                      // two 16-bit bins at a 2-byte boundary
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
                 SSQ_OPAQUE_S(fr); SSQ_OPAQUE_S(step);          // (re-read as scalars at every use: see tile2_kernel)
                 if (m < fr) {                                  // (wave-uniform)
                     const float4 v = take(k0 + m * RR);
-                    *reinterpret_cast<ssq_f4u*>(tb + (size_t)voff) = as_f4u(v);
+                    t3_store(reinterpret_cast<ssq_f4u*>(tb + (size_t)voff), as_f4u(v));
                     tb += step;
                     asm volatile("" ::: "memory");             // (keeps the rounds from being batched into registers)
                 }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
             {   // the last round: the rows left, and the scratch row cleared by the lanes past them
                 const int k = k0 + fr * RR;
                 const float4 v = take(k < na ? k : na);
-                if (k < na) *reinterpret_cast<ssq_f4u*>(tb + (size_t)voff) = as_f4u(v);
+                if (k < na) t3_store(reinterpret_cast<ssq_f4u*>(tb + (size_t)voff), as_f4u(v));
             }
         } else {
             // a signal's first tile when n1 is odd, its last when it is partial: column by column
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
             // (one 16-byte store per lane; a pair with a dead point: the live one alone)
             auto store_pair = [&](char* dst, const ssq_f2 a, const ssq_f2 b) {
                 char* q = dst + row8 + (size_t)lane_row16;
-                if (!rare) { ssq_f4u v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; *reinterpret_cast<ssq_f4u*>(q) = v; }
+                if (!rare) { ssq_f4u v; v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y; t3_store(reinterpret_cast<ssq_f4u*>(q), v); }
                 else {
                     if (live0) *reinterpret_cast<float2*>(q) = make_float2(a.x, a.y);
                     if (live1) *reinterpret_cast<float2*>(q + 8) = make_float2(b.x, b.y);
