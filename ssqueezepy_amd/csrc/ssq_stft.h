@@ -17,7 +17,32 @@ struct StftFusedArgs {
     // REASSIGN instantiation: Tx of the workgroup's frames is summed in LDS (float64, unordered adds -- see
     // accumulate_f64_kernel) and written here; neither the bin map nor a second pass over Sx is needed
     float2* Tx; const void* cst; int cst_uniform;
+    // the frames read the signal itself through the padding rule (round 6: no padded copy -- config 3's pad_kernel was
+    // 7 % of the call): x (batch, n), the left padding, the rule (SSQ_PAD_*); null: xp holds the padded batch
+    const float* x; int n, n1, padtype;
 };
+
+// padded sample t - n1 of a signal of n samples: the source index in [0, n), or -1 for a zero (the rule of pad_kernel,
+// ssq_kernels.hip, in 32-bit arithmetic)
+__device__ __forceinline__ int stft_pad_source(int t, int n, int padtype) {
+    if ((unsigned)t < (unsigned)n) return t;
+    switch (padtype) {
+        case SSQ_PAD_REFLECT: {
+            if (n == 1) return 0;
+            const int period = 2 * (n - 1);
+            int m = t % period; if (m < 0) m += period;
+            return m < n ? m : period - m;
+        }
+        case SSQ_PAD_SYMMETRIC: {
+            const int period = 2 * n;
+            int m = t % period; if (m < 0) m += period;
+            return m < n ? m : period - 1 - m;
+        }
+        case SSQ_PAD_REPLICATE: return t < 0 ? 0 : n - 1;
+        case SSQ_PAD_WRAP: { int m = t % n; if (m < 0) m += n; return m; }
+        default: return -1;
+    }
+}
 
 // ---- mixed-radix fused kernel (any n_fft with prime factors <= 31, float32)
 constexpr int GEN_NT = 256;

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
     const int tid = threadIdx.x, c0 = bx * G;
     if (c0 >= A.n_hops) return;
     const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
+    // (no padded copy: frames inside the signal read it directly -- all but the workgroups at its two ends)
+    const bool inside = A.x != nullptr && A.hop * c0 - A.n1 >= 0 && A.hop * (c0 + G - 1) + L - 1 - A.n1 < A.n;
+    const float* xs = A.x + (int64_t)blockIdx.y * A.n - A.n1;
     const bool deriv = A.dSx != nullptr || A.kidx != nullptr || REASSIGN;
     c32 z[PPT];
     {
@@ -87,7 +90,12 @@ __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqPara
                 const int s = !A.modulated ? r : (r < A.s20 ? A.s21 + r : r - A.s20);
                 float a = 0.f, b = 0.f;
                 if (c < A.n_hops) {
-                    const float v = xp[(int64_t)A.hop * c + s];
+                    float v;
+                    if (inside) v = xs[A.hop * c + s];         // (workgroup-uniform: every sample of its frames exists)
+                    else if (A.x) {                            // the signal's ends: padded on the fly
+                        const int src = stft_pad_source(A.hop * c + s - A.n1, A.n, A.padtype);
+                        v = src < 0 ? 0.f : A.x[(int64_t)blockIdx.y * A.n + src];
+                    } else v = xp[(int64_t)A.hop * c + s];
                     a = v * A.window[r];
                     if (deriv) b = v * A.diff_window[r];
                 }
@@ -360,7 +368,10 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     const int64_t rows = pl->rows, n_hops = pl->n_hops, n_fft = d.n_fft;
     const bool deriv = dSx || Tx || w;
     SSQ_REQUIRE(!deriv || pl->diff_window, "derivative outputs need a diff_window");
-    int rc = ssq_pad_signal(d.dtype, x, pl->xp, batch, d.n, pl->n1, pl->n2, d.padtype, stream);
+    // (the power-of-two fused kernel pads on the fly; the other routes read a padded copy)
+    const bool pad_in_kernel = sizeof(T) == 4 && pl->fused && d.n + pl->n1 + pl->n2 < ((int64_t)1 << 30);
+    int rc = 0;
+    if (!pad_in_kernel) rc = ssq_pad_signal(d.dtype, x, pl->xp, batch, d.n, pl->n1, pl->n2, d.padtype, stream);
     if (rc) return rc;
     const int64_t s20 = (n_fft + 1) / 2, s21 = (n_fft % 2 == 1) ? s20 - 1 : s20;
     // (decided below: whether the derivative is stored at all; its workspace exists from the first call that needs one)
@@ -403,6 +414,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.Tx = fused_tx ? (float2*)Tx : nullptr; A.cst = pl->cst; A.cst_uniform = pl->sp.cst_uniform;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated;
+            A.x = pad_in_kernel ? (const float*)x : nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype;
             switch (n_fft) {
                 case 128: rc = launch_stft_fused<128, 32, 16, 8, 1>(A, pl->sp, batch, stream); break;
                 case 256: rc = launch_stft_fused<256, 16, 16, 16, 1>(A, pl->sp, batch, stream); break;
@@ -423,6 +435,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.Tx = nullptr; A.cst = nullptr; A.cst_uniform = 0;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated; A.xcd = 0;
+            A.x = nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype;
             rc = launch_stft_generic(A, pl->sp, (const c32*)pl->ftw, (int)n_fft, pl->gen_radix, pl->gen_npass, pl->gen_G,
                                      batch, stream);
             if (rc) return rc;
