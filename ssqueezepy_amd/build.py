@@ -69,11 +69,20 @@ def _stamp(objdir, verbose):
         return obj, False
     with open(src, 'w') as fh:
         fh.write(text)
-    cmd = ['gcc', '-fPIC', '-c', src, '-o', obj]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return obj, True
+    # (any C compiler will do; without one the weak "unknown" stamp of ssq_kernels.hip stands)
+    for cc in (os.environ.get('CC'), 'cc', 'gcc', os.path.join(ROCM, 'lib', 'llvm', 'bin', 'clang')):
+        if not cc:
+            continue
+        cmd = [cc, '-fPIC', '-c', src, '-o', obj]
+        try:
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return obj, True
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    os.remove(src)
+    return None, False
 
 
 def _newer(src, dst):

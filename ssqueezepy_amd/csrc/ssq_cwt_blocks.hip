@@ -890,10 +890,11 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
         for (int c = a; c < b && !on; ++c) on = need[c] != 0;
         const int kind = (int)hcls[a].analytic;
         any_analytic = any_analytic || (on && kind);
-        if (on && own4096 && hcls[a].P == 4096) {
+        int wanted = 0;                            // (classes of this group the kernel's 8 slots would have to take)
+        for (int c = a; c < b; ++c) wanted += (need && !need[c]) ? 0 : 1;
+        if (on && own4096 && hcls[a].P == 4096 && S.ncls + wanted <= 8) {     // (a ninth: gather + rocFFT, as for other P)
             for (int c = a; c < b; ++c) {
                 if (need && !need[c]) continue;
-                SSQ_REQUIRE(S.ncls < 8, "more than 8 block classes of 4096 points");
                 S.cls[S.ncls] = c;
                 const int64_t wgs = kind ? hcls[c].nb : (hcls[c].nb + 1) / 2;
                 S.first[S.ncls + 1] = S.first[S.ncls] + (int)wgs;

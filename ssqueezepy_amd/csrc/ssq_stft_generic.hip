@@ -3,6 +3,7 @@
 // utils/stft_utils.py:69-98 (buffer), algos.py:956-984 (the bin rule of the fused ssq_stft form).
 // Compiled with -ffp-contract=off (bin indices; see ssq_kernels.hip).
 #include "ssq_stft.h"
+#include <algorithm>
 #include "ssq_dft_tables.h"
 #include <cmath>
 
@@ -219,8 +220,18 @@ int launch_stft_generic(const StftFusedArgs& A, const SsqParams& sp, const c32* 
     const size_t lds = (size_t)2 * n * G * sizeof(c32);
     SSQ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stft_generic_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, GEN_LDS_BYTES));
-    hipLaunchKernelGGL(stft_generic_kernel, dim3(nb, (unsigned)batch), dim3(GEN_NT), lds, stream, B, sp);
-    SSQ_LAUNCH_CHECK();
+    // (the batch rides on grid.y: slices of at most 65535 signals)
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {
+        const int64_t nb_sig = std::min<int64_t>(65535, batch - b0);
+        StftGenArgs C = B;
+        const int64_t pts = b0 * A.rows * A.n_hops;
+        C.F.xp = A.xp + b0 * A.padlen;
+        C.F.Sx = A.Sx + pts;
+        C.F.dSx = A.dSx ? A.dSx + pts : nullptr;
+        C.F.kidx = A.kidx ? A.kidx + pts : nullptr;
+        hipLaunchKernelGGL(stft_generic_kernel, dim3(nb, (unsigned)nb_sig), dim3(GEN_NT), lds, stream, C, sp);
+        SSQ_LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -41,13 +41,14 @@ namespace ssq {
 #include "ssq_tile_dev.h"
 
 constexpr int T3_COLS = 32, T3_RPI = 4, T3_LGC = 5;
-// Wx and Tx are written once and never read here: nontemporal stores (measured, one box: tile stage 179.2-179.5 us with
-// plain stores, Wx alone 180.9, Tx alone 175.7, both 172.0-176.1 -- profiles/r6_ab_history.txt r6n; the L2 keeps the
-// sample windows and the rows read back instead)
-template <typename V> __device__ __forceinline__ void t3_store(V* p, const V v) { __builtin_nontemporal_store(v, p); }
 typedef float ssq_f4u __attribute__((ext_vector_type(4), aligned(8)));     // 16 bytes at an 8-byte boundary (samples; Wx, Tx
                                                                             // pairs at an odd column)
 typedef unsigned ssq_u32u __attribute__((aligned(2)));                      // two 16-bit bins at a 2-byte boundary
+// Wx and Tx are written once and never read here: nontemporal stores (measured, one box: tile stage 179.2-179.5 us with
+// plain stores, Wx alone 180.9, Tx alone 175.7, both 172.0-176.1 -- profiles/r6_ab_history.txt r6n; the L2 keeps the
+// sample windows and the rows read back instead)
+// (not a template: deduction would drop the pointer type's 8-byte alignment and let the compiler assume 16)
+__device__ __forceinline__ void t3_store(ssq_f4u* p, const ssq_f4u v) { __builtin_nontemporal_store(v, p); }
 
 struct Tile3Args {
     const int* items;        // [n_items][8]: row0 | npad << 9 | kind << 12 | lgR << 13 | weights' offset << 18, samples'

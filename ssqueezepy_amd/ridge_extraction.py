@@ -64,11 +64,16 @@ def extract_ridges(Tf, scales, penalty=2., n_ridges=1, bw=15, transform='cwt',
     # costs about what one transform does
     batched = Tf.ndim == 3
     if batched and Tf.shape[0] > MAX_BATCH_PER_LAUNCH:
+        # (the chunks are device tensors whatever the caller passed: their results are joined as tensors and converted
+        # once, like the results of a single launch below)
         parts = [extract_ridges(Tf[b0:b0 + MAX_BATCH_PER_LAUNCH], scales, penalty, n_ridges, bw, transform,
                                 get_params, parallel)
                  for b0 in range(0, Tf.shape[0], MAX_BATCH_PER_LAUNCH)]
-        join = (lambda xs: torch.cat(list(xs))) if as_tensor else (lambda xs: np.concatenate(list(xs)))
-        return tuple(join(p[k] for p in parts) for k in range(3)) if get_params else join(parts)
+        if get_params:
+            out = tuple(torch.cat([p[k] for p in parts]) for k in range(3))
+            return out if as_tensor else (out[0].cpu().numpy().astype(int), out[1].cpu().numpy(), out[2].cpu().numpy())
+        out = torch.cat(parts)
+        return out if as_tensor else out.cpu().numpy().astype(int)
     if not batched:
         Tf = Tf[None]
     Tf = Tf.contiguous()

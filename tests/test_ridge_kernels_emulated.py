@@ -103,3 +103,31 @@ def test_emulated_batch_entry_points(emu, cdtype, na, n):
         assert emu.ssq_ridge_clear(code, _p(e1), _p(r1), dbl(4), _p(re1), i64(na), i64(n), None) == 0
         assert np.array_equal(Eb[b], E1) and np.array_equal(peb[b], pe1) and np.array_equal(rb[b], r1)
         assert np.array_equal(enb[b], e1) and np.array_equal(reb[b], re1)
+
+
+@pytest.mark.parametrize('as_numpy', [True, False])
+def test_batches_beyond_one_launch_are_walked_in_chunks(as_numpy, monkeypatch):
+    """`extract_ridges` on more transforms than one launch takes (MAX_BATCH_PER_LAUNCH, patched to 2 here) walks the
+    batch in chunks: the same results as transform by transform, NumPy in -> NumPy out (the chunks are device tensors
+    inside: joining them with np.concatenate raised for NumPy input -- round-5 advisor finding), tensor in -> tensor out,
+    with and without `get_params`."""
+    import emu_backend
+    rng = np.random.default_rng(5)
+    B, na, n = 5, 24, 40
+    mag = rng.random((B, na, n)) + 3 * np.exp(-0.5 * ((np.arange(na)[None, :, None] - 8 - np.arange(B)[:, None, None]) / 2)**2)
+    Tf = (mag * np.exp(2j * np.pi * rng.random((B, na, n)))).astype('complex64')
+    scales = np.exp(np.linspace(0.1, 3.0, na)).astype('float32')
+    with emu_backend.emulated() as S:
+        import torch
+        from ssqueezepy_amd import ridge_extraction as R
+        monkeypatch.setattr(R, 'MAX_BATCH_PER_LAUNCH', 2)
+        arg = Tf if as_numpy else torch.as_tensor(Tf)
+        idx = R.extract_ridges(arg, scales, penalty=2., n_ridges=2, bw=3)
+        idx_p, f_p, e_p = R.extract_ridges(arg, scales, penalty=2., n_ridges=2, bw=3, get_params=True)
+        kind = np.ndarray if as_numpy else torch.Tensor
+        assert isinstance(idx, kind) and isinstance(idx_p, kind) and isinstance(f_p, kind) and isinstance(e_p, kind)
+        to_np = (lambda a: a) if as_numpy else (lambda a: a.cpu().numpy())
+        assert to_np(idx).shape == (B, n, 2) and np.array_equal(to_np(idx), to_np(idx_p))
+        for b in range(B):
+            i1, f1, e1 = R.extract_ridges(Tf[b], scales, penalty=2., n_ridges=2, bw=3, get_params=True)
+            assert np.array_equal(to_np(idx)[b], i1) and np.array_equal(to_np(f_p)[b], f1) and np.array_equal(to_np(e_p)[b], e1)
