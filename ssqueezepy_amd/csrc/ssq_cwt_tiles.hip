@@ -165,6 +165,11 @@ int TilePlan::create(const ssq_cwt_tiles_desc& d, int64_t M_, int64_t N_, int64_
                 {
                     const int nr = nw / 4;
                     for (int w = 0; w < nw; ++w) speed[w] = 1.0 + skew * (nr > 1 ? 1.0 - 2.0 * (w / 4) / (double)(nr - 1) : 0.0);
+                    if (const char* e = getenv("SSQ_DEBUG_TILE3_SPEEDS")) {     // (A/B: a speed per age rank, "1.2,1.07,0.93,0.8")
+                        double v[8]; int n = 0;
+                        for (const char* q = e; *q && n < 8; ) { v[n++] = atof(q); while (*q && *q != ',' && *q != '/') ++q; if (*q) ++q; }
+                        if (n == nr) for (int w = 0; w < nw; ++w) speed[w] = v[w / 4];
+                    }
                 }
                 std::vector<std::vector<double>> f(nw + 1, std::vector<double>(ni + 1, 1e30));
                 std::vector<std::vector<int>> arg(nw + 1, std::vector<int>(ni + 1, 0));

@@ -120,8 +120,8 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
     const int ntl = A.carry ? (int)(((int64_t)A.nsig * ntx - bid + G - 1) / G) : per_sig * A.nsig;
     const auto* waves = SSQ_CONST_PTR(int4, A.waves);
     const int i0 = waves[wv].x, i1 = waves[wv].y, isp = waves[wv].z, ni = i1 - i0;
-    int prio = (wv >> 2) & 1;
-    auto rotate_priority = [&]() { SSQ_PRIO_TOGGLE(prio); };   // (two levels, swapped with every item: see tile2_kernel)
+    // (no issue priorities: tile2_kernel's two levels swapped with every item measured the same here as none -- 173.0
+    // against 172.8 us -- and a static priority by age rank, youngest highest, worse: 186; profiles/r6_ab_history.txt r6t)
     const float g2 = (float)(A.gamma * A.gamma);
     const float m2hi = g2 * 1.000004f, m2lo = g2 * 0.999996f;
     const int fx = sp.flipud ? -1 : 0, fa = sp.flipud ? na : 0;
@@ -325,7 +325,6 @@ __global__ __launch_bounds__(64 * TILE3_NW) void tile3_kernel(Tile3Args A, SsqPa
     auto body = [&](auto KK) {
         constexpr int k0 = decltype(KK)::value, k2 = (k0 + 2) % 3;
         const Pos pc = tc;
-        rotate_priority();
         D[k2] = load_data(Rn, it_l, tl);                       // the data of p + 2
         step_loads();
         const Data dc = D[k0];
