@@ -21,6 +21,8 @@
 #endif
 #ifndef SSQ_OPAQUE_S
 #define SSQ_OPAQUE_S(x) asm volatile("" : "+s"(x))
+// nothing moves across this point in the instruction scheduler (bounds how far ahead an unrolled loop's loads are hoisted)
+#define SSQ_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 #ifndef SSQ_LDS_ADD_F64

@@ -185,6 +185,41 @@ __device__ __forceinline__ int bin_screen_cwt(float w, const SsqParams& sp, int 
     return min(max(k, 0), omax);
 }
 
+// `bin_screen_f32` with its early-outs as selects (the grid kind is a scalar branch): the same estimate and the same
+// guard, `ok` = the screen decided, the return value the pre-flip bin when it did. For the unrolled epilogue of the fused
+// STFT kernel, where every early-out of a point is a divergent branch of the wavefront.
+__device__ __forceinline__ int bin_screen_sel(float w, float werr, float lerr, const SsqParams& sp, int omax, bool& ok) {
+    float t, g = sp.guard;
+    bool valid = true, seg1 = false;
+    int kofs = 0;
+    if (sp.grid == SSQ_GRID_LIN) {
+        t = (w - sp.pf[0]) * sp.pf[1];
+        g = g + (werr + (fabsf(w) + fabsf(sp.pf[0])) * 2e-7f) * sp.pf[1];
+    } else {
+        const float wl = __log2f(w);
+        if (sp.grid == SSQ_GRID_LOG) {
+            t = (wl - sp.pf[0]) * sp.pf[1];
+            g = g + lerr * sp.pf[1];
+        } else {
+            const float dv = wl - sp.pf[1];
+            valid = !(fabsf(dv) < 2e-5f + lerr);       // on the segment boundary
+            seg1 = dv > 0.f;
+            t = seg1 ? dv * sp.pf[3] : (wl - sp.pf[0]) * sp.pf[2];
+            g = g + lerr * (seg1 ? sp.pf[3] : sp.pf[2]);
+            kofs = seg1 ? (int)sp.pf[4] : 0;
+        }
+    }
+    // (w = inf or NaN, a log of 0, |t| beyond 1e6: g is infinite, NaN or past 1/4 -- one comparison)
+    g = g + fabsf(t) * 4e-7f;
+    valid &= g < 0.25f;
+    const float rt = rintf(t);
+    const bool zero = !seg1 & (t < g);     // exact map: 0 for t <= 0 and for 0 < t < 1/2
+    const bool near = (0.5f - fabsf(t - rt)) < g;
+    ok = valid & (zero | !near);
+    const int k = (int)rt + kofs;
+    return min(max(k, 0), omax);
+}
+
 // the two halves of the float32 `bin_of_point` below, for kernels that keep the
 // exact path out of their unrolled loops: `_screen` returns -2 when undecided
 __device__ __forceinline__ int bin_of_point_screen(float a, float b, float c, float d,
@@ -218,6 +253,23 @@ __device__ __forceinline__ int64_t bin_of_point(float a, float b, float c, float
     double r = (double)num / ((double)m2 * SSQ_TWO_PI);
     double w = stft ? fabs((double)sfs - r) : fabs(r);
     return bin_from_w(w, sp, omax);
+}
+// the STFT form of the float32 `bin_of_point` over `bin_screen_sel`: one rare branch (the exact map) per point, taken
+// only where the bin is `wanted` (a point below gamma has none: its zero magnitude must not buy a float64 division)
+__device__ __forceinline__ int bin_of_point_stft(float a, float b, float c, float d, float sfs,
+                                                 const SsqParams& sp, int omax, bool wanted) {
+    const float num = b * c - a * d;
+    const float m2 = c * c + d * d;
+    const float r32 = num * __builtin_amdgcn_rcpf(m2 * 6.2831855f);
+    const float w32 = fabsf(sfs - r32), werr = (fabsf(sfs) + fabsf(r32)) * 5e-7f;
+    const float lerr = 1.4428f * werr * __builtin_amdgcn_rcpf(w32);
+    bool ok;
+    int k = bin_screen_sel(w32, werr, lerr, sp, omax, ok);
+    if (!ok && wanted) {
+        const double r = (double)num / ((double)m2 * SSQ_TWO_PI);
+        k = (int)bin_from_w(fabs((double)sfs - r), sp, omax);
+    }
+    return k;
 }
 __device__ __forceinline__ int64_t bin_of_point(double a, double b, double c, double d, bool stft,
                                                 double sfs, const SsqParams& sp, int64_t omax) {

@@ -20,6 +20,8 @@ struct StftFusedArgs {
     // the frames read the signal itself through the padding rule (round 6: no padded copy -- config 3's pad_kernel was
     // 7 % of the call): x (batch, n), the left padding, the rule (SSQ_PAD_*); null: xp holds the padded batch
     const float* x; int n, n1, padtype;
+    const float2* wd;                   // (window, diff_window) interleaved, or null (stft_fused_kernel's staged loads)
+    int batch;                          // signals of the call (stft_fused_kernel's items: batch x groups of frames)
 };
 
 // padded sample t - n1 of a signal of n samples: the source index in [0, n), or -1 for a zero (the rule of pad_kernel,

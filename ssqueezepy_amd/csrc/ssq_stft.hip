@@ -26,6 +26,15 @@ namespace ssq {
 
 #include "ssq_point_math.inl"
 
+#ifdef STFT_STAMPS
+__device__ unsigned long long g_stft_prof[16];
+#define ST_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&g_stft_prof[i], t_ - tprev); tprev = t_; } while (0)
+#else
+#define ST_STAMP(i) do {} while (0)
+#endif
+typedef float ssq_f4 __attribute__((ext_vector_type(4)));
+typedef float ssq_f4a4 __attribute__((ext_vector_type(4), aligned(4)));     // 16 bytes at a sample's 4-byte boundary
+
 template <typename T>
 __global__ __launch_bounds__(256) void frame_window_kernel(
     const T* __restrict__ xp, const T* __restrict__ window, const T* __restrict__ diff_window,
@@ -46,128 +55,246 @@ __global__ __launch_bounds__(256) void frame_window_kernel(
 }
 
 // ---- fused framing + window + FFT (float32, n_fft = L a power of two) -----------------
-// One workgroup = G = 4096/L consecutive frames of one signal. The forward transform is
+// One item = G = 4096/L consecutive frames of one signal. The forward transform is
 // taken as conj(IFFT(conj(.))) with the inverse LDS FFT of ssq_ldsfft.h: input
 // a - ib, output Z' with FFT(a + ib) = conj(Z'). With A = FFT(a), B = FFT(b) Hermitian,
 //   A[f] = (Z[f] + conj(Z[L-f])) / 2,   B[f] = (Z[f] - conj(Z[L-f])) / (2i),  f <= L/2.
+// Round 6 (profiles/r6_ab_history.txt "r6w".."r6y"): the Tx planes take the FFT buffer's place (four workgroups per CU);
+// the item's samples come through LDS in one coalesced pass; the tables an item needs (window pairs, row frequencies,
+// weights) are asked for a phase ahead of their use. Persistent workgroups that fetch the next item's samples while they
+// transform the current one were built and measured slower (the loop costs 40 registers: three workgroups per CU).
 
 template <int L, int G, int R1, int R2, int R3, bool REASSIGN, bool CST64>
 __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
-    __shared__ c32 buf[D_POINTS];
-    // the frames' Tx: a real and an imaginary plane of (L/2 + 1) x G float64 cells
+    // the frames' Tx: a real and an imaginary plane of (L/2 + 1) x G float64 cells. The planes take the FFT buffer's
+    // place once its last reader is done (the workgroup's LDS stays at 32 KB + 16 G bytes: four workgroups per CU)
     constexpr int CELLS = REASSIGN ? (L / 2 + 1) * G : 1;
-    __shared__ double txt[2 * CELLS];
-    // (the REASSIGN builds hold the FFT buffer and the frames' float64 Tx planes side by side: a gfx950 workgroup may
-    // use 160 KB of LDS, two of these workgroups share a CU)
-    static_assert(sizeof(c32) * D_POINTS + sizeof(double) * 2 * CELLS <= 80 * 1024,
-                  "stft_fused_kernel: static LDS beyond half of a gfx950 CU's 160 KB");
-    if constexpr (REASSIGN) {
-        for (int i = threadIdx.x; i < 2 * CELLS; i += NT) txt[i] = 0.0;     // (barriers follow before its first use)
-    }
+    constexpr int RAW = REASSIGN && 2 * CELLS > D_POINTS ? 2 * CELLS : D_POINTS;
+    __shared__ double raw[RAW];
+    c32* const buf = reinterpret_cast<c32*>(raw);
+    double* const txt = raw;
+    float* const sm = reinterpret_cast<float*>(raw);
+    static_assert(sizeof(double) * RAW <= 40 * 1024, "stft_fused_kernel: static LDS beyond a quarter of a gfx950 CU's 160 KB");
     constexpr int RL = (R3 > 1) ? R3 : R2;
-    // workgroups are dealt to the 8 XCDs round-robin: give each XCD one contiguous range of
-    // frames, so that the G*8-byte pieces of an output line meet in one L2 before they leave
-    int bx = blockIdx.x;
-    if (A.xcd) bx = (bx & 7) * (int)(gridDim.x >> 3) + (bx >> 3);
-    const int tid = threadIdx.x, c0 = bx * G;
-    if (c0 >= A.n_hops) return;
-    const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
-    // (no padded copy: frames inside the signal read it directly -- all but the workgroups at its two ends)
-    const bool inside = A.x != nullptr && A.hop * c0 - A.n1 >= 0 && A.hop * (c0 + G - 1) + L - 1 - A.n1 < A.n;
-    const float* xs = A.x + (int64_t)blockIdx.y * A.n - A.n1;
+    constexpr int NI = ((L / 2 + 1) * G + NT - 1) / NT;       // epilogue points per work-item
+    using w_t = typename std::conditional<CST64, double, float>::type;
+    const int tid = threadIdx.x;
     const bool deriv = A.dSx != nullptr || A.kidx != nullptr || REASSIGN;
-    c32 z[PPT];
+    // The item's frames overlap (hop < L): their samples, hop (G - 1) + L of them, come in ONE coalesced pass -- global
+    // -> LDS (the FFT buffer, idle until the first pass) -> registers -- instead of 16 four-byte loads per work-item
+    // that touch G separate runs each. Frames too far apart for the buffer, and the padded-copy route, read global
+    // memory directly as before.
+    const int span = A.hop * (G - 1) + L;
+    const bool staged = A.x != nullptr && span <= 2 * D_POINTS;
+    // modulated: the frame is rotated by n_fft / 2 (utils/stft_utils.py:76-82) -- L is even: an XOR
+    const int rot = A.modulated ? L / 2 : 0;
+    // the items (signal, group of G frames), frames fastest. Workgroups are dealt to the 8 XCDs round-robin: each XCD
+    // takes one contiguous range of items, so that the G*8-byte pieces of an output line meet in one L2 before they leave
+    const int ng = (int)((A.n_hops + G - 1) / G);
+    const int64_t total = (int64_t)ng * A.batch;
+    int64_t item = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (A.xcd) {
+        const int64_t nwg = (int64_t)gridDim.x * gridDim.y, per = nwg >> 3;       // (the launch pads nwg to a multiple of 8)
+        item = (item & 7) * per + (item >> 3);
+    }
+    if (item >= total) return;
+#ifdef STFT_STAMPS
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     {
-        constexpr int NB = PPT / R1, STR = L / R1;
+        const int b = (int)(item / ng), c0 = (int)(item % ng) * G;
+        const int t0 = A.hop * c0 - A.n1;                      // the first sample's index in the signal
+        // (frames inside the signal read it directly -- all but the items at its two ends, padded on the fly)
+        const bool inside = A.x != nullptr && t0 >= 0 && t0 + span - 1 < A.n;
+        c32 z[PPT];
+        if (staged) {
+            // (the window pairs are asked for before the samples: their latency passes behind the staging barrier --
+            // phase stamps, "r6x": reading them after it was a quarter of a workgroup's life)
+            constexpr int NB = PPT / R1, STR = L / R1;
+            float2 wv[PPT];
 #pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            const int idx = tid + it * NT, g = idx % G, u = idx / G;
-            const int c = c0 + g;
+            for (int it = 0; it < NB; ++it) {
 #pragma unroll
-            for (int k = 0; k < R1; ++k) {
-                const int r = u + k * STR;                    // sample of the frame
-                // modulated: the frame is rotated by ceil(n_fft/2) (utils/stft_utils.py:76-82)
-                const int s = !A.modulated ? r : (r < A.s20 ? A.s21 + r : r - A.s20);
-                float a = 0.f, b = 0.f;
-                if (c < A.n_hops) {
-                    float v;
-                    if (inside) v = xs[A.hop * c + s];         // (workgroup-uniform: every sample of its frames exists)
-                    else if (A.x) {                            // the signal's ends: padded on the fly
-                        const int src = stft_pad_source(A.hop * c + s - A.n1, A.n, A.padtype);
-                        v = src < 0 ? 0.f : A.x[(int64_t)blockIdx.y * A.n + src];
-                    } else v = xp[(int64_t)A.hop * c + s];
-                    a = v * A.window[r];
-                    if (deriv) b = v * A.diff_window[r];
+                for (int k = 0; k < R1; ++k) {
+                    const int r = (tid + it * NT) / G + k * STR;
+                    if (deriv && A.wd) wv[it * R1 + k] = A.wd[r];
+                    else wv[it * R1 + k] = make_float2(A.window[r], 0.f);
                 }
-                z[it * R1 + k] = {a, -b};
             }
-        }
-    }
-    lds_ifft<L, G, R1, R2, R3>(z, buf, A.ftw, tid);
-    __syncthreads();                                  // last pass' LDS reads are done
-    {
-        constexpr int NB = PPT / RL, STR = L / RL;
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            const int idx = tid + it * NT, g = idx % G, u = idx / G;
-#pragma unroll
-            for (int k = 0; k < RL; ++k) buf[(u + k * STR) * G + g] = z[it * RL + k];
-        }
-    }
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.y * A.rows * A.n_hops;
-    for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
-        const int f = i / G, g = i % G, c = c0 + g;
-        if (c >= A.n_hops) continue;
-        const c32 P = buf[f * G + g], Q = buf[((L - f) & (L - 1)) * G + g];
-        const int64_t q = base + (int64_t)f * A.n_hops + c;
-        const float sr = 0.5f * (P.x + Q.x), si = 0.5f * (Q.y - P.y);
-        A.Sx[q] = make_float2(sr, si);
-        if (!deriv) continue;
-        const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
-        if (A.dSx) A.dSx[q] = make_float2(dr, di);
-        if (A.kidx || REASSIGN) {   // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
-            const int64_t omax = A.rows - 1;
-            unsigned short kk = 0xFFFFu;
-            if (mag_gt(sr, si, A.gamma)) {
-                const int64_t kb = bin_of_point(dr, di, sr, si, true, A.Sfs[f], sp, omax);
-                kk = (unsigned short)(sp.flipud ? omax - kb : kb);
-            }
-            if constexpr (REASSIGN) {
-                if (kk != 0xFFFFu) {
-                    // the term in the CPU path's arithmetic (float32 product; float64 with a float64 weight
-                    // vector), the sum in float64
-                    using w_t = typename std::conditional<CST64, double, float>::type;
-                    const w_t wv = ((const w_t*)A.cst)[A.cst_uniform ? 0 : f];
-                    const double tr = (double)((w_t)sr * wv), ti = (double)((w_t)si * wv);
-                    const unsigned off = ((unsigned)kk * G + (unsigned)g) * 8u;
-                    SSQ_LDS_ADD_F64(txt, off, tr);
-                    SSQ_LDS_ADD_F64(txt, off + (unsigned)CELLS * 8u, ti);
+            const float* xb = A.x + (int64_t)b * A.n;
+            if (inside) {
+                for (int i = tid * 4; i < span; i += NT * 4) {
+                    if (i + 4 <= span) *reinterpret_cast<ssq_f4*>(sm + i) = *reinterpret_cast<const ssq_f4a4*>(xb + t0 + i);
+                    else for (int q = i; q < span; ++q) sm[q] = xb[t0 + q];
                 }
             } else {
-                A.kidx[q] = kk;
+                for (int i = tid; i < span; i += NT) {
+                    const int src = stft_pad_source(t0 + i, A.n, A.padtype);
+                    sm[i] = src < 0 ? 0.f : xb[src];
+                }
+            }
+            __syncthreads();
+            ST_STAMP(0);
+#pragma unroll
+            for (int it = 0; it < NB; ++it) {
+                const int idx = tid + it * NT, g = idx % G, u = idx / G;
+                const bool live = c0 + g < A.n_hops;
+                const float* fr = sm + A.hop * g;
+#pragma unroll
+                for (int k = 0; k < R1; ++k) {
+                    const int r = u + k * STR;                // sample of the frame
+                    const float v = live ? fr[r ^ rot] : 0.f;
+                    z[it * R1 + k] = {v * wv[it * R1 + k].x, -(v * wv[it * R1 + k].y)};
+                }
+            }
+            __syncthreads();                                   // the samples are in registers: the buffer is the FFT's
+            ST_STAMP(1);
+        } else {
+            const float* xp = A.xp + (int64_t)b * A.padlen;
+            const float* xs = A.x + (int64_t)b * A.n - A.n1;
+            constexpr int NB = PPT / R1, STR = L / R1;
+#pragma unroll
+            for (int it = 0; it < NB; ++it) {
+                const int idx = tid + it * NT, g = idx % G, u = idx / G;
+                const int c = c0 + g;
+#pragma unroll
+                for (int k = 0; k < R1; ++k) {
+                    const int r = u + k * STR;                // sample of the frame
+                    const int s = r ^ rot;
+                    float a = 0.f, bb = 0.f;
+                    if (c < A.n_hops) {
+                        float v;
+                        if (inside) v = xs[A.hop * c + s];     // (item-uniform: every sample of its frames exists)
+                        else if (A.x) {                        // the signal's ends: padded on the fly
+                            const int src = stft_pad_source(A.hop * c + s - A.n1, A.n, A.padtype);
+                            v = src < 0 ? 0.f : A.x[(int64_t)b * A.n + src];
+                        } else v = xp[(int64_t)A.hop * c + s];
+                        a = v * A.window[r];
+                        if (deriv) bb = v * A.diff_window[r];
+                    }
+                    z[it * R1 + k] = {a, -bb};
+                }
+            }
+#ifdef STFT_STAMPS
+            __builtin_amdgcn_s_waitcnt(0); ST_STAMP(1);
+#endif
+        }
+        // the rows' frequencies of the epilogue's points (and the weight of the reference's linear grid -- a weight
+        // vector is read where it is used) are asked for here, a transform ahead of their use
+        float sf[REASSIGN ? NI : 1]; w_t cw0 = 0;
+        if constexpr (REASSIGN) {
+#pragma unroll
+            for (int it = 0; it < NI; ++it) sf[it] = A.Sfs[min((tid + it * NT) / G, L / 2)];
+            cw0 = ((const w_t*)A.cst)[0];
+        }
+        // (FRESH: a barrier has just passed; the twiddles asked for ahead of each pass' barrier measured no gain here)
+        lds_ifft<L, G, R1, R2, R3, false, true>(z, buf, A.ftw, tid);
+        __syncthreads();                              // last pass' LDS reads are done
+        ST_STAMP(2);
+        {
+            constexpr int NB = PPT / RL, STR = L / RL;
+#pragma unroll
+            for (int it = 0; it < NB; ++it) {
+                const int idx = tid + it * NT, g = idx % G, u = idx / G;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) buf[(u + k * STR) * G + g] = z[it * RL + k];
             }
         }
-    }
-    if constexpr (REASSIGN) {
         __syncthreads();
-        for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
-            const int f = i / G, g = i % G, c = c0 + g;
-            if (c >= A.n_hops) continue;
-            A.Tx[base + (int64_t)f * A.n_hops + c] = make_float2((float)txt[i], (float)txt[CELLS + i]);
+        ST_STAMP(3);
+        const int64_t base = (int64_t)b * A.rows * A.n_hops;
+        if constexpr (!REASSIGN) {
+            for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
+                const int f = i / G, g = i % G, c = c0 + g;
+                if (c >= A.n_hops) continue;
+                const c32 P = buf[f * G + g], Q = buf[((L - f) & (L - 1)) * G + g];
+                const int64_t q = base + (int64_t)f * A.n_hops + c;
+                const float sr = 0.5f * (P.x + Q.x), si = 0.5f * (Q.y - P.y);
+                A.Sx[q] = make_float2(sr, si);
+                if (!deriv) continue;
+                const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
+                if (A.dSx) A.dSx[q] = make_float2(dr, di);
+                if (A.kidx) {   // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
+                    const int64_t omax = A.rows - 1;
+                    unsigned short kk = 0xFFFFu;
+                    if (mag_gt(sr, si, A.gamma)) {
+                        const int64_t kb = bin_of_point(dr, di, sr, si, true, A.Sfs[f], sp, omax);
+                        kk = (unsigned short)(sp.flipud ? omax - kb : kb);
+                    }
+                    A.kidx[q] = kk;
+                }
+            }
+        } else {
+            // every point of the item's frames leaves the FFT buffer for registers (its Sx on the way to HBM, its bin
+            // beside it) before the buffer becomes the Tx planes. No early-outs: a point outside the frames, or below
+            // gamma, carries the bin 0xFFFF
+            float vr[NI], vi[NI]; unsigned kq[NI];
+            const int omax = (int)A.rows - 1;
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = tid + it * NT, f = min(i / G, L / 2), g = i % G, c = c0 + g;
+                const bool valid = i < (L / 2 + 1) * G && c < A.n_hops;
+                const c32 P = buf[f * G + g], Q = buf[((L - f) & (L - 1)) * G + g];
+                const float sr = 0.5f * (P.x + Q.x), si = 0.5f * (Q.y - P.y);
+                const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
+                if (valid) {
+                    A.Sx[base + (int64_t)f * A.n_hops + c] = make_float2(sr, si);
+                    if (A.dSx) A.dSx[base + (int64_t)f * A.n_hops + c] = make_float2(dr, di);
+                }
+                // the fused kernels' rule (algos.py:956-984): |Sx| > gamma, then the bin
+                const bool on = valid && mag_gt(sr, si, A.gamma);
+                const int kb = bin_of_point_stft(dr, di, sr, si, sf[it], sp, omax, on);
+                kq[it] = on ? (unsigned)(sp.flipud ? omax - kb : kb) : 0xFFFFu;
+                vr[it] = sr; vi[it] = si;
+                if (it % 3 == 2) SSQ_SCHED_FENCE();            // (three points' LDS reads in flight, not all nine)
+            }
+            ST_STAMP(4);
+            __syncthreads();                              // the buffer's last read
+            for (int i = tid; i < 2 * CELLS; i += NT) txt[i] = 0.0;
+            __syncthreads();
+            ST_STAMP(5);
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                if (kq[it] == 0xFFFFu) continue;
+                const int g = (tid + it * NT) % G;
+                // the term in the CPU path's arithmetic (float32 product; float64 with a float64 weight vector), the
+                // sum in float64
+                const w_t cw = A.cst_uniform ? cw0 : ((const w_t*)A.cst)[min((tid + it * NT) / G, L / 2)];
+                const double tr = (double)((w_t)vr[it] * cw), ti = (double)((w_t)vi[it] * cw);
+                const unsigned off = (kq[it] * G + (unsigned)g) * 8u;
+                SSQ_LDS_ADD_F64(txt, off, tr);
+                SSQ_LDS_ADD_F64(txt, off + (unsigned)CELLS * 8u, ti);
+            }
+            __syncthreads();
+            ST_STAMP(6);
+            for (int i = tid; i < (L / 2 + 1) * G; i += NT) {
+                const int f = i / G, g = i % G, c = c0 + g;
+                if (c >= A.n_hops) continue;
+                A.Tx[base + (int64_t)f * A.n_hops + c] = make_float2((float)txt[i], (float)txt[CELLS + i]);
+            }
+            ST_STAMP(7);
+#ifdef STFT_STAMPS
+            __builtin_amdgcn_s_waitcnt(0);
+            ST_STAMP(8);
+#endif
         }
     }
 }
 
+// one workgroup per item; the grid is two-dimensional only to hold more than 2^31 - 1 of them
 template <int L, int G, int R1, int R2, int R3>
 static int launch_stft_fused(const StftFusedArgs& A, const SsqParams& sp, int64_t batch, hipStream_t stream) {
     SSQ_REQUIRE(!A.Tx || A.rows == L / 2 + 1, "fused reassignment: %lld rows, transform of %d", (long long)A.rows, L);
     static const bool remap = [] { const char* e = getenv("SSQ_DEBUG_STFT_XCD"); return !e || atoi(e) != 0; }();
     StftFusedArgs B = A;
-    unsigned nb = (unsigned)((A.n_hops + G - 1) / G);
-    B.xcd = remap && nb >= 64;
-    if (B.xcd) nb = (nb + 7u) & ~7u;
-    dim3 grid(nb, (unsigned)batch);
+    B.batch = (int)batch;
+    int64_t total = (int64_t)((A.n_hops + G - 1) / G) * batch;
+    B.xcd = remap && total >= 64;
+    if (B.xcd) total = (total + 7) & ~(int64_t)7;
+    // (grid.x a multiple of 8 when the items are remapped, so that the product is one too)
+    const int64_t gx = std::min<int64_t>(total, (int64_t)1 << 20), gy = (total + gx - 1) / gx;
+    SSQ_REQUIRE(gy <= 65535, "stft_fused_kernel: %lld items", (long long)total);
+    dim3 grid((unsigned)gx, (unsigned)gy);
     if (!A.Tx)
         hipLaunchKernelGGL((stft_fused_kernel<L, G, R1, R2, R3, false, false>), grid, dim3(NT), 0, stream, B, sp);
     else if (sp.cst_f64)
@@ -232,6 +359,7 @@ struct ssq_stft_plan {
     void* xp = nullptr; void* frames = nullptr; void* dframes = nullptr; void* dSx_ws = nullptr;
     StridedR2C fft;
     bool fused = false; void* ftw = nullptr;      // fused float32 path (power-of-two n_fft)
+    void* wd = nullptr;                           // ... its (window, diff_window) pairs, one 8-byte load per sample
     // fused float32 path for the other sizes (prime factors <= 31): mixed-radix LDS transform
     bool generic_fused = false; int gen_radix[GEN_MAX_PASSES] = {0}; int gen_npass = 0, gen_G = 0;
     unsigned short* kidx = nullptr;               // bin map of the fused ssq_stft form
@@ -284,6 +412,14 @@ int ssq_stft_plan_create(ssq_stft_plan** out, const ssq_stft_desc* desc) {
         }
         if (hipMalloc(&pl->ftw, tw.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
         SSQ_CHECK_HIP(hipMemcpy(pl->ftw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice));
+        if (d.diff_window) {
+            std::vector<float> wd((size_t)2 * d.n_fft);
+            for (int64_t q = 0; q < d.n_fft; ++q) {
+                wd[2 * q] = ((const float*)d.window)[q]; wd[2 * q + 1] = ((const float*)d.diff_window)[q];
+            }
+            if (hipMalloc(&pl->wd, wd.size() * 4) != hipSuccess) { set_error("hipMalloc failed (stft plan)"); ssq_stft_plan_destroy(pl); return -2; }
+            SSQ_CHECK_HIP(hipMemcpy(pl->wd, wd.data(), wd.size() * 4, hipMemcpyHostToDevice));
+        }
         pl->fused = true;
     } else if (d.dtype == SSQ_F32 && !getenv("SSQ_DEBUG_STFT_GENERIC")
                && stft_generic_plan(d.n_fft, pl->gen_radix, &pl->gen_npass, &pl->gen_G)) {
@@ -317,7 +453,7 @@ void ssq_stft_plan_destroy(ssq_stft_plan* pl) {
     pl->fft.destroy();
     pl->weights.destroy(); pl->freqs.destroy(); pl->order.destroy();
     void* ptrs[] = {pl->window, pl->diff_window, pl->xp, pl->frames, pl->dframes, pl->dSx_ws,
-                    pl->ftw, pl->kidx};
+                    pl->ftw, pl->kidx, pl->wd};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete pl;
 }
@@ -348,6 +484,11 @@ int ssq_stft_plan_set_ssq(ssq_stft_plan* pl, const void* Sfs, int grid, const do
     return 0;
 }
 
+#ifdef STFT_STAMPS
+int ssq_debug_stft_prof(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ssq::g_stft_prof), sizeof(unsigned long long) * 16);
+}
+#endif
 const char* ssq_stft_plan_algo(const ssq_stft_plan* pl) {
     return !pl ? "" : pl->fused ? "fused" : pl->generic_fused ? "fused-mixed-radix" : "rocfft";
 }
@@ -389,13 +530,12 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
     if constexpr (sizeof(T) == 4) {
         if ((pl->fused || pl->generic_fused) && Tx && !w && !dSx && rows < 65535) {
             use_kidx = true;
-            // (measured, C3: one signal 68 us against 72 with the separate pass; 512 signals 2.75 ms against
-            // 2.35 -- a workgroup's Tx goes out as G * 8-byte pieces and the tile halves the occupancy, so
-            // the fused sums serve the calls that do not fill the GPU; SSQ_DEBUG_STFT_FUSED_TX=0/1 forces)
+            // (round 6, the Tx planes in the FFT buffer's place, four workgroups per CU: config 3 at 512 signals 1.87 ms
+            // against 2.19 with the separate pass, 64 signals 0.26 against 0.31, hop 1 0.83 against 1.02 -- profiles/
+            // r6_ab_history.txt "r6w"; the separate pass stays for the ordered sums; SSQ_DEBUG_STFT_FUSED_TX=0/1 forces)
             const char* fe = getenv("SSQ_DEBUG_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
-            const int force = fe ? atoi(fe) : -1;
-            fused_tx = pl->fused && !reassign_ordered() && rows == n_fft / 2 + 1 &&
-                       (force >= 0 ? force != 0 : batch * n_hops <= 4096);
+            const int force = (fe && *fe) ? atoi(fe) : -1;
+            fused_tx = pl->fused && !reassign_ordered() && rows == n_fft / 2 + 1 && force != 0;
             if (!fused_tx && !pl->kidx)
                 SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
         }
@@ -415,6 +555,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated;
             A.x = pad_in_kernel ? (const float*)x : nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype;
+            A.wd = (const float2*)pl->wd;
             switch (n_fft) {
                 case 128: rc = launch_stft_fused<128, 32, 16, 8, 1>(A, pl->sp, batch, stream); break;
                 case 256: rc = launch_stft_fused<256, 16, 16, 16, 1>(A, pl->sp, batch, stream); break;
@@ -435,7 +576,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.Tx = nullptr; A.cst = nullptr; A.cst_uniform = 0;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated; A.xcd = 0;
-            A.x = nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype;
+            A.x = nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype; A.wd = nullptr; A.batch = (int)batch;
             rc = launch_stft_generic(A, pl->sp, (const c32*)pl->ftw, (int)n_fft, pl->gen_radix, pl->gen_npass, pl->gen_G,
                                      batch, stream);
             if (rc) return rc;

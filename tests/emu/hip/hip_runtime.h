@@ -27,6 +27,7 @@ inline long long max(long long a, int b) { return a > b ? a : b; }
 
 #define SSQ_OPAQUE_V(x) ((void)(x))
 #define SSQ_OPAQUE_S(x) ((void)(x))
+#define SSQ_SCHED_FENCE() ((void)0)
 #define SSQ_WAVES_PER_EU(lo, hi)
 // stand-ins of the inline-assembly forms of csrc/ssq_common.h
 inline int emu_ds_bpermute(int byte_addr, int v);

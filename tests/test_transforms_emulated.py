@@ -199,7 +199,10 @@ def test_fused_stft_reassignment_emulated(S, monkeypatch):
     SSQ_TILE_ORDER=ordered gives the ordered sums bit for bit."""
     from conftest import two_chirps, assert_tx_vs_oracle
     from ssqueezepy_amd import _stft
-    for n_fft, hop, N, fl in ((128, 32, 1500, False), (1024, 256, 6000, False), (256, 37, 3000, True)):
+    # (hop 1: the frames' samples staged through LDS at an arbitrary alignment; hop 300 at n_fft 128: frames too far apart
+    # for the staging buffer, read directly)
+    for n_fft, hop, N, fl in ((128, 32, 1500, False), (1024, 256, 6000, False), (256, 37, 3000, True),
+                              (128, 1, 2200, False), (128, 300, 12000, True)):
         x = two_chirps(N, seed=n_fft)
         _stft._PLAN_CACHE.clear()
         Tx, Sx, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', get_dWx=True, flipud=fl,
