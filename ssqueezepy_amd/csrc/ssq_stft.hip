@@ -63,6 +63,10 @@ __global__ __launch_bounds__(256) void frame_window_kernel(
 // the item's samples come through LDS in one coalesced pass; the tables an item needs (window pairs, row frequencies,
 // weights) are asked for a phase ahead of their use. Persistent workgroups that fetch the next item's samples while they
 // transform the current one were built and measured slower (the loop costs 40 registers: three workgroups per CU).
+// What the kernel is NOT bound by, each measured ("r6y8".."r6y11"): a fifth workgroup per CU (the last row of the planes
+// kept in registers, LDS exactly 32 KB: no change), its 32-byte output pieces (the same bytes as full lines: -4 %), the
+// transform's LDS bank conflicts (padded columns: +2 %). The counters put the vector ALU at ~60 % and the LDS pipe at
+// ~58 % busy: what is left is instruction count.
 
 template <int L, int G, int R1, int R2, int R3, bool REASSIGN, bool CST64>
 __global__ __launch_bounds__(NT) void stft_fused_kernel(StftFusedArgs A, SsqParams sp) {
