@@ -51,6 +51,7 @@ constexpr int GEN_NT = 256;
 constexpr int GEN_MAX_PASSES = 10;
 constexpr int GEN_MAX_PPT = 40;                     // complex points a work-item holds in a pass (n_fft * G / 256 <= 39)
 constexpr int GEN_LDS_BYTES = 78 * 1024;            // n_fft * G * 8 bytes at most: two workgroups per CU
+constexpr int GEN_MAX_EPI = 10;                     // epilogue points a work-item holds: (n_fft / 2 + 1) * G / 256, rounded up
 // factors of n (16s, 8s, 4s, a 2, then the odd primes up to 31) and the frames per workgroup; false when n has a
 // larger prime factor, too many factors, or does not fit the LDS
 bool stft_generic_plan(int64_t n, int* radix, int* npass, int* G);

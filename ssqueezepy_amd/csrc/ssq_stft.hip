@@ -539,7 +539,7 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             // r6_ab_history.txt "r6w"; the separate pass stays for the ordered sums; SSQ_DEBUG_STFT_FUSED_TX=0/1 forces)
             const char* fe = getenv("SSQ_DEBUG_STFT_FUSED_TX");        // (read at every call, like SSQ_TILE_ORDER: tests switch it)
             const int force = (fe && *fe) ? atoi(fe) : -1;
-            fused_tx = pl->fused && !reassign_ordered() && rows == n_fft / 2 + 1 && force != 0;
+            fused_tx = !reassign_ordered() && rows == n_fft / 2 + 1 && force != 0;
             if (!fused_tx && !pl->kidx)
                 SSQ_CHECK_HIP(hipMalloc((void**)&pl->kidx, (size_t)pl->d.max_batch * rows * n_hops * 2));
         }
@@ -576,8 +576,8 @@ static int stft_execute_t(ssq_stft_plan* pl, const void* x, int64_t batch, void*
             A.xp = (const float*)pl->xp; A.window = (const float*)pl->window;
             A.diff_window = (const float*)pl->diff_window; A.ftw = nullptr;
             A.Sx = (float2*)Sx; A.dSx = (deriv && !use_kidx) ? (float2*)dS : nullptr;
-            A.kidx = use_kidx ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
-            A.Tx = nullptr; A.cst = nullptr; A.cst_uniform = 0;
+            A.kidx = (use_kidx && !fused_tx) ? pl->kidx : nullptr; A.Sfs = (const float*)pl->Sfs; A.gamma = pl->sp.gamma;
+            A.Tx = fused_tx ? (float2*)Tx : nullptr; A.cst = pl->cst; A.cst_uniform = pl->sp.cst_uniform;
             A.padlen = pl->padlen; A.n_hops = n_hops; A.rows = rows;
             A.hop = (int)d.hop_len; A.s20 = (int)s20; A.s21 = (int)s21; A.modulated = d.modulated; A.xcd = 0;
             A.x = nullptr; A.n = (int)d.n; A.n1 = (int)pl->n1; A.padtype = d.padtype; A.wd = nullptr; A.batch = (int)batch;

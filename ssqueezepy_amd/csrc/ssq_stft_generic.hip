@@ -116,7 +116,7 @@ __global__ __launch_bounds__(GEN_NT) void stft_generic_kernel(StftGenArgs B, Ssq
     const int tid = threadIdx.x, c0 = bx * G;
     if (c0 >= A.n_hops) return;
     const float* xp = A.xp + (int64_t)blockIdx.y * A.padlen;
-    const bool deriv = A.dSx != nullptr || A.kidx != nullptr;
+    const bool deriv = A.dSx != nullptr || A.kidx != nullptr || A.Tx != nullptr;
     for (int i = tid; i < (n << lgG); i += GEN_NT) {
         const int g = i & (G - 1), r = i >> lgG, c = c0 + g;
         // modulated: the frame is rotated by ceil(n_fft/2) (utils/stft_utils.py:76-82)
@@ -157,6 +157,55 @@ __global__ __launch_bounds__(GEN_NT) void stft_generic_kernel(StftGenArgs B, Ssq
     // Z' = IDFT(a - ib) = conj(FFT(a + ib)); A[f] = (Z[f] + conj(Z[n-f])) / 2, B[f] = (Z[f] - conj(Z[n-f])) / 2i
     const int64_t base = (int64_t)blockIdx.y * A.rows * A.n_hops;
     const int nrow = (n >> 1) + 1;
+    if (A.Tx) {
+        // The fused ssq_stft form sums Tx of the workgroup's frames itself, as stft_fused_kernel does (round 6): every
+        // point leaves the buffer for registers (its Sx on the way to HBM, its bin beside it), then both buffers
+        // become a real and an imaginary plane of nrow x G float64 cells ((n + 2) G 8 bytes of the 2 n G 8 there are).
+        constexpr int NI = GEN_MAX_EPI;                 // (n / 2 + 1) G / 256 <= 10: n G * 16 <= GEN_LDS_BYTES, G <= 16
+        float vr[NI], vi[NI]; unsigned kq[NI];
+        const int omax = (int)A.rows - 1, cells = nrow << lgG;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * GEN_NT, f = min(i >> lgG, nrow - 1), g = i & (G - 1), c = c0 + g;
+            const bool valid = i < cells && c < A.n_hops;
+            const c32 P = buf[(f << lgG) + g], Q = buf[((f ? n - f : 0) << lgG) + g];
+            const float sr = 0.5f * (P.x + Q.x), si = 0.5f * (Q.y - P.y);
+            const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
+            if (valid) A.Sx[base + (int64_t)f * A.n_hops + c] = make_float2(sr, si);
+            const bool on = valid && mag_gt(sr, si, A.gamma);
+            const int kb = bin_of_point_stft(dr, di, sr, si, A.Sfs[f], sp, omax, on);
+            kq[it] = on ? (unsigned)(sp.flipud ? omax - kb : kb) : 0xFFFFu;
+            vr[it] = sr; vi[it] = si;
+        }
+        __syncthreads();                                // the buffer's last read
+        double* const txt = reinterpret_cast<double*>(lds_raw);
+        for (int i = tid; i < 2 * cells; i += GEN_NT) txt[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            if (kq[it] == 0xFFFFu) continue;
+            const int i = tid + it * GEN_NT, f = i >> lgG, g = i & (G - 1);
+            // the term in the CPU path's arithmetic (float32 product; float64 with a float64 weight vector)
+            double tr, ti;
+            if (sp.cst_f64) {
+                const double w = ((const double*)A.cst)[A.cst_uniform ? 0 : f];
+                tr = (double)vr[it] * w; ti = (double)vi[it] * w;
+            } else {
+                const float w = ((const float*)A.cst)[A.cst_uniform ? 0 : f];
+                tr = (double)(vr[it] * w); ti = (double)(vi[it] * w);
+            }
+            const unsigned off = ((kq[it] << lgG) + (unsigned)g) * 8u;
+            SSQ_LDS_ADD_F64(txt, off, tr);
+            SSQ_LDS_ADD_F64(txt, off + (unsigned)cells * 8u, ti);
+        }
+        __syncthreads();
+        for (int i = tid; i < cells; i += GEN_NT) {
+            const int f = i >> lgG, g = i & (G - 1), c = c0 + g;
+            if (c >= A.n_hops) continue;
+            A.Tx[base + (int64_t)f * A.n_hops + c] = make_float2((float)txt[i], (float)txt[cells + i]);
+        }
+        return;
+    }
     for (int i = tid; i < (nrow << lgG); i += GEN_NT) {
         const int f = i >> lgG, g = i & (G - 1), c = c0 + g;
         if (c >= A.n_hops) continue;
@@ -229,6 +278,7 @@ int launch_stft_generic(const StftFusedArgs& A, const SsqParams& sp, const c32* 
         C.F.Sx = A.Sx + pts;
         C.F.dSx = A.dSx ? A.dSx + pts : nullptr;
         C.F.kidx = A.kidx ? A.kidx + pts : nullptr;
+        C.F.Tx = A.Tx ? A.Tx + pts : nullptr;
         hipLaunchKernelGGL(stft_generic_kernel, dim3(nb, (unsigned)nb_sig), dim3(GEN_NT), lds, stream, C, sp);
         SSQ_LAUNCH_CHECK();
     }

@@ -202,7 +202,9 @@ def test_fused_stft_reassignment_emulated(S, monkeypatch):
     # (hop 1: the frames' samples staged through LDS at an arbitrary alignment; hop 300 at n_fft 128: frames too far apart
     # for the staging buffer, read directly)
     for n_fft, hop, N, fl in ((128, 32, 1500, False), (1024, 256, 6000, False), (256, 37, 3000, True),
-                              (128, 1, 2200, False), (128, 300, 12000, True)):
+                              (128, 1, 2200, False), (128, 300, 12000, True),
+                              # (the mixed-radix kernel sums Tx itself too: 598 = 2 x 13 x 23 at G = 8, 60 = 4 x 3 x 5 at G = 16)
+                              (598, 119, 2500, False), (60, 7, 900, True)):
         x = two_chirps(N, seed=n_fft)
         _stft._PLAN_CACHE.clear()
         Tx, Sx, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', get_dWx=True, flipud=fl,
