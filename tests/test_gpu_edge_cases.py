@@ -151,6 +151,29 @@ def test_fused_stft_every_size(S, orc, n_fft):
         assert relmax(dSx, dSx2) <= 1e-5
 
 
+@pytest.mark.parametrize('n_fft,hop', [(1024, 256), (256, 1), (598, 37), (2048, 300), (128, 77)])
+def test_fused_stft_sums_equal_the_separate_pass(S, n_fft, hop, monkeypatch):
+    """Round 6: the fused STFT kernels sum Tx themselves at EVERY batch size (their float64 planes take the transform
+    buffer's place in LDS). Batches beyond the old 4096-frame rule, the mixed-radix kernel included, against the
+    separate pass over the 2-byte bin map (`SSQ_DEBUG_STFT_FUSED_TX=0`): the same Sx bit for bit, the same float64 sums
+    of the same terms -- equal up to the order of the adds."""
+    from ssqueezepy_amd import _stft
+    N, B = 20000, (6 if hop == 1 else 24)
+    x = np.stack([two_chirps(N, seed=100 + s) for s in range(B)])
+    out = {}
+    for ft in ('1', '0'):
+        monkeypatch.setenv('SSQ_DEBUG_STFT_FUSED_TX', ft)
+        _stft._PLAN_CACHE.clear()
+        Tx, Sx, *_ = S.ssq_stft(x, n_fft=n_fft, hop_len=hop, dtype='float32', astensor=False)
+        out[ft] = (Tx, Sx)
+    monkeypatch.delenv('SSQ_DEBUG_STFT_FUSED_TX')
+    _stft._PLAN_CACHE.clear()
+    assert B * out['1'][1].shape[-1] > 4096
+    assert np.array_equal(out['1'][1], out['0'][1])
+    for b in range(B):
+        assert_tx_vs_oracle(out['1'][0][b], out['0'][0][b], what=(n_fft, hop, b))
+
+
 def test_plan_reuse_across_streams_and_parameter_changes(S):
     """One cached plan, two non-blocking streams, reassignment parameters that alternate
     between the calls: an execute must neither see the other's weights nor share its
