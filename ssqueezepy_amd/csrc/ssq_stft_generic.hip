@@ -243,6 +243,11 @@ bool stft_generic_plan(int64_t n, int* radix, int* npass, int* G) {
     if (m != 1 || np > GEN_MAX_PASSES) return false;
     if (n * 16 > GEN_LDS_BYTES || n >= 65536) return false;     // (two buffers of n x G x 8 bytes; 16-bit butterfly indices)
     int g = 16;
+    // Four workgroups per CU (39 KB each) where at least four frames still fit, two (78 KB) for the longer transforms:
+    // n_fft = 598 at G = 4 instead of 8 measured 0.87 -> 0.78 ms at hop 1 ("r6y15"; G = 2, eight workgroups: 1.21 ms).
+    // (SSQ_DEBUG_STFT_GEN_LDS=<KB> moves the first limit -- A/B aid)
+    static const int64_t soft_cap = [] { const char* e = getenv("SSQ_DEBUG_STFT_GEN_LDS"); return e && atoi(e) > 0 ? (int64_t)atoi(e) * 1024 : (int64_t)GEN_LDS_BYTES / 2; }();
+    while (g > 4 && n * g * 16 > std::min<int64_t>(soft_cap, GEN_LDS_BYTES)) g >>= 1;
     while (g > 1 && n * g * 16 > GEN_LDS_BYTES) g >>= 1;
     *npass = np; *G = g;
     return true;
