@@ -130,6 +130,12 @@ __global__ __launch_bounds__(GEN_NT) void stft_generic_kernel(StftGenArgs B, Ssq
         cur[i] = {a, -b};
     }
     __syncthreads();
+    // (the fused ssq_stft form: the rows' frequencies of the epilogue's points are asked for a transform ahead)
+    float sfq[GEN_MAX_EPI];
+    if (A.Tx) {
+#pragma unroll
+        for (int it = 0; it < GEN_MAX_EPI; ++it) sfq[it] = A.Sfs[min((tid + it * GEN_NT) >> lgG, n >> 1)];
+    }
     int Ns = 1;
     for (int p = 0; p < B.npass; ++p) {
         const int R = B.radix[p];
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(GEN_NT) void stft_generic_kernel(StftGenArgs B, Ssq
             const float dr = -0.5f * (P.y + Q.y), di = 0.5f * (Q.x - P.x);
             if (valid) A.Sx[base + (int64_t)f * A.n_hops + c] = make_float2(sr, si);
             const bool on = valid && mag_gt(sr, si, A.gamma);
-            const int kb = bin_of_point_stft(dr, di, sr, si, A.Sfs[f], sp, omax, on);
+            const int kb = bin_of_point_stft(dr, di, sr, si, sfq[it], sp, omax, on);
             kq[it] = on ? (unsigned)(sp.flipud ? omax - kb : kb) : 0xFFFFu;
             vr[it] = sr; vi[it] = si;
         }
