@@ -271,8 +271,35 @@ __device__ __forceinline__ int bin_of_point_stft(float a, float b, float c, floa
     }
     return k;
 }
+// float64 data: the exact map costs a double division and a double log2 per point (a third of the float64 block
+// kernels' instructions). The float32 screen decides it for all but the points near a rounding boundary as well, given
+// an honest bound on the estimate's error: the inputs rounded to float32 (6e-8 each), the two products and their
+// difference (cancellation: the bound is absolute, on the products' magnitudes), the reciprocal, 2 pi as a float.
 __device__ __forceinline__ int64_t bin_of_point(double a, double b, double c, double d, bool stft,
                                                 double sfs, const SsqParams& sp, int64_t omax) {
+#ifndef SSQ_F64_NO_SCREEN
+    {
+        const float af = (float)a, bf = (float)b, cf = (float)c, df = (float)d;
+        const float p1 = bf * cf, p2 = af * df, num = p1 - p2;
+        const float m2 = cf * cf + df * df;
+        const float inv = __builtin_amdgcn_rcpf(m2 * 6.2831855f);
+        const float r32 = num * inv;
+        // |num - exact| <= (|p1| + |p2|) * 2.5e-7 (inputs 2 x 6e-8, product 6e-8, difference 6e-8): 4e-7 budgeted; the
+        // scale 1 / (2 pi m2) carries 4e-7 more (m2's inputs and sum, 2 pi, the reciprocal, the product)
+        const float rerr = (fabsf(p1) + fabsf(p2)) * 4e-7f * inv + fabsf(r32) * 4e-7f;
+        float w32, werr;
+        if (stft) {
+            const float sf = (float)sfs;
+            w32 = fabsf(sf - r32); werr = rerr + (fabsf(sf) + fabsf(r32)) * 2e-7f;
+        } else { w32 = fabsf(r32); werr = rerr; }
+        // (magnitudes outside float32's comfortable range: m2 under- or overflows, the estimate is void)
+        if (m2 > 1e-30f && m2 < 1e30f) {
+            const float lerr = 1.4428f * werr * __builtin_amdgcn_rcpf(w32);
+            const int k = bin_screen_f32(w32, werr, lerr, sp, (int)omax);
+            if (k != -2) return k;
+        }
+    }
+#endif
     double r = phase_ratio(a, b, c, d);
     double w = stft ? fabs(sfs - r) : fabs(r);
     return bin_from_w(w, sp, omax);
