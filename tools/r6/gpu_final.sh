@@ -10,6 +10,8 @@ l = ctypes.CDLL('/root/repo/ssqueezepy_amd/libssq_hip.so'); l.ssq_build_sha.rest
 print(l.ssq_build_sha().decode())
 PY
 echo "library: $(cat $O/build_sha.txt)"
+# (evidence belongs to a committed state: rebuild AFTER committing -- the stamp is taken at build time)
+if grep -q dirty $O/build_sha.txt && [ -z "$ALLOW_DIRTY" ]; then echo "the library was built from an uncommitted tree: commit, rebuild, run again (ALLOW_DIRTY=1 overrides)"; exit 3; fi
 # 1. the GPU suite (full-size BASELINE-config tests first)
 timeout 1500 python -m pytest tests -q -m gpu -x > $O/gpu_suite.txt 2>&1; tail -3 $O/gpu_suite.txt | cut -c1-300
 cp gpurun_out/parity_measured.jsonl $O/ 2>/dev/null
