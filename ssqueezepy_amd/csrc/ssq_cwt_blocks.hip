@@ -395,6 +395,21 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
     const double* psi = A.pbank + r.pb_off;
     const double* pxi = A.pxi + r.pb_off;
     const double invP = 1.0 / (double)P;
+    // (round 6, as in the float32 kernels since round 5: the band's three loads per point are issued BEFORE the barrier
+    // behind the staged twiddles -- two dependent round trips become one; config 5 "r6y21")
+    constexpr int NBP = PPT / R1, STRP = L / R1;
+    double bp[PPT], bm[PPT]; c64 bX[PPT];
+#pragma unroll
+    for (int it = 0; it < NBP; ++it) {
+        const int u = (tid + it * NT64) / G;
+        const int off0 = (u - r.klo) & (L - 1);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) {
+            const int off = (off0 + k * STRP) & (L - 1);
+            const int oc = off < r.KP ? off : 0;             // unconditional, clamped loads
+            bp[it * R1 + k] = psi[oc]; bX[it * R1 + k] = xb[r.klo + oc]; bm[it * R1 + k] = pxi[oc];
+        }
+    }
     {
         constexpr int STR = L / R1;
         for (int i = tid; i < R1 * G; i += NT64) {
@@ -406,6 +421,13 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
             wrapf[tid] = ctw[(0u - (unsigned)L * col) & (unsigned)(P - 1)];
         }
     }
+    c64 cw0s[NBP];
+#pragma unroll
+    for (int it = 0; it < NBP; ++it) {
+        const int idx = tid + it * NT64, g = idx % G, u = idx / G;
+        const int off0 = (u - r.klo) & (L - 1);
+        cw0s[it] = ctw[((unsigned)(r.klo + off0) * (unsigned)(c0 + g)) & (unsigned)(P - 1)];
+    }
     __syncthreads();
     c64 zw[PPT], zd[PPT];
     {
@@ -413,18 +435,16 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int idx = tid + it * NT64, g = idx % G, u = idx / G;
-            const unsigned col = (unsigned)(c0 + g);
             const int off0 = (u - r.klo) & (L - 1);
-            const c64 cw0 = ctw[((unsigned)(r.klo + off0) * col) & (unsigned)(P - 1)];
+            const c64 cw0 = cw0s[it];
             const c64 wf = wrapf[g];
 #pragma unroll
             for (int k = 0; k < R1; ++k) {
                 const int offu = off0 + k * STR, off = offu & (L - 1);
                 const bool in = off < r.KP;
-                const int oc = in ? off : 0;                 // unconditional, clamped loads
-                const double p = psi[oc] * invP;
-                const c64 X = xb[r.klo + oc];
-                const double mm = pxi[oc] * A.inv_dt;
+                const double p = bp[it * R1 + k] * invP;
+                const c64 X = bX[it * R1 + k];
+                const double mm = bm[it * R1 + k] * A.inv_dt;
                 c64 cw = (k == 0) ? cw0 : cmul(cw0, spow[k * G + g]);
                 if (offu >= L) cw = cmul_v(cw, wf);
                 const c64 bz = {p * X.x, p * X.y};
@@ -435,7 +455,7 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
             }
         }
     }
-    lds_ifft<L, G, R1, R2, R3>(zw, buf, A.ftw, tid);
+    lds_ifft<L, G, R1, R2, R3, false, true>(zw, buf, A.ftw, tid);      // (the buffer is untouched so far: no barrier in front)
     lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
 
     constexpr int NB = PPT / RL, STR = L / RL;
