@@ -536,7 +536,9 @@ __global__ __launch_bounds__(64 * NW) void accumulate_f64_kernel(
             const float2 z = reinterpret_cast<const float2*>(Wb)[q];
             zc[u] = z.x; zd[u] = z.y;
         } else {
-            const double2 z = reinterpret_cast<const double2*>(Wb)[q];
+            // (float64: read once, written once -- nontemporal, config 5 -1.5 ... -2 %, "r6y22")
+            typedef double ssq_d2v __attribute__((ext_vector_type(2)));
+            const ssq_d2v z = __builtin_nontemporal_load(reinterpret_cast<const ssq_d2v*>(Wb) + q);
             zc[u] = z.x; zd[u] = z.y;
         }
         kk[u] = kb[q];
@@ -569,7 +571,7 @@ __global__ __launch_bounds__(64 * NW) void accumulate_f64_kernel(
             const double re = plane[k * COLS + c], im = plane[cells + k * COLS + c];
             const size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)j);
             if constexpr (sizeof(T) == 4) reinterpret_cast<float2*>(Tb)[q] = make_float2((float)re, (float)im);
-            else reinterpret_cast<double2*>(Tb)[q] = make_double2(re, im);
+            else { typedef double ssq_d2v __attribute__((ext_vector_type(2))); __builtin_nontemporal_store(ssq_d2v{re, im}, reinterpret_cast<ssq_d2v*>(Tb) + q); }
         }
     }
 }

@@ -343,6 +343,7 @@ inline float atomicAdd(float* p, float v) { float old = *p; *p = old + v; return
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))      // (a cache hint; host movnt wants 16-byte alignment)
+#define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 // memory fences: the work-items of a workgroup are fibers of one OS thread
 #define __builtin_amdgcn_fence(order, scope, ...) ((void)0)
