@@ -571,7 +571,11 @@ __global__ __launch_bounds__(64 * NW) void accumulate_f64_kernel(
             const double re = plane[k * COLS + c], im = plane[cells + k * COLS + c];
             const size_t q = (size_t)((unsigned)k * (unsigned)n + (unsigned)j);
             if constexpr (sizeof(T) == 4) reinterpret_cast<float2*>(Tb)[q] = make_float2((float)re, (float)im);
-            else { typedef double ssq_d2v __attribute__((ext_vector_type(2))); __builtin_nontemporal_store(ssq_d2v{re, im}, reinterpret_cast<ssq_d2v*>(Tb) + q); }
+            else {
+                typedef double ssq_d2v __attribute__((ext_vector_type(2)));
+                const ssq_d2v v = {re, im};
+                __builtin_nontemporal_store(v, reinterpret_cast<ssq_d2v*>(Tb) + q);
+            }
         }
     }
 }
