@@ -221,6 +221,55 @@ print("QUAD_OK")
 
 
 @pytest.mark.parametrize('st', ['log', 'log-piecewise', 'linear'])
+def test_bin_screening_stress_float64(A, orc, st):
+    """Round 6: float64 data goes through the float32 screen too (inputs rounded to float32, an explicit bound on the
+    estimate's error; `bin_of_point(double ...)`, csrc/ssq_point_math.inl) -- the exact double map only inside the guard
+    band. 3M points that sweep the grid and both ends densely, a tenth of them placed within 1e-3 ... 1e-10 bins of the rounding
+    boundaries k + 1/2 on either side, and points whose numerator b c - a d cancels to a
+    sliver of its terms: every index must equal the CPU path's exact map."""
+    from ssqueezepy_amd.ssqueezing import ssq_grid_params
+    na, n = 300, 10000
+    rng = np.random.default_rng(321)
+    logscale = st.startswith('log')
+    if st == 'linear':
+        sf = np.linspace(1e-3, 0.5, na)
+        wt = rng.uniform(-0.02, 0.55, (na, n))
+    else:
+        sf = 0.5 * 2.0 ** (-(np.arange(na)[::-1]) / 32.0) if st == 'log' else make_ssq_freqs(na, st)
+        lo, hi = np.log2(sf[0]) - 1, np.log2(sf[-1]) + 1
+        wt = 2.0 ** rng.uniform(lo, hi, (na, n))
+    # boundary points: the grid's own half-way marks (in the map's coordinate) and their close neighbourhoods
+    kk = rng.integers(0, na - 1, (na, n // 10)).astype(np.float64)
+    # (not ON them: at k + 1/2 exactly the CPU path's own answer hangs on its libm's last bit)
+    dl = rng.choice([1e-10, -1e-10, 1e-9, -1e-9, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3],
+                    (na, n // 10))
+    t = kk + 0.5 + dl
+    if st == 'linear':
+        wb = sf[0] + t * (sf[1] - sf[0])
+    elif st == 'log':
+        wb = 2.0 ** (np.log2(sf[0]) + t * (np.log2(sf[1]) - np.log2(sf[0])))
+    else:
+        i0 = np.clip(np.floor(t).astype(int), 0, na - 2)      # (between neighbours of the piecewise grid, log-linearly)
+        fr = t - i0
+        wb = 2.0 ** (np.log2(sf[i0]) * (1 - fr) + np.log2(sf[i0 + 1]) * fr)
+    wt[:, :n // 10] = wb
+    Wx = rng.standard_normal((na, n)) + 1j * rng.standard_normal((na, n))
+    g = rng.standard_normal((na, n))
+    g[:, n // 10:n // 5] *= 1e6                                 # a large real part: the imaginary part survives a cancellation
+    dWx = Wx * (g + 2j * np.pi * wt)
+    kind, p = ssq_grid_params(sf, logscale)
+    const = np.log(2) / 32
+    for flipud in (False, True):
+        out, k = A.ssqueeze_fast(Wx, dWx, sf, const, logscale, flipud, 1e-3, get_k=True)
+        ref, kref = orc.ssqueeze(Wx, dWx, st, p, const, 1e-3, flipud, typing=NUMBA, get_k=True)
+        k = _np(k)
+        bad = np.argwhere(k != kref)
+        info = [(int(i), int(j), float(dl[i, j]) if j < n // 10 else None, int(k[i, j]), int(kref[i, j])) for i, j in bad[:12]]
+        assert np.array_equal(k, kref), (st, flipud, int((k != kref).sum()), info)
+        assert np.array_equal(_np(out), ref)
+
+
+@pytest.mark.parametrize('st', ['log', 'log-piecewise', 'linear'])
 def test_bin_screening_stress(A, orc, st):
     """float32 bin map under load: 6M points whose phase transform sweeps the whole
     grid (and beyond both ends) densely, so that many land within the float32
