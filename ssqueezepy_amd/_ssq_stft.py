@@ -18,8 +18,20 @@ from .ssqueezing import _check_ssqueezing_args, ssq_grid_params
 __all__ = ['ssq_stft', 'phase_stft']
 
 
+_SFS_CACHE = {}
+
+
 def _make_Sfs(n_rows, fs, dtype):
-    return np.linspace(0, .5 * fs, n_rows, dtype=dtype)
+    """`Sfs = linspace(0, fs/2, n_rows)` (ssqueezepy/_ssq_stft.py:103); the last few grids are kept (a call at one
+    signal per launch is host-bound: `linspace` was a quarter of its Python time). A copy is handed out: the caller
+    owns what `ssq_stft` returns."""
+    key = (int(n_rows), float(fs), str(dtype))
+    Sfs = _SFS_CACHE.get(key)
+    if Sfs is None:
+        if len(_SFS_CACHE) >= 16:
+            _SFS_CACHE.clear()
+        Sfs = _SFS_CACHE[key] = np.linspace(0, .5 * fs, n_rows, dtype=dtype)
+    return Sfs.copy()
 
 
 def ssq_stft(x, window=None, n_fft=None, win_len=None, hop_len=1, fs=None, t=None,
