@@ -54,6 +54,7 @@ struct BlockPlan {
     AnalyticFft* ana = nullptr;      // four-step kernels of ssq_cwt_tiles.hip (float32)
     int n_analytic = 0;
     bool own4096 = false;            // float32: the P = 4096 classes' spectra by block_spectra4096_kernel (one launch)
+    bool own_big = false;            // ... and short launches of P = 8192 / 16384 blocks by block_spectra_multi_kernel
     int64_t n_generic = 0;
     // exact (full-length, four-step) path for the rows the blocks cannot take
     bool exact_ok = false;

@@ -146,7 +146,9 @@ struct BlockArgs {
 // The body of one workgroup (item `item_idx` of the class's list; blockIdx.y = signal of the launch). Its LDS
 // arrays come from the caller: blockzoom_kernel sizes them for its class, blockzoom_multi_kernel -- every class
 // in ONE launch, for transforms too small to fill the GPU per class -- shares one set between the classes.
-template <int L, int G, int R1, int R2, int R3, bool LEAN>
+// NOD: the call asks for Wx alone (a plain cwt: no dWx, no w, no bin map) -- the derivative's inputs, its transform and
+// its share of the epilogue are compiled out (config 1's block rows 27 -> 17 us).
+template <int L, int G, int R1, int R2, int R3, bool LEAN, bool NOD = false>
 __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqParams& sp, int item_idx,
                                                c32* __restrict__ buf, c32* __restrict__ spow,
                                                c32* __restrict__ wrapf, c32* __restrict__ bandW,
@@ -276,7 +278,7 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
     // (twiddles requested ahead of each pass' barrier; nothing has touched `buf` before the first transform:
     // 58.9 -> 56.7 -> 56.2 us at config 2, round 5)
     lds_ifft<L, G, R1, R2, R3, true, true>(zw, buf, A.ftw, tid);
-    lds_ifft<L, G, R1, R2, R3, true>(zd, buf, A.ftw, tid);
+    if constexpr (!NOD) lds_ifft<L, G, R1, R2, R3, true>(zd, buf, A.ftw, tid);
 
     // ---- epilogue: unpad, store, phase transform, bin map
     constexpr int NB = PPT / RL, STR = L / RL;
@@ -296,7 +298,11 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
                 const int dcol = (u + k * STR) * Rp + g + (c0 - m);   // sample index inside the block - margin
                 if ((unsigned)dcol >= span) continue;               // margin or past the signal's end
                 const int j = dcol + blk * (int)cl.V;               // output column
-                if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], zd[it * RL + k], sp))
+                if constexpr (NOD) {                                 // Wx alone (rs == 1, exact, when unscaled)
+                    er.W[j] = make_float2(zw[it * RL + k].x * er.rs, zw[it * RL + k].y * er.rs);
+                    continue;
+                }
+                if (emit_point<LEAN, GRID>(er, j, zw[it * RL + k], NOD ? c32{0.f, 0.f} : zd[it * RL + k], sp))
                     pend |= 1u << (it * RL + k);
             }
         }
@@ -315,20 +321,20 @@ __device__ __forceinline__ void blockzoom_body(const BlockArgs& A, const SsqPara
 #pragma unroll
             for (int k = 0; k < RL; ++k)
                 if (low == (1u << (it * RL + k))) {
-                    W = zw[it * RL + k]; D = zd[it * RL + k]; j = jbase + (u + k * STR) * Rp + g;
+                    W = zw[it * RL + k]; D = NOD ? c32{0.f, 0.f} : zd[it * RL + k]; j = jbase + (u + k * STR) * Rp + g;
                 }
         }
         if (low) emit_point_exact(er, er.k + j, W, D, sp);
     }
 }
 
-template <int L, int G, int R1, int R2, int R3, bool LEAN>
+template <int L, int G, int R1, int R2, int R3, bool LEAN, bool NOD = false>
 __global__ __launch_bounds__(NT) void blockzoom_kernel(BlockArgs A, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     __shared__ c32 spow[R1 * G];
     __shared__ c32 wrapf[G];
     __shared__ c32 bandW[(L <= 512) ? L : 1], bandD[(L <= 512) ? L : 1];
-    blockzoom_body<L, G, R1, R2, R3, LEAN>(A, sp, (int)blockIdx.x, buf, spow, wrapf, bandW, bandD);
+    blockzoom_body<L, G, R1, R2, R3, LEAN, NOD>(A, sp, (int)blockIdx.x, buf, spow, wrapf, bandW, bandD);
 }
 
 // every class of a plan in one launch: workgroup b belongs to the class whose item range holds b
@@ -337,7 +343,7 @@ struct BlockMultiArgs {
     const int4* items[5]; const c32* ftw[5];
     int first[6];                      // first workgroup of class s; first[5] = grid size
 };
-template <bool LEAN>
+template <bool LEAN, bool NOD = false>
 __global__ __launch_bounds__(NT) void blockzoom_multi_kernel(BlockMultiArgs M, SsqParams sp) {
     __shared__ c32 buf[D_POINTS];
     __shared__ c32 spow[512];          // max R1 * G (16 x 32)
@@ -351,11 +357,11 @@ __global__ __launch_bounds__(NT) void blockzoom_multi_kernel(BlockMultiArgs M, S
     A.items = M.items[s]; A.ftw = M.ftw[s];
     const int it = b - M.first[s];
     switch (s) {
-        case 0: blockzoom_body<128, 32, 16, 8, 1, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
-        case 1: blockzoom_body<256, 16, 16, 16, 1, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
-        case 2: blockzoom_body<512, 8, 8, 8, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
-        case 3: blockzoom_body<1024, 4, 16, 8, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
-        default: blockzoom_body<2048, 2, 16, 16, 8, LEAN>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 0: blockzoom_body<128, 32, 16, 8, 1, LEAN, NOD>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 1: blockzoom_body<256, 16, 16, 16, 1, LEAN, NOD>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 2: blockzoom_body<512, 8, 8, 8, 8, LEAN, NOD>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        case 3: blockzoom_body<1024, 4, 16, 8, 8, LEAN, NOD>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
+        default: blockzoom_body<2048, 2, 16, 16, 8, LEAN, NOD>(A, sp, it, buf, spow, wrapf, bandW, bandD); break;
     }
 }
 
@@ -744,6 +750,7 @@ __global__ __launch_bounds__(256) void analytic_spectrum_kernel(const C* __restr
 //   X_a[k] = (Z'[P-k] + conj Z'[k]) / 2,   X_b[k] = (Z'[P-k] - conj Z'[k]) / 2i,   k <= P / 2;   analytic: X[k] = Z'[P-k].
 struct BlockSpecArgs {
     const float* xp; const c32* xa; c32* xb;
+    const c32* xh;                     // the padded signals' half spectra (block_spectra_multi_kernel: a class with P = M)
     const BlockClassDev* classes; const c32* ctw;
     int64_t M, n1;
     int cls[8]; int first[9];          // classes served, first workgroup of each (first[n]: the grid's x size)
@@ -792,12 +799,177 @@ __global__ __launch_bounds__(NT) void block_spectra4096_kernel(BlockSpecArgs A) 
     }
 }
 
+// ---- block spectra of the P = 4096 / 8192 / 16384 classes in ONE launch (float32; small calls, round 6) ---------
+// A short signal's plan (config 1: N = 10 000, M = 16 384) has classes of P = 8192 and 16 384 next to the P = 4096
+// ones, and their spectra went gather kernel -> rocFFT's two-kernel transforms -> real-to-complex post-processing, six
+// launches of 3-7 us in a row on a call of 0.1 ms. Here one launch serves every class. A workgroup has 256 QMAX
+// threads (QMAX = the longest block / 4096 = 2 or 4) and runs CW = 4 QMAX columns of 1024 points through lds_ifft at
+// once (16 points per thread as everywhere; 8 and 16 columns keep the passes' LDS accesses nearly conflict-free, which
+// one column of 4096 points is far from): a block of P = 1024 C points is its C interleaved sub-sequences y[j C + r]
+// (the class' e^{2 pi i q / P} table read at every C-th entry), so a workgroup holds CW / C blocks ("slots": pairs of
+// real blocks as one complex sequence, or one analytic block, as above), and the last radix-C step
+//   Y'[f + 1024 s] = sum_r e^{2 pi i r f / P} e^{2 pi i r s / C} Z'_r[f]
+// goes through LDS (the C terms of an f sit in C different lanes). LDS: 32 QMAX KB (static; gfx950: 160 KB).
+// Latency, not throughput, is what this kernel is for: BlockPlan::spectra uses it when the launch is at most a couple
+// of workgroups per CU and leaves long batches of P > 4096 blocks to gather + rocFFT.
+constexpr int WIDE_L = 1024;
+// the columns' transform: radices 16 x 8 x 8; entry z[k] = column g's point u + 64 k (g = tid % CW, u = tid / CW);
+// exit z[8 it + k] = its output u' + 128 k, u' = (tid + it NTH) / CW. Its twiddles e^{2 pi i q / 1024} come from an
+// 8 KB table in LDS (wide_stage_tw: every C-th entry of the class' table, one coalesced read at the kernel's start) --
+// a lone workgroup with cold caches pays a trip to memory for every dependent table read, and there were two per transform.
+template <int CW, int C>
+__device__ __forceinline__ void wide_stage_tw(c32* __restrict__ stw, const c32* __restrict__ tw, int tid) {
+#pragma unroll
+    for (int i = tid; i < WIDE_L; i += 64 * CW) stw[i] = tw[i * C];
+}
+template <int CW>
+__device__ __forceinline__ void wide_ifft(c32 (&z)[PPT], c32* __restrict__ buf, const c32* __restrict__ stw, int tid) {
+    lds_ifft<WIDE_L, CW, 16, 8, 8, false, false, 1, 64 * CW>(z, buf, stw, tid);   // (its first barrier: stw is in place)
+}
+// the last step's twiddles e^{2 pi i r f / P} of a thread's (slot, f) pairs: asked for at the kernel's start
+template <int CW, int C>
+__device__ __forceinline__ void wide_load_w(c32 (&w)[PPT / C][C], const c32* __restrict__ tw, int tid) {
+#pragma unroll
+    for (int i = 0; i < PPT / C; ++i) {
+        const int f = (tid + i * 64 * CW) % WIDE_L;
+        w[i][0] = {1.f, 0.f};
+#pragma unroll
+        for (int r = 1; r < C; ++r) w[i][r] = tw[r * f];
+    }
+}
+// wide_natural: the transforms' outputs -> buf[slot P + n] = Y'_slot[n] in natural order, behind a barrier.
+// In between, Z'_r[n] sits at [slot][r][(n + 4 r) mod 1024]: the rotation keeps both the writes (a wavefront's lanes
+// differ in r first) and the reads (consecutive n) off each other's banks.
+template <int CW, int C>
+__device__ __forceinline__ void wide_natural(const c32 (&z)[PPT], c32* __restrict__ buf, const c32 (&w)[PPT / C][C], int tid) {
+    constexpr int L = WIDE_L, P = L * C, NTH = 64 * CW, SL = CW / C;
+    constexpr int NI = PPT / C;                                  // (slot, f) pairs per thread
+    __syncthreads();                                             // (the last pass' reads)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * NTH, g = idx % CW, u = idx / CW, slot = g / C, r = g % C;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) buf[slot * P + r * L + ((u + k * (L / 8) + 4 * r) & (L - 1))] = z[it * 8 + k];
+    }
+    __syncthreads();
+    c32 y[NI][C];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * NTH, sl = e / L, f = e % L;
+#pragma unroll
+        for (int r = 0; r < C; ++r) {
+            const c32 v = buf[sl * P + r * L + ((f + 4 * r) & (L - 1))];
+            y[i][r] = r ? cmul_v(v, w[i][r]) : v;
+        }
+        Dft<C>::run(y[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * NTH, sl = e / L, f = e % L;
+#pragma unroll
+        for (int s2 = 0; s2 < C; ++s2) buf[sl * P + f + s2 * L] = y[i][s2];
+    }
+    __syncthreads();
+    (void)SL;
+}
+template <int CW, int C>
+__device__ __forceinline__ void block_spectra_wide(const BlockSpecArgs& A, const BlockClassDev& k, int b, c32* __restrict__ buf,
+                                                   c32* __restrict__ stw) {
+    constexpr int L = WIDE_L, P = L * C, NTH = 64 * CW, SL = CW / C;
+    const int tid = threadIdx.x;
+    const int g = tid % CW, u = tid / CW, slot = g / C, r = g % C;
+    const int64_t sig = blockIdx.y, M = A.M;
+    const bool ana = k.analytic != 0;
+    const int nunits = ana ? (int)k.nb : ((int)k.nb + 1) / 2;     // a unit: one analytic block or a pair of real ones
+    const c32* __restrict__ tw = A.ctw + k.ctw_off;              // e^{2 pi i q / P}
+    const c32* __restrict__ xa = A.xa + sig * M;
+    const float* __restrict__ xp = A.xp + sig * M;
+    const int64_t lead = A.n1 - k.m;
+    const int m32 = (int)M;
+    wide_stage_tw<CW, C>(stw, tw, tid);
+    c32 w[PPT / C][C];
+    wide_load_w<CW, C>(w, tw, tid);
+    c32 z[PPT];
+    {
+        const int unit = b * SL + slot;
+        const bool live = unit < nunits;
+        const int b0 = ana ? unit : 2 * unit, b1 = b0 + 1;
+        const bool two = !ana && b1 < (int)k.nb;
+        // first sample of each block in the periodic padded signal, reduced once (P <= M: one wrap at most per point)
+        int64_t o0 = (lead + (int64_t)b0 * k.V) % M; if (o0 < 0) o0 += M;
+        int64_t o1 = (lead + (int64_t)b1 * k.V) % M; if (o1 < 0) o1 += M;
+        const int a0 = (int)o0, a1 = (int)o1;
+#pragma unroll
+        for (int t = 0; t < PPT; ++t) {
+            const int p = (u + t * (L / 16)) * C + r;
+            int s0 = a0 + p; if (s0 >= m32) s0 -= m32;
+            int s1 = a1 + p; if (s1 >= m32) s1 -= m32;
+            c32 v = {0.f, 0.f};
+            if (live) {
+                if (ana) v = xa[s0];
+                else v = {xp[s0], two ? xp[s1] : 0.f};
+            }
+            z[t] = v;
+        }
+    }
+    wide_ifft<CW>(z, buf, stw, tid);
+    wide_natural<CW, C>(z, buf, w, tid);
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+        const int unit = b * SL + sl;
+        if (unit >= nunits) break;
+        const int b0 = ana ? unit : 2 * unit;
+        const bool two = !ana && b0 + 1 < (int)k.nb;
+        const c32* __restrict__ Y = buf + sl * P;
+        c32* out0 = A.xb + k.xb_off + (sig * k.nb + b0) * k.xb_stride;
+        if (ana) {
+            for (int f = tid; f < P; f += NTH) out0[f] = Y[(P - f) & (P - 1)];
+        } else {
+            c32* out1 = out0 + k.xb_stride;
+            for (int f = tid; f <= P / 2; f += NTH) {
+                const c32 Pk = Y[f], Qk = Y[(P - f) & (P - 1)];
+                out0[f] = {0.5f * (Qk.x + Pk.x), 0.5f * (Qk.y - Pk.y)};
+                if (two) out1[f] = {0.5f * (Qk.y + Pk.y), 0.5f * (Pk.x - Qk.x)};
+            }
+        }
+    }
+}
+template <int QMAX>
+__global__ __launch_bounds__(NT * QMAX) void block_spectra_multi_kernel(BlockSpecArgs A) {
+    __shared__ c32 buf[4096 * QMAX];               // 64 / 128 KB
+    __shared__ c32 stw[WIDE_L];
+    int b = (int)blockIdx.x, c = 0;
+    while (c + 1 < A.ncls && b >= A.first[c + 1]) ++c;
+    b -= A.first[c];
+    const BlockClassDev k = A.classes[A.cls[c]];
+    if (k.P == A.M && k.nb == 1 && !k.analytic && A.xh) {
+        // one block = the whole periodic signal from sample o on: its spectrum is the signal's own, already there,
+        // turned: X_b[k] = xh[k] e^{2 pi i k o / M} -- no transform (config 1's widest class; such a class has one block,
+        // and a 16 384-point transform in one workgroup was the launch's longest chain)
+        const int64_t M = A.M, sig = blockIdx.y;
+        int64_t o = (A.n1 - k.m) % M; if (o < 0) o += M;
+        const c32* __restrict__ tw = A.ctw + k.ctw_off;          // e^{2 pi i q / M}
+        const c32* __restrict__ xh = A.xh + sig * (M / 2 + 1);
+        c32* __restrict__ out0 = A.xb + k.xb_off + sig * k.nb * k.xb_stride;
+        const unsigned mask = (unsigned)M - 1u, ou = (unsigned)o;
+        for (int f = (int)threadIdx.x; f <= (int)(M / 2); f += NT * QMAX)
+            out0[f] = cmul_v(xh[f], tw[((unsigned)f * ou) & mask]);
+        return;
+    }
+    if (k.P == 4096) block_spectra_wide<4 * QMAX, 4>(A, k, b, buf, stw);
+    else if (k.P == 8192) block_spectra_wide<4 * QMAX, 8>(A, k, b, buf, stw);
+    else if constexpr (QMAX >= 4) block_spectra_wide<4 * QMAX, 16>(A, k, b, buf, stw);
+}
+
 template <int L, int G, int R1, int R2, int R3>
 static int launch_zoom(const BlockArgs& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
     const dim3 grid((unsigned)A.n_items, (unsigned)nsig);
     if (A.kidx && !A.dWx && !A.w && !A.row_scale)
         hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, true>), grid, dim3(NT), 0, stream, A, sp);
+    else if (!A.kidx && !A.dWx && !A.w)            // Wx alone
+        hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, false, true>), grid, dim3(NT), 0, stream, A, sp);
     else
         hipLaunchKernelGGL((blockzoom_kernel<L, G, R1, R2, R3, false>), grid, dim3(NT), 0, stream, A, sp);
     SSQ_LAUNCH_CHECK();
@@ -875,10 +1047,16 @@ int BlockPlan::create(const ssq_cwt_blocks_desc& d, int dtype_, int64_t M_, int6
     n_generic = d.n_generic;
     // (SSQ_DEBUG_BLOCK_SPECTRA=rocfft: every class through gather + rocFFT, as in rounds 1-4)
     own4096 = dtype == SSQ_F32 && M > 4096 && !(getenv("SSQ_DEBUG_BLOCK_SPECTRA") && !strcmp(getenv("SSQ_DEBUG_BLOCK_SPECTRA"), "rocfft"));
+    // (SSQ_DEBUG_BLOCK_SPECTRA=4096: the one-launch kernel for the P = 4096 classes only, as until round 6's second half)
+    own_big = own4096 && !(getenv("SSQ_DEBUG_BLOCK_SPECTRA") && !strcmp(getenv("SSQ_DEBUG_BLOCK_SPECTRA"), "4096"));
     {   // the CU count of the device the plan lives on (the multi-class launch asks how full a launch is)
         int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+        bool lds128 = false;                       // (block_spectra_multi_kernel<4>: 128 KB of LDS; gfx950 has 160 KB)
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) {
             ncu = pr.multiProcessorCount;
+            lds128 = (size_t)pr.maxSharedMemoryPerMultiProcessor >= 128 * 1024;
+        }
+        own_big = own_big && lds128;
     }
     return 0;
 }
@@ -904,6 +1082,8 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
     bool any_analytic = false;
     BlockSpecArgs S;
     S.ncls = 0; S.first[0] = 0;
+    int qmax = 1;                                  // longest block the own kernel serves, in units of 4096
+    bool prefix[2] = {true, true};
     for (size_t f = 0; f < ffts.size(); ++f) {
         const int a = fft_first[f], b = f + 1 < ffts.size() ? fft_first[f + 1] : nc;
         bool on = !need;
@@ -911,18 +1091,32 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
         const int kind = (int)hcls[a].analytic;
         any_analytic = any_analytic || (on && kind);
         int wanted = 0;                            // (classes of this group the kernel's 8 slots would have to take)
-        for (int c = a; c < b; ++c) wanted += (need && !need[c]) ? 0 : 1;
-        if (on && own4096 && hcls[a].P == 4096 && S.ncls + wanted <= 8) {     // (a ninth: gather + rocFFT, as for other P)
+        int64_t group_wgs = 0;
+        for (int c = a; c < b; ++c) {
+            if (need && !need[c]) continue;
+            ++wanted;
+            group_wgs += kind ? hcls[c].nb : (hcls[c].nb + 1) / 2;
+        }
+        // P = 4096: always the library's own kernel; P = 8192 / 16384: the one-launch kernel when the launch is small
+        // (a call bound by its launches), gather + rocFFT for long batches of such blocks
+        const int64_t Pg = hcls[a].P;
+        const bool small = (Pg == 8192 || Pg == 16384) && own_big && Pg <= M && M < ((int64_t)1 << 30) &&
+                           group_wgs * max_batch <= 2 * (int64_t)ncu;
+        // (the classes the kernel takes are a prefix of their kind: the gather launch below covers ONE class range per kind,
+        // and for the analytic kind it writes into the spectra's own storage)
+        if (on && own4096 && prefix[kind] && (Pg == 4096 || small) && S.ncls + wanted <= 8) {     // (a ninth: gather + rocFFT, as for other P)
             for (int c = a; c < b; ++c) {
                 if (need && !need[c]) continue;
-                S.cls[S.ncls] = c;
-                const int64_t wgs = kind ? hcls[c].nb : (hcls[c].nb + 1) / 2;
-                S.first[S.ncls + 1] = S.first[S.ncls] + (int)wgs;
-                ++S.ncls;
+                S.cls[S.ncls++] = c;
+                // (a single block as long as the signal takes no transform -- the kernel turns the signal's own spectrum --
+                // and does not ask for the wider workgroup)
+                const bool twist = Pg == M && hcls[c].nb == 1 && !kind && xh;
+                qmax = std::max(qmax, twist ? 2 : (int)(Pg / 4096));      // (the P = 4096-only kernel knows neither)
             }
             on = false;                            // (not through gather + rocFFT)
         }
         run_on[f] = on;
+        if (on) prefix[kind] = false;
         if (on) { lo[kind] = std::min(lo[kind], a); hi[kind] = std::max(hi[kind], b - 1); }
     }
     const size_t rs = dtype == SSQ_F32 ? 4 : 8;
@@ -944,10 +1138,23 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
         }
     }
     if (S.ncls) {
-        S.xp = (const float*)xp; S.xa = (const c32*)xa; S.xb = (c32*)xb;
+        S.xp = (const float*)xp; S.xa = (const c32*)xa; S.xb = (c32*)xb; S.xh = (const c32*)xh;
         S.classes = classes; S.ctw = (const c32*)ctw; S.M = M; S.n1 = n1;
-        hipLaunchKernelGGL(block_spectra4096_kernel, dim3((unsigned)S.first[S.ncls], (unsigned)max_batch), dim3(NT), 0,
-                           stream, S);
+        // a workgroup of the wide kernel holds qmax / (P / 4096) units of a class (a unit: a pair of real blocks or one
+        // analytic block); the P = 4096-only kernel one
+        for (int i = 0; i < S.ncls; ++i) {
+            const BlockClassDev& k = hcls[S.cls[i]];
+            const int64_t units = k.analytic ? k.nb : (k.nb + 1) / 2;
+            const int64_t per = std::max<int64_t>(1, qmax / (k.P / 4096));
+            S.first[i + 1] = S.first[i] + (int)((units + per - 1) / per);
+        }
+        const dim3 sg((unsigned)S.first[S.ncls], (unsigned)max_batch);
+        if (qmax == 1)
+            hipLaunchKernelGGL(block_spectra4096_kernel, sg, dim3(NT), 0, stream, S);
+        else if (qmax == 2)
+            hipLaunchKernelGGL(block_spectra_multi_kernel<2>, sg, dim3(NT * 2), 0, stream, S);
+        else
+            hipLaunchKernelGGL(block_spectra_multi_kernel<4>, sg, dim3(NT * 4), 0, stream, S);
         SSQ_LAUNCH_CHECK();
     }
     for (int kind = 0; kind < 2; ++kind) {
@@ -1026,6 +1233,8 @@ int BlockPlan::run(int sig, int nsig, float* Wx, float* dWx, float* w, unsigned 
             const dim3 grid((unsigned)total, (unsigned)nsig);
             if (lean)
                 hipLaunchKernelGGL((blockzoom_multi_kernel<true>), grid, dim3(NT), 0, stream, Mx, sp);
+            else if (!Mx.A.kidx && !Mx.A.dWx && !Mx.A.w)   // Wx alone
+                hipLaunchKernelGGL((blockzoom_multi_kernel<false, true>), grid, dim3(NT), 0, stream, Mx, sp);
             else
                 hipLaunchKernelGGL((blockzoom_multi_kernel<false>), grid, dim3(NT), 0, stream, Mx, sp);
             SSQ_LAUNCH_CHECK();

@@ -107,12 +107,14 @@ constexpr int NT = FftGeom<float>::NT;          //                  256 threads
 // EARLY_TW (float32): the twiddles of passes 2 and 3 are requested before the barrier in front of the pass instead of
 // after its LDS reads -- the table reads' latency runs under the barrier (block rows 58.9 -> 56.7 us at config 2; no
 // change for the intermediates' kernels, which wait on HBM). FRESH: `buf` holds nothing a wavefront may still be
-// reading (a kernel's first transform): no barrier before pass 1.
-template <int L, int G, int R1, int R2, int R3, bool EARLY_TW = false, bool FRESH = false, typename R>
+// reading (a kernel's first transform): no barrier before pass 1. TWS: the twiddle table is e^{2 pi i q / (L TWS)} --
+// a longer transform's table read at every TWS-th entry (the sub-transforms of block_spectra_multi_kernel). NTH: the
+// workgroup's thread count when it is not the geometry's 256 / 128 (16 points per thread all the same).
+template <int L, int G, int R1, int R2, int R3, bool EARLY_TW = false, bool FRESH = false, int TWS = 1, int NTH = 0, typename R>
 __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ buf,
                                          const cx<R>* __restrict__ ftw, int tid) {
-    constexpr int NT = FftGeom<R>::NT;
-    static_assert(L * G == FftGeom<R>::D, "L * G must fill the workgroup");
+    constexpr int NT = NTH ? NTH : FftGeom<R>::NT;
+    static_assert(L * G == NT * PPT, "L * G must fill the workgroup");
     constexpr bool three = (R3 > 1);
     constexpr bool ETW = EARLY_TW && sizeof(R) == 4;
     if constexpr (!FRESH) __syncthreads();         // LDS free (previous transform's reads done)
@@ -137,7 +139,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
         for (int it = 0; it < NB; ++it) {
             const int kk = ((tid + it * NT) / G) % Ns;
 #pragma unroll
-            for (int k = 1; k < R2; ++k) tw2[it][k] = ftw[kk * k * TW];
+            for (int k = 1; k < R2; ++k) tw2[it][k] = ftw[kk * k * TW * TWS];
         }
     }
     __syncthreads();
@@ -158,7 +160,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             int kk = u % Ns;
             constexpr int TW = L / (Ns * R2);
 #pragma unroll
-            for (int k = 1; k < R2; ++k) t[it][k] = cmul_v(t[it][k], ETW ? tw2[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k * TW]);
+            for (int k = 1; k < R2; ++k) t[it][k] = cmul_v(t[it][k], ETW ? tw2[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k * TW * TWS]);
             Dft<R2>::run(t[it]);
             if (three) {
                 int j0 = (u / Ns) * Ns * R2 + kk;
@@ -177,7 +179,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             for (int it = 0; it < PPT / R3; ++it) {
                 const int kk = ((tid + it * NT) / G) % (R1 * R2);
 #pragma unroll
-                for (int k = 1; k < R3; ++k) tw3[it][k] = ftw[kk * k];
+                for (int k = 1; k < R3; ++k) tw3[it][k] = ftw[kk * k * TWS];
             }
         }
         __syncthreads();
@@ -190,7 +192,7 @@ __device__ __forceinline__ void lds_ifft(cx<R> (&v)[PPT], cx<R>* __restrict__ bu
             for (int k = 0; k < R3; ++k) t[k] = buf[(u + k * STR) * G + g];
             int kk = u % Ns;                       // == u (Ns*R3 == L)
 #pragma unroll
-            for (int k = 1; k < R3; ++k) t[k] = cmul_v(t[k], ETW ? tw3[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k]);
+            for (int k = 1; k < R3; ++k) t[k] = cmul_v(t[k], ETW ? tw3[ETW ? it : 0][ETW ? k : 0] : ftw[kk * k * TWS]);
             Dft<R3>::run(t);
 #pragma unroll
             for (int k = 0; k < R3; ++k) v[it * R3 + k] = t[k];

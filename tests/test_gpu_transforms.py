@@ -339,6 +339,52 @@ def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, mo
     _cwt.clear_plan_cache()
 
 
+@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric')])
+def test_short_signal_prestage_and_spectra_in_one_launch(S, orc, N, padtype, monkeypatch):
+    """Short float32 signals (M = 8192 / 16384; BASELINE config 1's shape): `small_prestage_kernel` (pad + forward
+    transform + analytic signal, one workgroup per signal) and `block_spectra_multi_kernel` (the P = 4096 / 8192 /
+    16384 classes' spectra in one launch) against the routes they replace (pad kernel + rocFFT + four-step analytic
+    signal + gather + rocFFT: SSQ_DEBUG_BLOCK_SPECTRA=rocfft), against the oracle of the reference's full-length
+    algorithm, and a batch (one workgroup per signal) against its signals one at a time."""
+    from ssqueezepy_amd import _cwt
+    nv = 8
+    x = two_chirps(N, seed=N).astype(np.float32)
+    wav = S.Wavelet(('gmw', {'dtype': 'float32'}))
+    out = {}
+    for mode in ('', 'rocfft'):
+        if mode:
+            monkeypatch.setenv('SSQ_DEBUG_BLOCK_SPECTRA', mode)
+        else:
+            monkeypatch.delenv('SSQ_DEBUG_BLOCK_SPECTRA', raising=False)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, padtype=padtype, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan.algo.startswith('blockzoom')
+        assert plan.block_plan['classes'][:, 0].max() >= 8192     # (a class the P = 4096-only kernel does not serve)
+        out[mode] = (Wx, dWx, Tx)
+    monkeypatch.delenv('SSQ_DEBUG_BLOCK_SPECTRA', raising=False)
+    _cwt.clear_plan_cache()
+    eW, eD = relmax(out[''][0], out['rocfft'][0]), relmax(out[''][1], out['rocfft'][1])
+    assert eW <= 2e-6 and eD <= 2e-6, (eW, eD)
+    # a plain cwt (Wx alone: the block kernels' instantiation without the derivative) gives the Wx of a cwt with its
+    # derivative, bit for bit
+    Wc = S.cwt(x, wav, scales='log', nv=nv, padtype=padtype, astensor=False)[0]
+    Wd, _, dWd = S.cwt(x, wav, scales='log', nv=nv, padtype=padtype, derivative=True, astensor=False)
+    assert np.array_equal(Wc, Wd)
+    assert relmax(Wd, out[''][0]) <= 5e-6 and relmax(dWd, out[''][1]) <= 5e-6      # (ssq_cwt's rows come from the tile kernel)
+    if padtype == 'reflect':
+        r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv, typing=1)
+        eW, eD = relmax(out[''][0], r['Wx']), relmax(out[''][1], r['dWx'])
+        assert eW <= 1e-5 and eD <= 1e-5, (eW, eD)
+        check_Tx(orc, out[''][2], out[''][0], out[''][1], r, 'float32')
+    xb = np.stack([x, x[::-1].copy(), 0.5 * x])
+    Wxb = S.cwt(xb, wav, scales='log', nv=nv, padtype=padtype, astensor=False)[0]
+    for i in range(3):
+        Wi = S.cwt(xb[i], wav, scales='log', nv=nv, padtype=padtype, astensor=False)[0]
+        assert np.array_equal(Wxb[i], Wi)
+    _cwt.clear_plan_cache()
+
+
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
 @pytest.mark.parametrize('N,nv', [(6000, 16), (20000, 8), (40000, 4)])
 def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):

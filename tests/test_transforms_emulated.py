@@ -412,3 +412,39 @@ def test_pair_kernel_equals_single_column_kernel_emulated(monkeypatch):
             assert np.array_equal(out['1'][1], out['0'][1]) and np.array_equal(out['1'][2], out['0'][2]), N
             assert_tx_repeat(out['1'][0], out['0'][0], what=N)
         _cwt.clear_plan_cache()
+
+
+@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric')])
+def test_short_signal_prestage_and_spectra_in_one_launch_emulated(S, orc, N, padtype, monkeypatch):
+    """Short float32 signals (M = 8192 / 16384): `small_prestage_kernel` (pad + forward transform + analytic signal in
+    one workgroup per signal) and `block_spectra_multi_kernel` (the P = 4096 / 8192 / 16384 classes' spectra in one
+    launch) against the routes they replace (pad kernel, rocFFT, four-step analytic signal, gather + rocFFT:
+    SSQ_DEBUG_BLOCK_SPECTRA=rocfft) and against the oracle of the reference's full-length algorithm."""
+    from ssqueezepy_amd import _cwt
+    nv = 8
+    x = two_chirps(N, seed=N).astype(np.float32)
+    wav = S.Wavelet(('gmw', {'dtype': 'float32'}))
+    out = {}
+    for mode in ('', 'rocfft'):
+        if mode:
+            monkeypatch.setenv('SSQ_DEBUG_BLOCK_SPECTRA', mode)
+        else:
+            monkeypatch.delenv('SSQ_DEBUG_BLOCK_SPECTRA', raising=False)
+        _cwt.clear_plan_cache()
+        Tx, Wx, sf, sc, dWx = S.ssq_cwt(x, wav, scales='log', nv=nv, padtype=padtype, get_dWx=True, astensor=False)
+        plan = next(iter(_cwt._PLAN_CACHE.values()))
+        assert plan.algo.startswith('blockzoom')
+        P = plan.block_plan['classes'][:, 0]
+        assert P.max() >= 8192, P                     # (a class the P = 4096-only kernel does not serve)
+        out[mode] = (Wx, dWx)
+    _cwt.clear_plan_cache()
+    assert relmax(out[''][0], out['rocfft'][0]) <= 2e-6 and relmax(out[''][1], out['rocfft'][1]) <= 2e-6
+    # a plain cwt (Wx alone: the block kernels' instantiation without the derivative) gives the Wx of a cwt with its
+    # derivative, bit for bit
+    Wc = S.cwt(x, wav, scales='log', nv=nv, padtype=padtype, astensor=False)[0]
+    Wd, _, dWd = S.cwt(x, wav, scales='log', nv=nv, padtype=padtype, derivative=True, astensor=False)
+    assert np.array_equal(Wc, Wd)
+    assert relmax(Wd, out[''][0]) <= 5e-6 and relmax(dWd, out[''][1]) <= 5e-6      # (ssq_cwt's rows come from the tile kernel)
+    if padtype == 'reflect':
+        r = oracle_ssq_cwt(orc, x, 'float32', scales='log', nv=nv, typing=1)
+        assert relmax(out[''][0], r['Wx']) <= 1e-5 and relmax(out[''][1], r['dWx']) <= 1e-5
