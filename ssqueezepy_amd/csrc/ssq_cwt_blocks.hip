@@ -382,7 +382,8 @@ struct BlockArgs64 {
 
 // (two wavefronts per SIMD: left alone the compiler takes 276-280 registers -- one wavefront per SIMD -- and config 5's
 // block rows run at 10.5 ms instead of 8.1; at 256 it spills ~90 bytes per lane)
-template <int L, int G, int R1, int R2, int R3>
+// NOD: Wx alone (a plain cwt), as for the float32 kernels: the derivative's transform and outputs compiled out.
+template <int L, int G, int R1, int R2, int R3, bool NOD = false>
 __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void blockzoom_f64_kernel(BlockArgs64 A, SsqParams sp) {
     constexpr int NT64 = FftGeom<double>::NT;
     __shared__ c64 buf[FftGeom<double>::D];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
         }
     }
     lds_ifft<L, G, R1, R2, R3, false, true>(zw, buf, A.ftw, tid);      // (the buffer is untouched so far: no barrier in front)
-    lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
+    if constexpr (!NOD) lds_ifft<L, G, R1, R2, R3>(zd, buf, A.ftw, tid);
 
     constexpr int NB = PPT / RL, STR = L / RL;
     const int64_t base = ((int64_t)sig * A.na + row) * A.N;
@@ -482,9 +483,10 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
             const int dcol = (u + k * STR) * Rp + g + (c0 - m);
             if ((unsigned)dcol >= span) continue;
             const int j = dcol + blk * (int)cl.V;
-            const c64 W = zw[it * RL + k], D = zd[it * RL + k];
+            const c64 W = zw[it * RL + k], D = NOD ? c64{0.0, 0.0} : zd[it * RL + k];
             const double c = W.x * rs, d = W.y * rs, a = D.x * rs, b = D.y * rs;
             Wo[j] = make_double2(c, d);
+            if constexpr (NOD) continue;
             if (Do) Do[j] = make_double2(a, b);
             if (wo) wo[j] = mag_lt(c, d, A.gamma) ? (double)INFINITY : fabs(phase_ratio(a, b, c, d));
             if (ko) {
@@ -502,6 +504,10 @@ __global__ __launch_bounds__(FftGeom<double>::NT) SSQ_WAVES_PER_EU(2, 2) void bl
 template <int L, int G, int R1, int R2, int R3>
 static int launch_zoom64(const BlockArgs64& A, const SsqParams& sp, int nsig, hipStream_t stream) {
     if (A.n_items == 0) return 0;
+    if (!A.dWx && !A.w && !A.kidx)                 // Wx alone
+        hipLaunchKernelGGL((blockzoom_f64_kernel<L, G, R1, R2, R3, true>), dim3((unsigned)A.n_items, (unsigned)nsig),
+                           dim3(FftGeom<double>::NT), 0, stream, A, sp);
+    else
     hipLaunchKernelGGL((blockzoom_f64_kernel<L, G, R1, R2, R3>), dim3((unsigned)A.n_items, (unsigned)nsig),
                        dim3(FftGeom<double>::NT), 0, stream, A, sp);
     SSQ_LAUNCH_CHECK();

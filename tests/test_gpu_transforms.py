@@ -425,6 +425,10 @@ def test_block_fast_path_vs_oracle(S, orc, N, nv, dtype):
     out = S.ssq_cwt(x, wav, scales='log', nv=nv, get_w=True, get_dWx=True, astensor=False)
     assert np.array_equal(out[4], orc.phase_cwt(out[1], out[5], r['gamma'], typing=0))
     assert relmax(out[1], Wx) <= tol / 2      # two-step form: every row on the block kernels
+    # a plain cwt runs the kernels' Wx-only instantiation (no derivative transform): the same Wx, bit for bit
+    Wc = S.cwt(x, wav, scales='log', nv=nv, astensor=False)[0]
+    Wd = S.cwt(x, wav, scales='log', nv=nv, derivative=True, astensor=False)[0]
+    assert np.array_equal(Wc, Wd) and relmax(Wc, r['Wx']) <= tol
     xb = np.stack([x, x[::-1].copy()])
     Txb, Wxb, *_ = S.ssq_cwt(xb, wav, scales='log', nv=nv, astensor=False)
     assert np.array_equal(Wxb[0], Wx)

@@ -75,6 +75,10 @@ def test_block_kernels_vs_oracle(S, orc, dtype):
     from conftest import assert_tx_repeat
     assert np.array_equal(Wx2, Wx)
     assert_tx_repeat(Tx2, Tx)
+    # a plain cwt runs the kernels' Wx-only instantiation (no derivative transform): the same Wx, bit for bit
+    Wc = S.cwt(x, wav, scales='log', nv=nv, astensor=False)[0]
+    Wd = S.cwt(x, wav, scales='log', nv=nv, derivative=True, astensor=False)[0]
+    assert np.array_equal(Wc, Wd) and relmax(Wc, r['Wx']) <= RTOL[dtype]
     _cwt.clear_plan_cache()
 
 
