@@ -50,6 +50,9 @@ rm -rf $O/prof_h1
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/prof_c5 -o c5 -- python tools/run_configs.py c5 > $O/prof_c5.log 2>&1
 DB=$(find $O/prof_c5 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/prof_summary.py $DB $O/kernel_stats_c5.txt | head -6 | cut -c1-160
 rm -rf $O/prof_c5
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o c1 -- python tools/run_configs.py c1 > $O/prof_c1.log 2>&1
+DB=$(find $O/prof_c1 -name "*_results.db" | head -1); [ -n "$DB" ] && python tools/prof_summary.py $DB $O/kernel_stats_c1.txt | head -6 | cut -c1-160
+rm -rf $O/prof_c1
 bash tools/pmc_cmd.sh $O/pmc_c3 python tools/probes/c3_batched_probe.py 512 > $O/pmc_c3.log 2>&1
 python tools/pmc_summary.py $O/pmc_c3 > $O/pmc_summary_c3.txt 2>&1; rm -rf $O/pmc_c3/*/
 # 6. the GPU suite in the other two modes, and the randomised sweep (MODES=0 skips)
