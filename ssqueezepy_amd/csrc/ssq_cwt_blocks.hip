@@ -1106,8 +1106,10 @@ int BlockPlan::spectra(const void* xp, const void* xh, int64_t batch, hipStream_
         // P = 4096: always the library's own kernel; P = 8192 / 16384: the one-launch kernel when the launch is small
         // (a call bound by its launches), gather + rocFFT for long batches of such blocks
         const int64_t Pg = hcls[a].P;
-        const bool small = (Pg == 8192 || Pg == 16384) && own_big && Pg <= M && M < ((int64_t)1 << 30) &&
-                           group_wgs * max_batch <= 2 * (int64_t)ncu;
+        bool whole = Pg == M && !kind && xh;       // blocks as long as the signal, one per signal: no transform at all
+        for (int c = a; c < b && whole; ++c) whole = hcls[c].nb == 1;
+        const bool small = own_big && M < ((int64_t)1 << 30) && group_wgs * max_batch <= 2 * (int64_t)ncu &&
+                           (whole || ((Pg == 8192 || Pg == 16384) && Pg <= M));
         // (the classes the kernel takes are a prefix of their kind: the gather launch below covers ONE class range per kind,
         // and for the analytic kind it writes into the spectra's own storage)
         if (on && own4096 && prefix[kind] && (Pg == 4096 || small) && S.ncls + wanted <= 8) {     // (a ninth: gather + rocFFT, as for other P)

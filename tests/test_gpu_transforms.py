@@ -339,7 +339,7 @@ def test_nyquist_rows_continued_vs_exact_paths(S, orc, N, nv, wavelet, dtype, mo
     _cwt.clear_plan_cache()
 
 
-@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric')])
+@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric'), (20000, 'reflect')])
 def test_short_signal_prestage_and_spectra_in_one_launch(S, orc, N, padtype, monkeypatch):
     """Short float32 signals (M = 8192 / 16384; BASELINE config 1's shape): `small_prestage_kernel` (pad + forward
     transform + analytic signal, one workgroup per signal) and `block_spectra_multi_kernel` (the P = 4096 / 8192 /

@@ -418,7 +418,7 @@ def test_pair_kernel_equals_single_column_kernel_emulated(monkeypatch):
         _cwt.clear_plan_cache()
 
 
-@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric')])
+@pytest.mark.parametrize('N,padtype', [(3000, 'reflect'), (10000, 'reflect'), (10000, 'zero'), (6000, 'symmetric'), (20000, 'reflect')])
 def test_short_signal_prestage_and_spectra_in_one_launch_emulated(S, orc, N, padtype, monkeypatch):
     """Short float32 signals (M = 8192 / 16384): `small_prestage_kernel` (pad + forward transform + analytic signal in
     one workgroup per signal) and `block_spectra_multi_kernel` (the P = 4096 / 8192 / 16384 classes' spectra in one
