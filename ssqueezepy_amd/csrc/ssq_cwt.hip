@@ -438,6 +438,18 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     // (a tile plan the selected kernel cannot run -- more rows than the ordered kernel's tile holds -- is decided
     // HERE, before any row is routed: those calls take the block kernels + the separate reassignment)
     const bool use_tiles = use_blocks && pl->tile && pl->tile->usable() && Tx && !w && sizeof(T) == 4;
+    // The first launch group's decimated samples need the spectra xh and nothing else: their kernels go to the side stream
+    // HERE, beside the analytic signal and the block spectra, not only beside the block rows (a short signal's ssq_cwt:
+    // their three launches are the longer branch). SSQ_DEBUG_EARLY_FORK=0: forked behind the block spectra, as before.
+    static const bool early_ok = !(getenv("SSQ_DEBUG_EARLY_FORK") && atoi(getenv("SSQ_DEBUG_EARLY_FORK")) == 0);
+    const bool early = early_ok && use_tiles && pl->tile->side && !tm;
+    if (early) {
+        SSQ_CHECK_HIP(hipEventRecord(pl->tile->ev_fork, stream));
+        SSQ_CHECK_HIP(hipStreamWaitEvent(pl->tile->side, pl->tile->ev_fork, 0));
+        int rc2 = pl->tile->spectra(0, (int)std::min<int64_t>(pl->group, batch), pl->xh, pl->tile->side);
+        if (rc2) return rc2;
+        SSQ_CHECK_HIP(hipEventRecord(pl->tile->ev_join, pl->tile->side));
+    }
     if (use_blocks) {
         int rc = pl->blk->spectra(pl->xp, pl->xh, batch, stream, use_tiles ? pl->tile->class_need.data() : nullptr);
         if (rc) return rc;
@@ -447,7 +459,7 @@ static int cwt_execute_t(ssq_cwt_plan* pl, const void* x, int64_t batch, void* W
     for (int64_t b0 = 0; b0 < batch; b0 += pl->group, ++slot) {
         const int ng = (int)std::min<int64_t>(pl->group, batch - b0);
         const bool fork = use_tiles && pl->tile->side && !tm;
-        if (use_tiles) {            // decimated samples of the interpolated rows: counted with stage 0
+        if (use_tiles && !(early && b0 == 0)) {   // decimated samples of the interpolated rows: counted with stage 0
             mark(2 + 4 * batch + 2 * slot);
             // (beside the block / exact kernels when not timing stage by stage; the fork also
             // orders this group's samples behind the previous group's tile kernel)
