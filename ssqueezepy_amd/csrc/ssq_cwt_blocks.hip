@@ -810,8 +810,9 @@ __global__ __launch_bounds__(NT) void block_spectra4096_kernel(BlockSpecArgs A) 
 // ones, and their spectra went gather kernel -> rocFFT's two-kernel transforms -> real-to-complex post-processing, six
 // launches of 3-7 us in a row on a call of 0.1 ms. Here one launch serves every class. A workgroup has 256 QMAX
 // threads (QMAX = the longest block / 4096 = 2 or 4) and runs CW = 4 QMAX columns of 1024 points through lds_ifft at
-// once (16 points per thread as everywhere; 8 and 16 columns keep the passes' LDS accesses nearly conflict-free, which
-// one column of 4096 points is far from): a block of P = 1024 C points is its C interleaved sub-sequences y[j C + r]
+// once (16 points per thread as everywhere; measured no faster than QMAX columns of 4096 points, whose passes' LDS
+// accesses conflict far more -- "r7c" / "r7d" of profiles/r6_ab_history.txt: the banks are not what bounds a launch of a
+// few workgroups): a block of P = 1024 C points is its C interleaved sub-sequences y[j C + r]
 // (the class' e^{2 pi i q / P} table read at every C-th entry), so a workgroup holds CW / C blocks ("slots": pairs of
 // real blocks as one complex sequence, or one analytic block, as above), and the last radix-C step
 //   Y'[f + 1024 s] = sum_r e^{2 pi i r f / P} e^{2 pi i r s / C} Z'_r[f]
@@ -821,11 +822,11 @@ __global__ __launch_bounds__(NT) void block_spectra4096_kernel(BlockSpecArgs A) 
 constexpr int WIDE_L = 1024;
 // the columns' transform: radices 16 x 8 x 8; entry z[k] = column g's point u + 64 k (g = tid % CW, u = tid / CW);
 // exit z[8 it + k] = its output u' + 128 k, u' = (tid + it NTH) / CW. Its twiddles e^{2 pi i q / 1024} come from an
-// 8 KB table in LDS (wide_stage_tw: every C-th entry of the class' table, one coalesced read at the kernel's start) --
-// a lone workgroup with cold caches pays a trip to memory for every dependent table read, and there were two per transform.
+// 8 KB table in LDS (wide_stage_tw: every C-th entry of the class' table, one coalesced read at the kernel's start,
+// beside the signal's loads, instead of two dependent table reads per transform: "r7e" -- worth 14 of 47 us to a kernel
+// that ran two transforms in a row in one workgroup, nothing measurable to this one).
 template <int CW, int C>
 __device__ __forceinline__ void wide_stage_tw(c32* __restrict__ stw, const c32* __restrict__ tw, int tid) {
-#pragma unroll
     for (int i = tid; i < WIDE_L; i += 64 * CW) stw[i] = tw[i * C];
 }
 template <int CW>
@@ -848,7 +849,7 @@ __device__ __forceinline__ void wide_load_w(c32 (&w)[PPT / C][C], const c32* __r
 // differ in r first) and the reads (consecutive n) off each other's banks.
 template <int CW, int C>
 __device__ __forceinline__ void wide_natural(const c32 (&z)[PPT], c32* __restrict__ buf, const c32 (&w)[PPT / C][C], int tid) {
-    constexpr int L = WIDE_L, P = L * C, NTH = 64 * CW, SL = CW / C;
+    constexpr int L = WIDE_L, P = L * C, NTH = 64 * CW;
     constexpr int NI = PPT / C;                                  // (slot, f) pairs per thread
     __syncthreads();                                             // (the last pass' reads)
 #pragma unroll
@@ -877,7 +878,6 @@ __device__ __forceinline__ void wide_natural(const c32 (&z)[PPT], c32* __restric
         for (int s2 = 0; s2 < C; ++s2) buf[sl * P + f + s2 * L] = y[i][s2];
     }
     __syncthreads();
-    (void)SL;
 }
 template <int CW, int C>
 __device__ __forceinline__ void block_spectra_wide(const BlockSpecArgs& A, const BlockClassDev& k, int b, c32* __restrict__ buf,
@@ -921,7 +921,6 @@ __device__ __forceinline__ void block_spectra_wide(const BlockSpecArgs& A, const
     }
     wide_ifft<CW>(z, buf, stw, tid);
     wide_natural<CW, C>(z, buf, w, tid);
-#pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
         const int unit = b * SL + sl;
         if (unit >= nunits) break;
